@@ -1,0 +1,93 @@
+"""ctypes binding of libuvc_hip.so (the C-ABI declared in include/*.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails this raises.
+`import torch` happens first on purpose -- torch bundles its own libamdhip64.so.7 and the
+library must bind to the SAME HIP runtime instance so that torch's device pointers and
+streams are valid inside our kernels (the dynamic loader reuses the already-loaded soname).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuvc_hip.so")
+
+
+class UvcHipError(RuntimeError):
+    pass
+
+
+class uvc_dims(C.Structure):
+    _fields_ = [("L", C.c_int32), ("H", C.c_int32), ("hd", C.c_int32), ("D", C.c_int32), ("F", C.c_int32)]
+
+
+class uvc_hyper(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("budget", "slr", "rlr", "glr", "ylr", "plr", "zlr", "sl2wd", "z_grad_clip",
+                                         "gating_weight", "eps")] + \
+               [(n, C.c_int32) for n in ("gating_interval", "use_gumbel", "enable_block_gating")]
+
+
+class uvc_state(C.Structure):
+    _fields_ = [("s", C.c_void_p), ("r", C.c_void_p), ("y", C.c_void_p), ("p", C.c_void_p), ("z", C.c_void_p),
+                ("gate", C.c_void_p), ("gate_grad", C.c_void_p), ("gate_momentum", C.c_void_p),
+                ("gate_gsum", C.c_void_p), ("gate_counters", C.c_void_p), ("total_macs", C.c_void_p),
+                ("embed_macs", C.c_float), ("resource_ub", C.c_float),
+                ("scores1", C.c_void_p), ("scores2", C.c_void_p), ("scores3", C.c_void_p),
+                ("rank1", C.c_void_p), ("rankh", C.c_void_p), ("rank3", C.c_void_p), ("out", C.c_void_p)]
+
+
+_lib = None
+VP = C.c_void_p
+
+_SIGNATURES = {
+    # include/uvc_engine.h
+    "uvc_scores": [VP, VP, uvc_dims, VP, VP, VP, VP, VP],
+    "uvc_rank": [VP, VP, VP, uvc_dims, VP, VP, VP, VP],
+    "uvc_prox": [VP, VP, uvc_dims, VP, VP, VP, VP, VP, VP, VP, C.c_double, VP, VP, VP, VP, VP],
+    "uvc_dual_step": [C.POINTER(uvc_state), uvc_dims, uvc_hyper, VP, VP, C.c_int32, C.c_int32, VP],
+    "uvc_resource": [C.POINTER(uvc_state), uvc_dims, uvc_hyper, VP, C.c_int32, VP, VP],
+    "uvc_write_masks": [VP, VP, VP, uvc_dims, VP, VP, VP, VP, VP, VP],
+}
+
+
+def exported_symbols():
+    return list(_SIGNATURES) + ["uvc_last_error"]
+
+
+def lib():
+    """Load (once) and return the CDLL.  Raises UvcHipError when the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UvcHipError(f"{LIB_PATH} not found: build it with `python -m uvc_amd.build` "
+                              "(there is no CPU fallback for the product path)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.uvc_last_error.restype = C.c_char_p
+        for name, args in _SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise UvcHipError(f"{what} failed (rc={rc}): {lib().uvc_last_error().decode()}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def cur_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise UvcHipError("uvc_amd runs on MI355X only: got a CPU tensor (no CPU fallback)")

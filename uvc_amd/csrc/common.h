@@ -1,0 +1,77 @@
+// Shared device/host helpers for the uvc_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UVC_OK 0
+#define UVC_ERR_ARG 1
+#define UVC_ERR_LAUNCH 2
+#define UVC_ERR_UNSUPPORTED 3
+
+#define UVC_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return uvc_set_error(e__, __FILE__, __LINE__); \
+  } while (0)
+
+int uvc_set_error(hipError_t e, const char* file, int line);
+int uvc_set_error_msg(int code, const char* msg);
+
+typedef uint16_t bf16_t;  // storage type: raw bfloat16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved (quiet)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct ElemIO;
+template <> struct ElemIO<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct ElemIO<bf16_t> {
+  static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// exact-erf GELU and its derivative (nn.GELU default, model_distilled.py:108,118)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,164 @@
+/* C-ABI of the DeiT Stage-1 compute kernels on MI355X (libuvc_hip.so): MFMA GEMMs with fused
+ * epilogues, LayerNorm, fused attention, distillation loss, fused clip+AdamW, token/gate helpers.
+ *
+ * The reference reaches these through ATen/cuBLAS/cuDNN from UVC/models/model_distilled.py,
+ * UVC/utils/losses.py and torch.optim; it has no operator/FFI layer of
+ * its own, so each entry point cites the reference lines whose arithmetic it performs.
+ *
+ * Conventions as in uvc_engine.h: device pointers owned by the caller, no allocation, no host
+ * sync, `stream` is a hipStream_t, int status return (0 = ok; uvc_last_error()).
+ * dtype selects the arithmetic: UVC_F32 = float32 storage + v_mfma_f32_16x16x4_f32 (exact fmaf
+ * chain; the 1e-3 parity mode), UVC_BF16 = bfloat16 operands + v_mfma_f32_16x16x32_bf16 with
+ * float32 accumulation (the throughput mode).  "T" below means float or bfloat16 accordingly.
+ */
+#ifndef UVC_KERNELS_H
+#define UVC_KERNELS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { UVC_F32 = 0, UVC_BF16 = 1 };
+
+enum {
+  UVC_EPI_NONE = 0,            /* C = alpha*acc                                                        */
+  UVC_EPI_BIAS = 1,            /* C = alpha*acc + bias[n]                       (nn.Linear)            */
+  UVC_EPI_BIAS_GELU = 2,       /* C = a = acc + bias ; C2 = GELU_erf(a)         (Mlp fc1+act, :116-118) */
+  UVC_EPI_BIAS_RESID = 3,      /* C = acc + bias + R[m,n]                       (x + proj(...), :240)   */
+  UVC_EPI_BIAS_RESID_GATE = 4, /* C = g1*(acc + bias + R[m,n]) + g0*R2[m,n]     (:244 then :493)        */
+  UVC_EPI_DGELU = 5            /* C = alpha*acc * GELU'(aux[m,n])               (backward of :118)      */
+};
+
+/* C[M,N] = epilogue( A[M,K] . B[N,K]^T ); A, B row-major with K contiguous. */
+typedef struct uvc_gemm_nt_args {
+  const void* A;       /* [M,K]  T, or float32 when a_is_f32 (converted to T while staging) */
+  const void* B;       /* [N,K]  T */
+  void* C;             /* [M,N]  T, or float32 when c_is_f32 */
+  void* C2;            /* second output of UVC_EPI_BIAS_GELU, same type/ld as C */
+  const float* bias;   /* [N] */
+  const float* R;      /* [M,N] float32 residual */
+  const float* R2;     /* [M,N] float32, gate epilogue */
+  const void* aux;     /* [M,N] T, pre-activation for UVC_EPI_DGELU */
+  const float* gate;   /* device float[2] = (g0, g1) block-gate distribution */
+  const float* alpha_ptr; /* optional device scalar multiplied into alpha */
+  float alpha;
+  int32_t M, N, K, lda, ldb, ldc, ldr, ldaux;
+  int32_t dtype, a_is_f32, c_is_f32, epilogue;
+} uvc_gemm_nt_args;
+int uvc_gemm_nt(const uvc_gemm_nt_args* args, void* stream);
+
+/* C[N1,N2] = beta*C + alpha * A[M,N1]^T . B[M,N2]  (weight gradients; float32 C).
+ * Deterministic: M is cut into slices reduced in a fixed order through `workspace`. */
+typedef struct uvc_gemm_tn_args {
+  const void* A;       /* [M,N1] T, or float32 when a_is_f32 */
+  const void* B;       /* [M,N2] T */
+  float* C;            /* [N1,N2] float32 */
+  void* workspace;     /* >= uvc_gemm_tn_workspace_bytes() */
+  int64_t workspace_bytes;
+  const float* alpha_ptr;
+  float alpha, beta;
+  int32_t M, N1, N2, lda, ldb, ldc;
+  int32_t dtype, a_is_f32;
+} uvc_gemm_tn_args;
+int uvc_gemm_tn(const uvc_gemm_tn_args* args, void* stream);
+int uvc_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2, int64_t* bytes, int32_t* splits);
+
+/* Fused softmax(q k^T * scale) v for one DeiT sequence per (batch, head)
+ * (UVC/models/model_distilled.py:175-185).  qkv is the packed Linear(dim, 3*dim) output
+ * [B, N, 3, H, 64]; o is [B, N, H*64]; lse/delta are float32 [B, H, N].  N <= 256, head_dim = 64. */
+typedef struct uvc_attn_args {
+  const void* qkv;   /* T */
+  void* o;           /* T  (forward output; backward input) */
+  float* lse;        /* log-sum-exp of the scaled scores (forward output; backward input) */
+  const void* dout;  /* T  [B,N,H*64]      backward only */
+  void* dqkv;        /* T  [B,N,3,H,64]    backward output */
+  float* delta;      /* scratch [B,H,N]    backward only */
+  int32_t B, N, H, head_dim, dtype;
+  float scale;
+} uvc_attn_args;
+int uvc_attention_fwd(const uvc_attn_args* args, void* stream);
+int uvc_attention_bwd(const uvc_attn_args* args, void* stream);
+
+/* nn.LayerNorm(D, eps) forward over `rows` rows (model_distilled.py:199,204,288; eps=1e-6 from
+ * joint_train.py:138).  Row r of x starts at x + (r / rows_per_group) * group_stride + (r % rows_per_group) * D
+ * (dense: rows_per_group = 1, group_stride = D; class/dist-token rows only: group_stride = N*D).
+ * y is dense [rows, D] of type T (or float32 when y_is_f32); mean/rstd float32 [rows]. */
+typedef struct uvc_ln_args {
+  const float* x; const float* gamma; const float* beta;
+  void* y; float* mean; float* rstd;
+  /* backward */
+  const void* dy;       /* dense [rows, D]; T, or float32 when dy_is_f32 */
+  float* dx;            /* same row addressing as x; dx = LN'(dy) + a1*add1 + a2*add2 */
+  const float* add1; const float* a1;   /* optional dense-as-x addends; a1/a2 device scalars (NULL = 1) */
+  const float* add2; const float* a2;
+  float* partial;       /* scratch [ln_bwd_blocks, 2*D + 2] */
+  float* dgamma; float* dbeta;          /* [D], written as beta_acc*old + sum */
+  float* dots;          /* optional [2]: { <dx, x>, <add2, x> } over all rows (gate-logit gradients) */
+  float eps, beta_acc;
+  int32_t rows, D, rows_per_group, dtype, y_is_f32, dy_is_f32;
+  int64_t group_stride;
+} uvc_ln_args;
+int uvc_layernorm_fwd(const uvc_ln_args* args, void* stream);
+int uvc_layernorm_bwd(const uvc_ln_args* args, void* stream);
+int uvc_layernorm_bwd_blocks(int32_t rows);
+
+/* DistillationLoss over SoftTargetCrossEntropy (UVC/utils/losses.py:25-65, joint_train.py:940):
+ * loss = (1-alpha) * mean_b sum_c -y log_softmax(o) + alpha * KL(softmax(t/T) || softmax(o_kd/T)) * T^2 / (B*C).
+ * All float32 [B,C].  Writes loss[0] and the gradients d_o, d_okd (d_okd may alias d_o when
+ * o_kd == o, i.e. enable_deit = 0: the two contributions are summed). */
+typedef struct uvc_loss_args {
+  const float* o; const float* o_kd; const float* y_soft; const float* teacher;
+  float* loss; float* d_o; float* d_okd; float* row_scratch; /* [B] */
+  float alpha, tau;
+  int32_t B, C, kind; /* kind: 0 none, 1 soft */
+} uvc_loss_args;
+int uvc_distill_loss(const uvc_loss_args* args, void* stream);
+
+/* clip_grad_norm_(max_norm) + AdamW over flat float32 buffers (joint_train.py:428-429;
+ * torch.optim.AdamW(lr, betas, eps, weight_decay) semantics, decoupled decay).
+ * uvc_grad_sqnorm accumulates sum(g^2) of a segment into sq[0] (call once per segment after zeroing);
+ * uvc_adamw_step applies clip coefficient min(1, max_norm/(sqrt(sq[0])+1e-6)) read on the device. */
+int uvc_grad_sqnorm(const float* g, int64_t n, float* partial /*[1024]*/, float* sq, int32_t accumulate, void* stream);
+typedef struct uvc_adamw_args {
+  float* p; const float* g; float* m; float* v;
+  void* p_shadow;        /* optional bf16 copy of p (GEMM operands), same layout */
+  const float* sq;       /* device: total squared grad norm */
+  float* gnorm_out;      /* optional device float: total norm (pre-clip) */
+  int64_t n;
+  float lr, beta1, beta2, eps, weight_decay, max_norm;
+  int32_t step;          /* this segment's 1-based step count (bias correction) */
+} uvc_adamw_args;
+int uvc_adamw_step(const uvc_adamw_args* args, void* stream);
+/* g *= clip coefficient (so later readers see what clip_grad_norm_ left in .grad; uvc_optimizer.py:90 reads it). */
+int uvc_scale_by_clip(float* g, int64_t n, const float* sq, float max_norm, void* stream);
+
+/* misc elementwise / layout kernels */
+/* im2col of 16x16/stride-16 patches (PatchEmbed conv as a GEMM, model_distilled.py:142-151):
+ * x [B,C,S,S] float32 -> out [B*(S/P)^2, C*P*P] T, k = c*P*P + ky*P + kx. */
+int uvc_patchify(const float* x, void* out, int32_t B, int32_t C, int32_t S, int32_t P, int32_t dtype, void* stream);
+/* tokens = cat(cls[, dist], patches * mask) + pos  (model_distilled.py:434-471).
+ * pe [B,P,D] float32; row_mask optional [B,P] (patch gating), tok [B,N,D] float32. */
+int uvc_assemble_tokens(const float* pe, const float* cls, const float* dist, const float* pos, const float* row_mask,
+                        float* tok, int32_t B, int32_t P, int32_t D, int32_t ntok, void* stream);
+/* backward of uvc_assemble_tokens: dpe [B,P,D] (T or f32) = dtok rows * mask; dpos/dcls/ddist = sums over batch
+ * (written as beta_acc*old + sum); optional dmask[B,P] = <dtok row, pe row>. */
+int uvc_assemble_tokens_bwd(const float* dtok, const float* pe, const float* row_mask, void* dpe, float* dpos, float* dcls,
+                            float* ddist, float* dmask, int32_t B, int32_t P, int32_t D, int32_t ntok, int32_t dtype,
+                            int32_t dpe_is_f32, float beta_acc, void* stream);
+/* column sums: out[n] = beta*out[n] + alpha * sum_m X[m,n];  X is T or float32.  partial: [uvc_colsum_blocks(M), N]. */
+int uvc_colsum(const void* X, int32_t M, int32_t N, int32_t ldx, int32_t dtype, int32_t x_is_f32, float* partial, float* out,
+               float alpha, const float* alpha_ptr, float beta, void* stream);
+int uvc_colsum_blocks(int32_t M);
+/* float32 -> bf16 copy and transposed copy of a [R,C] matrix (weight shadows for the GEMMs). */
+int uvc_cast_transpose(const float* W, int32_t R, int32_t C, void* w_bf16, void* wt, int32_t dtype, void* stream);
+/* block-gate distributions (model_distilled.py:480-488): d[L,2] from g[L,2] and Exp(1) draws. */
+int uvc_gate_distrib(const float* g, const float* e, float* d, int32_t L, int32_t mode, float eps, void* stream);
+/* gradient of the gate logits from the two dot products per block:
+ * dots [L,2] = { <gA, out>, <gA, x> }; dg written as beta_acc*old + grad. */
+int uvc_gate_grad(const float* g, const float* d, const float* dots, float* dg, int32_t L, int32_t mode, float eps,
+                  float beta_acc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

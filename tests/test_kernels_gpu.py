@@ -1,0 +1,314 @@
+"""GPU: each floating-point HIP kernel (through the C-ABI) against a plain PyTorch float32/float64
+reference of the same op, float32-exact mode at tight tolerance and bf16 mode at the tolerance the
+bf16 operands allow (stated per test).  Ragged / edge shapes included."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = 0, 1
+
+
+def dev():
+    return torch.device("cuda")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+def to_t(x, dtype):
+    return x if dtype == F32 else x.to(torch.bfloat16)
+
+
+def tol(dtype):
+    # float32 MFMA is an exact fmaf chain: only summation order differs from torch.  bf16 operands
+    # carry 2^-9 relative rounding each; accumulation is float32.
+    return dict(rtol=2e-5, atol=2e-5) if dtype == F32 else dict(rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N,K", [(1576, 576, 192), (100, 1000, 192), (130, 10, 128), (257, 192, 768), (64, 64, 64)])
+def test_gemm_nt_bias(dtype, M, N, K):
+    from uvc_amd import ops
+    A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    At, Bt = to_t(A, dtype), to_t(B, dtype)
+    ref = At.double() @ Bt.double().t() + bias.double()
+    for cf32 in ([True] if dtype == F32 else [True, False]):
+        Cc = torch.empty(M, N, device=dev(), dtype=torch.float32 if cf32 else torch.bfloat16)
+        ops.gemm_nt(At, Bt, Cc, dtype=dtype, epilogue=ops.EPI_BIAS, bias=bias)
+        t = tol(dtype) if cf32 else dict(rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(Cc.double(), ref, **t)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gemm_nt_f32_source_and_epilogues(dtype):
+    from uvc_amd import ops
+    M, N, K = 333, 192, 768
+    A, B, bias = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.05), rnd(N, seed=6)
+    R, R2 = rnd(M, N, seed=7), rnd(M, N, seed=8)
+    gate = torch.tensor([0.3, 0.7], device=dev())
+    Bt = to_t(B, dtype)
+    Aeff = A if dtype == F32 else A.to(torch.bfloat16)
+    lin = Aeff.double() @ Bt.double().t() + bias.double()
+    # residual (float32 A source converted while staging)
+    Cc = torch.empty(M, N, device=dev())
+    ops.gemm_nt(A, Bt, Cc, dtype=dtype, epilogue=ops.EPI_BIAS_RESID, bias=bias, R=R)
+    torch.testing.assert_close(Cc.double(), lin + R.double(), **tol(dtype))
+    ops.gemm_nt(A, Bt, Cc, dtype=dtype, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bias, R=R, R2=R2, gate=gate)
+    torch.testing.assert_close(Cc.double(), 0.7 * (lin + R.double()) + 0.3 * R2.double(), **tol(dtype))
+    # GELU pair
+    T = ops.tdtype(dtype)
+    Ca, Cu = torch.empty(M, N, device=dev(), dtype=T), torch.empty(M, N, device=dev(), dtype=T)
+    ops.gemm_nt(to_t(A, dtype), Bt, Ca, dtype=dtype, epilogue=ops.EPI_BIAS_GELU, bias=bias, C2=Cu)
+    torch.testing.assert_close(Ca.double(), lin, **tol(dtype))
+    torch.testing.assert_close(Cu.double(), F.gelu(lin), **tol(dtype))
+    # dGELU with device alpha
+    aux = to_t(rnd(M, N, seed=9), dtype)
+    alpha = torch.tensor([0.6], device=dev())
+    Cd = torch.empty(M, N, device=dev(), dtype=T)
+    ops.gemm_nt(A, Bt, Cd, dtype=dtype, epilogue=ops.EPI_DGELU, aux=aux, alpha_ptr=alpha)
+    x = aux.double().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    torch.testing.assert_close(Cd.double(), 0.6 * (Aeff.double() @ Bt.double().t()) * x.grad, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N1,N2", [(1576, 576, 192), (403, 192, 768), (64, 1000, 192), (5000, 128, 128), (40, 8, 16)])
+def test_gemm_tn(dtype, M, N1, N2):
+    from uvc_amd import ops
+    A, B = rnd(M, N1, seed=11), rnd(M, N2, seed=12)
+    Cc = rnd(N1, N2, seed=13)
+    C0 = Cc.clone()
+    ws = torch.empty(ops.gemm_tn_workspace_bytes(M, N1, N2) // 4, device=dev())
+    alpha = torch.tensor([0.5], device=dev())
+    for a_f32 in ([True] if dtype == F32 else [True, False]):
+        At = A if a_f32 else A.to(torch.bfloat16)
+        Bt = to_t(B, dtype)
+        Aeff = A.to(torch.bfloat16) if dtype == BF16 else A
+        Cc.copy_(C0)
+        ops.gemm_tn(At, Bt, Cc, ws, dtype=dtype, alpha=2.0, alpha_ptr=alpha, beta=1.0)
+        ref = C0.double() + Aeff.double().t() @ Bt.double()
+        t = dict(rtol=2e-5, atol=2e-4) if dtype == F32 else dict(rtol=2e-2, atol=5e-2)
+        torch.testing.assert_close(Cc.double(), ref, **t)
+    # determinism: two runs bit-identical
+    C1, C2 = torch.empty(N1, N2, device=dev()), torch.empty(N1, N2, device=dev())
+    ops.gemm_tn(to_t(A, dtype), to_t(B, dtype), C1, ws, dtype=dtype)
+    ops.gemm_tn(to_t(A, dtype), to_t(B, dtype), C2, ws, dtype=dtype)
+    assert torch.equal(C1, C2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (3, 198, 2), (2, 17, 2), (1, 64, 1), (2, 5, 1)])
+def test_attention_fwd_bwd(dtype, B, N, H):
+    from uvc_amd import ops
+    D = H * 64
+    T = ops.tdtype(dtype)
+    qkv = to_t(rnd(B, N, 3 * D, seed=21), dtype)
+    dout = to_t(rnd(B, N, D, seed=22), dtype)
+    o = torch.empty(B, N, D, device=dev(), dtype=T)
+    lse = torch.empty(B, H, N, device=dev())
+    ops.attention_fwd(qkv, o, lse, B, N, H, dtype)
+    x = qkv.double().requires_grad_(True)
+    q, k, v = x.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * 64 ** -0.5
+    ref = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, N, D)
+    t = dict(rtol=1e-4, atol=1e-5) if dtype == F32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(o.double(), ref, **t)
+    torch.testing.assert_close(lse.double(), torch.logsumexp(s, -1), rtol=1e-4 if dtype == F32 else 2e-2, atol=1e-4 if dtype == F32 else 2e-2)
+    dqkv = torch.full((B, N, 3 * D), float("nan"), device=dev(), dtype=T)
+    delta = torch.empty(B, H, N, device=dev())
+    ops.attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype)
+    ref.backward(dout.double())
+    tb = dict(rtol=2e-4, atol=2e-5) if dtype == F32 else dict(rtol=5e-2, atol=6e-2)
+    torch.testing.assert_close(dqkv.double(), x.grad, **tb)
+
+
+def test_attention_softmax_extremes_f32():
+    """Rows dominated by one key (large logits) and identical keys: no NaN/inf, matches float64."""
+    from uvc_amd import ops
+    B, N, H = 1, 40, 1
+    qkv = rnd(B, N, 192, seed=23)
+    qkv[0, 3, :64] *= 40.0
+    qkv[0, :, 64:128] = qkv[0, 0, 64:128]          # all keys identical -> uniform attention
+    qkv[0, 5, 64:128] *= 30.0
+    o = torch.empty(B, N, 64, device=dev()); lse = torch.empty(B, H, N, device=dev())
+    ops.attention_fwd(qkv, o, lse, B, N, H, F32)
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (((q @ k.transpose(-2, -1)) * 0.125).softmax(-1) @ v).transpose(1, 2).reshape(B, N, 64)
+    assert torch.isfinite(o).all()
+    torch.testing.assert_close(o.double(), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("rows,D", [(1576, 192), (333, 384), (130, 768), (7, 128)])
+def test_layernorm_fwd_bwd(dtype, rows, D):
+    from uvc_amd import ops
+    T = ops.tdtype(dtype)
+    x, gamma, beta = rnd(rows, D, seed=31) * 2 + 0.5, rnd(D, seed=32) * 0.2 + 1.0, rnd(D, seed=33) * 0.1
+    y = torch.empty(rows, D, device=dev(), dtype=T)
+    mean, rstd = torch.empty(rows, device=dev()), torch.empty(rows, device=dev())
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, dtype)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = F.layer_norm(xd, (D,), gd, bd, 1e-6)
+    torch.testing.assert_close(y.double(), ref, **(dict(rtol=1e-5, atol=1e-5) if dtype == F32 else dict(rtol=1e-2, atol=1e-2)))
+    dy = to_t(rnd(rows, D, seed=34), dtype)
+    add1, add2 = rnd(rows, D, seed=35), rnd(rows, D, seed=36)
+    a1, a2 = torch.tensor([0.7], device=dev()), torch.tensor([0.3], device=dev())
+    dx = torch.empty(rows, D, device=dev())
+    partial = torch.empty(ops.layernorm_bwd_blocks(rows) * (2 * D + 2), device=dev())
+    dg, db, dots = torch.ones(D, device=dev()), torch.ones(D, device=dev()), torch.empty(2, device=dev())
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dg, db, rows, D, dtype, add1=add1, a1=a1, add2=add2, a2=a2,
+                      dots=dots, beta_acc=1.0)
+    ref.backward(dy.double())
+    dxr = xd.grad + 0.7 * add1.double() + 0.3 * add2.double()
+    torch.testing.assert_close(dx.double(), dxr, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dg.double(), 1 + gd.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.double(), 1 + bd.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dots.double(), torch.stack([(dxr * x.double()).sum(), (add2.double() * x.double()).sum()]),
+                               rtol=1e-4, atol=1e-2)
+
+
+def test_layernorm_class_token_rows():
+    """Final norm on the class/dist-token rows only (model_distilled.py:507-508): strided rows."""
+    from uvc_amd import ops
+    B, N, D = 5, 198, 192
+    x, gamma, beta = rnd(B, N, D, seed=37), rnd(D, seed=38) + 1, rnd(D, seed=39)
+    for rpg in (1, 2):
+        rows = B * rpg
+        y = torch.empty(rows, D, device=dev()); mean = torch.empty(rows, device=dev()); rstd = torch.empty(rows, device=dev())
+        ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, F32, rows_per_group=rpg, group_stride=N * D)
+        ref = F.layer_norm(x[:, :rpg].double(), (D,), gamma.double(), beta.double(), 1e-6).reshape(rows, D)
+        torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
+        dy = rnd(rows, D, seed=40)
+        dx = torch.zeros(B, N, D, device=dev())
+        partial = torch.empty(ops.layernorm_bwd_blocks(rows) * (2 * D + 2), device=dev())
+        dg, db, dots = torch.empty(D, device=dev()), torch.empty(D, device=dev()), torch.empty(2, device=dev())
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dg, db, rows, D, F32, dots=dots, rows_per_group=rpg,
+                          group_stride=N * D)
+        xd = x.double().requires_grad_(True)
+        F.layer_norm(xd[:, :rpg], (D,), gamma.double(), beta.double(), 1e-6).backward(dy.double().reshape(B, rpg, D))
+        torch.testing.assert_close(dx.double(), xd.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,same", [(8, 1000, True), (5, 10, True), (6, 1000, False)])
+def test_distill_loss(B, C, same):
+    from uvc_amd import ops
+    o, y, t = rnd(B, C, seed=41) * 2, F.softmax(rnd(B, C, seed=42) * 2, -1), rnd(B, C, seed=43) * 2
+    okd = o if same else rnd(B, C, seed=44)
+    loss = torch.empty(1, device=dev()); d_o = torch.empty(B, C, device=dev())
+    d_k = d_o if same else torch.empty(B, C, device=dev())
+    scratch = torch.empty(B, device=dev())
+    alpha, tau = 0.1, 2.0
+    ops.distill_loss(o, okd, y, t, loss, d_o, d_k, scratch, alpha, tau, kind=1)
+    od = o.double().requires_grad_(True)
+    kd_in = od if same else okd.double().requires_grad_(True)
+    base = torch.sum(-y.double() * F.log_softmax(od, -1), -1).mean()
+    kd = F.kl_div(F.log_softmax(kd_in / tau, 1), F.log_softmax(t.double() / tau, 1), reduction="sum", log_target=True) * tau * tau / (B * C)
+    ref = base * (1 - alpha) + kd * alpha
+    ref.backward()
+    torch.testing.assert_close(loss.double()[0], ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(d_o.double(), od.grad, rtol=1e-4, atol=1e-7)
+    if not same:
+        torch.testing.assert_close(d_k.double(), kd_in.grad, rtol=1e-4, atol=1e-8)
+
+
+def test_clip_adamw_matches_torch():
+    from uvc_amd import ops
+    n = 100003
+    p0, g0 = rnd(n, seed=51), rnd(n, seed=52) * 0.01
+    P = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([P], lr=3e-4, weight_decay=0.05)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    shadow = torch.empty(n, device=dev(), dtype=torch.bfloat16)
+    partial, sq, gn = torch.empty(1024, device=dev()), torch.empty(1, device=dev()), torch.empty(1, device=dev())
+    for step in range(1, 4):
+        g = g0 * step
+        P.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([P], 1.0)
+        opt.step()
+        ops.grad_sqnorm(g, partial, sq)
+        ops.adamw_step(p, g, m, v, sq, lr=3e-4, step=step, p_shadow=shadow, gnorm_out=gn)
+        torch.testing.assert_close(gn[0], tn, rtol=1e-5, atol=0)
+        torch.testing.assert_close(p, P.data, rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(shadow.float(), P.data.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-3)
+    gg = g0.clone()
+    ops.scale_by_clip(gg, sq, 1.0)
+    torch.testing.assert_close(gg, g0 * min(1.0, 1.0 / (float(sq.sqrt()) + 1e-6)), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_patchify_assemble_colsum_transpose(dtype):
+    from uvc_amd import ops
+    B, S, P, D, ntok = 3, 64, 16, 128, 2
+    T = ops.tdtype(dtype)
+    x = rnd(B, 3, S, S, seed=61)
+    npatch = (S // P) ** 2
+    out = torch.empty(B * npatch, 3 * P * P, device=dev(), dtype=T)
+    ops.patchify(x, out, P, dtype)
+    ref = F.unfold(x, P, stride=P).transpose(1, 2).reshape(B * npatch, -1)
+    torch.testing.assert_close(out.float(), ref.to(T).float(), rtol=0, atol=0)
+    pe, cls, dist, pos = rnd(B, npatch, D, seed=62), rnd(D, seed=63), rnd(D, seed=64), rnd(npatch + ntok, D, seed=65)
+    mask = (rnd(B, npatch, seed=66) > 0).float()
+    tok = torch.empty(B, npatch + ntok, D, device=dev())
+    ops.assemble_tokens(pe, cls, dist, pos, mask, tok, B, npatch, D, ntok)
+    reft = torch.cat([cls.expand(B, 1, D), dist.expand(B, 1, D), pe * mask.unsqueeze(-1)], 1) + pos
+    torch.testing.assert_close(tok, reft, rtol=0, atol=0)
+    dtok = rnd(B, npatch + ntok, D, seed=67)
+    dpe = torch.empty(B, npatch, D, device=dev(), dtype=T)
+    dpos, dcls, ddist, dmask = (torch.empty(npatch + ntok, D, device=dev()), torch.empty(D, device=dev()),
+                                torch.empty(D, device=dev()), torch.empty(B, npatch, device=dev()))
+    ops.assemble_tokens_bwd(dtok, pe, mask, dpe, dpos, dcls, ddist, dmask, B, npatch, D, ntok, dtype)
+    torch.testing.assert_close(dpe.float(), (dtok[:, ntok:] * mask.unsqueeze(-1)).to(T).float(), rtol=0, atol=0)
+    torch.testing.assert_close(dpos, dtok.sum(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dcls, dtok[:, 0].sum(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ddist, dtok[:, 1].sum(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dmask, (dtok[:, ntok:] * pe).sum(-1), rtol=1e-4, atol=1e-4)
+    for M, N in ((1576, 576), (300, 10), (5, 1000)):
+        X = to_t(rnd(M, N, seed=68), dtype)
+        partial = torch.empty(ops.colsum_blocks(M) * N, device=dev())
+        o = torch.ones(N, device=dev())
+        ops.colsum(X, partial, o, dtype, alpha=2.0, beta=1.0)
+        torch.testing.assert_close(o.double(), 1 + 2 * X.double().sum(0), rtol=1e-4, atol=1e-3)
+    W = rnd(192, 576, seed=69)
+    wc, wt = torch.empty(192, 576, device=dev(), dtype=T), torch.empty(576, 192, device=dev(), dtype=T)
+    ops.cast_transpose(W, 192, 576, wc, wt, dtype)
+    assert torch.equal(wc, W.to(T)) and torch.equal(wt, W.to(T).t().contiguous())
+
+
+def test_gate_distrib_and_grad():
+    from uvc_amd import ops
+    Lb = 12
+    g = rnd(Lb, 2, seed=71)
+    e = torch.empty(Lb, 2, device=dev()).exponential_()
+    d = torch.empty(Lb, 2, device=dev())
+    ops.gate_distrib(g, e, d, Lb, 1, 0.1)
+    ref = ((g + (-e.log())) / 0.5).softmax(-1)
+    torch.testing.assert_close(d, ref, rtol=1e-5, atol=1e-6)
+    ops.gate_distrib(g, e, d, Lb, 0, 0.1)
+    assert torch.equal(d, torch.full_like(d, 0.5))
+    ops.gate_distrib(g, e, d, Lb, 2, 0.1)
+    t = g[:, 1] ** 2
+    torch.testing.assert_close(d[:, 1], t / (t + 0.1), rtol=1e-6, atol=1e-7)
+    # gradient identities: out = d1*x2 + d0*x ; A = <gA,out>, B = <gA,x>
+    for mode in (1, 2):
+        gd = g.double().requires_grad_(True)
+        if mode == 1:
+            dd = ((gd + (-e.double().log())) / 0.5).softmax(-1)
+        else:
+            d1 = gd[:, 1] ** 2 / (gd[:, 1] ** 2 + 0.1)
+            dd = torch.stack([1 - d1, d1], 1)
+        gx2, gx = rnd(Lb, seed=72).double(), rnd(Lb, seed=73).double()       # <gA,x2>, <gA,x> per block
+        (dd[:, 1] * gx2 + dd[:, 0] * gx).sum().backward()
+        A = (dd[:, 1] * gx2 + dd[:, 0] * gx).detach()
+        dots = torch.stack([A, gx], 1).float().contiguous()
+        ops.gate_distrib(g, e, d, Lb, mode, 0.1)
+        dg = torch.empty(Lb, 2, device=dev())
+        ops.gate_grad(g, d, dots, dg, Lb, mode, 0.1)
+        torch.testing.assert_close(dg.double(), gd.grad, rtol=1e-3, atol=1e-5)

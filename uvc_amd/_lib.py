@@ -39,8 +39,49 @@ class uvc_state(C.Structure):
                 ("rank1", C.c_void_p), ("rankh", C.c_void_p), ("rank3", C.c_void_p), ("out", C.c_void_p)]
 
 
+class uvc_gemm_nt_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("A", "B", "C", "C2", "bias", "R", "R2", "aux", "gate", "alpha_ptr")] + \
+               [("alpha", C.c_float)] + \
+               [(n, C.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldr", "ldaux", "dtype", "a_is_f32",
+                                         "c_is_f32", "epilogue")]
+
+
+class uvc_gemm_tn_args(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_int64), ("alpha_ptr", C.c_void_p), ("alpha", C.c_float), ("beta", C.c_float)] + \
+               [(n, C.c_int32) for n in ("M", "N1", "N2", "lda", "ldb", "ldc", "dtype", "a_is_f32")]
+
+
+class uvc_attn_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv", "o", "lse", "dout", "dqkv", "delta")] + \
+               [(n, C.c_int32) for n in ("B", "N", "H", "head_dim", "dtype")] + [("scale", C.c_float)]
+
+
+class uvc_ln_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "gamma", "beta", "y", "mean", "rstd", "dy", "dx", "add1", "a1", "add2",
+                                          "a2", "partial", "dgamma", "dbeta", "dots")] + \
+               [("eps", C.c_float), ("beta_acc", C.c_float)] + \
+               [(n, C.c_int32) for n in ("rows", "D", "rows_per_group", "dtype", "y_is_f32", "dy_is_f32")] + \
+               [("group_stride", C.c_int64)]
+
+
+class uvc_loss_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("o", "o_kd", "y_soft", "teacher", "loss", "d_o", "d_okd", "row_scratch")] + \
+               [("alpha", C.c_float), ("tau", C.c_float), ("B", C.c_int32), ("C", C.c_int32), ("kind", C.c_int32)]
+
+
+class uvc_adamw_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("p", "g", "m", "v", "p_shadow", "sq", "gnorm_out")] + [("n", C.c_int64)] + \
+               [(n, C.c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "max_norm")] + \
+               [("step", C.c_int32)]
+
+
+UVC_F32, UVC_BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU = range(6)
+
 _lib = None
 VP = C.c_void_p
+I32, I64, F32 = C.c_int32, C.c_int64, C.c_float
 
 _SIGNATURES = {
     # include/uvc_engine.h
@@ -50,6 +91,27 @@ _SIGNATURES = {
     "uvc_dual_step": [C.POINTER(uvc_state), uvc_dims, uvc_hyper, VP, VP, C.c_int32, C.c_int32, VP],
     "uvc_resource": [C.POINTER(uvc_state), uvc_dims, uvc_hyper, VP, C.c_int32, VP, VP],
     "uvc_write_masks": [VP, VP, VP, uvc_dims, VP, VP, VP, VP, VP, VP],
+    # include/uvc_kernels.h
+    "uvc_gemm_nt": [C.POINTER(uvc_gemm_nt_args), VP],
+    "uvc_gemm_tn": [C.POINTER(uvc_gemm_tn_args), VP],
+    "uvc_gemm_tn_workspace_bytes": [I32, I32, I32, C.POINTER(I64), C.POINTER(I32)],
+    "uvc_attention_fwd": [C.POINTER(uvc_attn_args), VP],
+    "uvc_attention_bwd": [C.POINTER(uvc_attn_args), VP],
+    "uvc_layernorm_fwd": [C.POINTER(uvc_ln_args), VP],
+    "uvc_layernorm_bwd": [C.POINTER(uvc_ln_args), VP],
+    "uvc_layernorm_bwd_blocks": [I32],
+    "uvc_distill_loss": [C.POINTER(uvc_loss_args), VP],
+    "uvc_grad_sqnorm": [VP, I64, VP, VP, I32, VP],
+    "uvc_adamw_step": [C.POINTER(uvc_adamw_args), VP],
+    "uvc_scale_by_clip": [VP, I64, VP, F32, VP],
+    "uvc_patchify": [VP, VP, I32, I32, I32, I32, I32, VP],
+    "uvc_assemble_tokens": [VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, VP],
+    "uvc_assemble_tokens_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, I32, I32, F32, VP],
+    "uvc_colsum": [VP, I32, I32, I32, I32, I32, VP, VP, F32, VP, F32, VP],
+    "uvc_colsum_blocks": [I32],
+    "uvc_cast_transpose": [VP, I32, I32, VP, VP, I32, VP],
+    "uvc_gate_distrib": [VP, VP, VP, I32, I32, F32, VP],
+    "uvc_gate_grad": [VP, VP, VP, VP, I32, I32, F32, F32, VP],
 }
 
 

@@ -1,0 +1,426 @@
+// Fused multi-head attention forward/backward for DeiT sequences (N <= 256, head_dim = 64) on gfx950.
+// Reference arithmetic: UVC/models/model_distilled.py:175-185  (softmax(q k^T * hd^-0.5) v, dropout p=0).
+//
+// One workgroup (4 waves) per (batch, head).  N = 197/198 means a whole head's K and V fit in LDS
+// (bf16: 2 x 224 x 144 B = 63 KB), so there is no online-softmax rescaling: each wave owns 16-row
+// query tiles, computes S^T = K Q^T with the keys on the MFMA rows and the query on the lane
+// (lane & 15), so the softmax row lives in one lane's registers + 2 wave shuffles, and P^T is
+// already the B operand of O^T = V^T P^T.  V^T / K^T / Q^T / dO^T operands are gathered straight
+// from the row-major LDS image with ds_read_b64_tr_b16 (bf16) or ds_read_b32 (float32 mode).
+//
+// Backward is two kernels with the same structure:
+//   dQ  kernel: per query tile   S^T, dP^T = V dO^T, dS^T -> dQ^T = K^T dS^T     (K, V in LDS)
+//   dKV kernel: per key tile     S = Q K^T, dP = dO V^T, dS -> dV^T = dO^T P, dK^T = Q^T dS  (Q, dO in LDS)
+#include "common.h"
+#include "../../include/uvc_kernels.h"
+
+namespace {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int CH = 8, KSTEP = 32;
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  // two accumulator tiles (8 floats: keys/queries 4g+{0..3} of tile A then tile B) -> operand fragment
+  static __device__ __forceinline__ Frag pack(const f32x4& lo, const f32x4& hi) {
+    u32x4 r;
+    r[0] = pack_bf16x2(lo[0], lo[1]); r[1] = pack_bf16x2(lo[2], lo[3]);
+    r[2] = pack_bf16x2(hi[0], hi[1]); r[3] = pack_bf16x2(hi[2], hi[3]);
+    return __builtin_bit_cast(Frag, r);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int CH = 4, KSTEP = 16;
+  typedef f32x4 Frag;
+  static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ Frag pack(const f32x4& lo, const f32x4&) { return lo; }
+};
+
+template <typename T> struct TrFrag;
+template <> struct TrFrag<bf16_t> {
+  static __device__ __forceinline__ bf16x8 ld(const char* tile, int ld, int k0, int c0, int lane) {
+    const int i = lane & 15, gq = lane >> 4;
+    const char* p = tile + (k0 + 4 * gq + (i >> 2)) * ld + (c0 + (i & 3) * 4) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(p + 16 * ld));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+template <> struct TrFrag<float> {
+  static __device__ __forceinline__ f32x4 ld(const char* tile, int ld, int k0, int c0, int lane) {
+    const int i = lane & 15, gq = lane >> 4;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float*>(tile + (k0 + 4 * gq + j) * ld + (c0 + i) * 4);
+    return v;
+  }
+};
+
+constexpr int HD = 64;
+template <typename T> struct Geom {
+  static constexpr int ROWB = HD * (int)sizeof(T) + 16;      // LDS row stride (bytes)
+  static constexpr int KS = HD / Mma<T>::KSTEP;              // MFMA k-steps across head_dim
+  static constexpr int TPS = Mma<T>::KSTEP / 16;             // 16-row tiles consumed per "pair" step (2 bf16, 1 f32)
+};
+
+// stage `rows` rows of 64 T (row stride ld_g elements) into LDS rows of ROWB bytes; rows >= nvalid zero
+template <typename T>
+__device__ __forceinline__ void stage_rows(char* lds, const T* g, size_t ld_g, int nvalid, int nrows_pad) {
+  constexpr int CPR = HD / Mma<T>::CH;                        // chunks per row
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (int id = threadIdx.x; id < nrows_pad * CPR; id += blockDim.x) {
+    const int row = id / CPR, c = id % CPR;
+    const u32x4 v = row < nvalid ? *reinterpret_cast<const u32x4*>(g + (size_t)row * ld_g + c * Mma<T>::CH) : z;
+    *reinterpret_cast<u32x4*>(lds + row * Geom<T>::ROWB + c * 16) = v;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::Frag row_frag_lds(const char* lds, int row, int chunk) {
+  return *reinterpret_cast<const typename Mma<T>::Frag*>(lds + row * Geom<T>::ROWB + chunk * 16);
+}
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::Frag row_frag_global(const T* g, size_t ld_g, int row, int nvalid, int chunk) {
+  if (row < nvalid) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(g + (size_t)row * ld_g + chunk * Mma<T>::CH);
+    return __builtin_bit_cast(typename Mma<T>::Frag, v);
+  }
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(typename Mma<T>::Frag, z);
+}
+template <typename T> __device__ __forceinline__ float frag_dot(const typename Mma<T>::Frag& a, const typename Mma<T>::Frag& b);
+template <> __device__ __forceinline__ float frag_dot<bf16_t>(const bf16x8& a, const bf16x8& b) {
+  const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s += __uint_as_float(ua[e] << 16) * __uint_as_float(ub[e] << 16);
+    s += __uint_as_float(ua[e] & 0xffff0000u) * __uint_as_float(ub[e] & 0xffff0000u);
+  }
+  return s;
+}
+template <> __device__ __forceinline__ float frag_dot<float>(const f32x4& a, const f32x4& b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+}
+
+template <typename T> struct Store4;
+template <> struct Store4<float> {
+  static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Store4<bf16_t> {
+  static __device__ __forceinline__ void st(bf16_t* p, f32x4 v) {
+    u32x2 r; r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p) = r;
+  }
+};
+
+struct AttnArgs {
+  const void* qkv;   // [B, N, 3, H, 64]
+  void* o;           // [B, N, H, 64]
+  float* lse;        // [B, H, N]
+  const void* dout;  // [B, N, H, 64]
+  void* dqkv;        // [B, N, 3, H, 64]
+  float* delta;      // [B, H, N]
+  int B, N, H;
+  float scale;
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward.  NT16 = number of 16-key tiles (multiple of TPS).
+template <typename T, int NT16>
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+  typedef Mma<T> MM;
+  typedef Geom<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = NT16 * 16;
+  char* sK = smem;
+  char* sV = smem + NP * G::ROWB;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const size_t ldq = (size_t)3 * a.H * HD;
+  const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
+  const T* kb = qb + a.H * HD;
+  const T* vb = qb + 2 * a.H * HD;
+  stage_rows<T>(sK, kb, ldq, a.N, NP);
+  stage_rows<T>(sV, vb, ldq, a.N, NP);
+  __syncthreads();
+  T* ob = reinterpret_cast<T*>(a.o) + (size_t)b * a.N * a.H * HD + h * HD;
+  const int nqt = (a.N + 15) / 16;
+  for (int qt = w; qt < nqt; qt += 4) {
+    typename MM::Frag qf[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) qf[ks] = row_frag_global<T>(qb, ldq, qt * 16 + li, a.N, ks * 4 + g);
+    f32x4 st[NT16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) c = MM::mma(row_frag_lds<T>(sK, t * 16 + li, ks * 4 + g), qf[ks], c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = t * 16 + g * 4 + e;
+        c[e] = key < a.N ? c[e] * a.scale : -INFINITY;
+        mx = fmaxf(mx, c[e]);
+      }
+      st[t] = c;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT16; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float p = __expf(st[t][e] - mx); st[t][e] = p; sum += p; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    f32x4 ot[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NT16 / G::TPS; ++s) {
+      const typename MM::Frag pf = MM::pack(st[s * G::TPS], st[s * G::TPS + G::TPS - 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) ot[dt] = MM::mma(TrFrag<T>::ld(sV, G::ROWB, s * MM::KSTEP, dt * 16, lane), pf, ot[dt]);
+    }
+    const int q = qt * 16 + li;
+    if (q < a.N) {
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4 v = ot[dt];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= inv;
+        Store4<T>::st(ob + (size_t)q * a.H * HD + dt * 16 + g * 4, v);
+      }
+      if (g == 0 && a.lse) a.lse[((size_t)b * a.H + h) * a.N + q] = mx + __logf(sum);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, dQ (and delta = rowsum(dO * O)).  K, V in LDS.
+template <typename T, int NT16>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
+  typedef Mma<T> MM;
+  typedef Geom<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = NT16 * 16;
+  char* sK = smem;
+  char* sV = smem + NP * G::ROWB;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const size_t ldq = (size_t)3 * a.H * HD, ldo = (size_t)a.H * HD;
+  const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
+  const T* kb = qb + a.H * HD;
+  const T* vb = qb + 2 * a.H * HD;
+  const T* ob = reinterpret_cast<const T*>(a.o) + (size_t)b * a.N * ldo + h * HD;
+  const T* dob = reinterpret_cast<const T*>(a.dout) + (size_t)b * a.N * ldo + h * HD;
+  T* dqb = reinterpret_cast<T*>(a.dqkv) + (size_t)b * a.N * ldq + h * HD;
+  stage_rows<T>(sK, kb, ldq, a.N, NP);
+  stage_rows<T>(sV, vb, ldq, a.N, NP);
+  __syncthreads();
+  const int nqt = (a.N + 15) / 16;
+  for (int qt = w; qt < nqt; qt += 4) {
+    const int q = qt * 16 + li;
+    typename MM::Frag qf[G::KS], dof[G::KS];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      qf[ks] = row_frag_global<T>(qb, ldq, q, a.N, ks * 4 + g);
+      dof[ks] = row_frag_global<T>(dob, ldo, q, a.N, ks * 4 + g);
+      dl += frag_dot<T>(dof[ks], row_frag_global<T>(ob, ldo, q, a.N, ks * 4 + g));
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    const float lse = q < a.N ? a.lse[((size_t)b * a.H + h) * a.N + q] : 0.f;
+    if (q < a.N && g == 0) a.delta[((size_t)b * a.H + h) * a.N + q] = dl;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int s = 0; s < NT16 / G::TPS; ++s) {
+      f32x4 ds[G::TPS];
+#pragma unroll
+      for (int u = 0; u < G::TPS; ++u) {
+        const int t = s * G::TPS + u;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+          c = MM::mma(row_frag_lds<T>(sK, t * 16 + li, ks * 4 + g), qf[ks], c);
+          dp = MM::mma(row_frag_lds<T>(sV, t * 16 + li, ks * 4 + g), dof[ks], dp);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = t * 16 + g * 4 + e;
+          const float p = key < a.N ? __expf(c[e] * a.scale - lse) : 0.f;
+          ds[u][e] = p * (dp[e] - dl) * a.scale;
+        }
+      }
+      const typename MM::Frag dsf = MM::pack(ds[0], ds[G::TPS - 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = MM::mma(TrFrag<T>::ld(sK, G::ROWB, s * MM::KSTEP, dt * 16, lane), dsf, dq[dt]);
+    }
+    if (q < a.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) Store4<T>::st(dqb + (size_t)q * ldq + dt * 16 + g * 4, dq[dt]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, dK and dV.  Q, dO (+ lse, delta) in LDS; each wave owns 16-key tiles.
+template <typename T, int NT16>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
+  typedef Mma<T> MM;
+  typedef Geom<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = NT16 * 16;
+  char* sQ = smem;
+  char* sDO = smem + NP * G::ROWB;
+  float* sLse = reinterpret_cast<float*>(smem + 2 * NP * G::ROWB);
+  float* sDel = sLse + NP;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const size_t ldq = (size_t)3 * a.H * HD, ldo = (size_t)a.H * HD;
+  const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
+  const T* kb = qb + a.H * HD;
+  const T* vb = qb + 2 * a.H * HD;
+  const T* dob = reinterpret_cast<const T*>(a.dout) + (size_t)b * a.N * ldo + h * HD;
+  T* dkb = reinterpret_cast<T*>(a.dqkv) + (size_t)b * a.N * ldq + (a.H + h) * HD;
+  T* dvb = dkb + a.H * HD;
+  stage_rows<T>(sQ, qb, ldq, a.N, NP);
+  stage_rows<T>(sDO, dob, ldo, a.N, NP);
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+    sLse[i] = i < a.N ? a.lse[((size_t)b * a.H + h) * a.N + i] : 0.f;
+    sDel[i] = i < a.N ? a.delta[((size_t)b * a.H + h) * a.N + i] : 0.f;
+  }
+  __syncthreads();
+  const int nkt = (a.N + 15) / 16;
+  for (int kt = w; kt < nkt; kt += 4) {
+    const int key = kt * 16 + li;
+    typename MM::Frag kf[G::KS], vf[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      kf[ks] = row_frag_global<T>(kb, ldq, key, a.N, ks * 4 + g);
+      vf[ks] = row_frag_global<T>(vb, ldq, key, a.N, ks * 4 + g);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int s = 0; s < NT16 / G::TPS; ++s) {
+      f32x4 pp[G::TPS], ds[G::TPS];
+#pragma unroll
+      for (int u = 0; u < G::TPS; ++u) {
+        const int t = s * G::TPS + u;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+          c = MM::mma(row_frag_lds<T>(sQ, t * 16 + li, ks * 4 + g), kf[ks], c);
+          dp = MM::mma(row_frag_lds<T>(sDO, t * 16 + li, ks * 4 + g), vf[ks], dp);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = t * 16 + g * 4 + e;
+          const float p = q < a.N ? __expf(c[e] * a.scale - sLse[q]) : 0.f;
+          pp[u][e] = p;
+          ds[u][e] = p * (dp[e] - sDel[q]) * a.scale;
+        }
+      }
+      const typename MM::Frag pf = MM::pack(pp[0], pp[G::TPS - 1]);
+      const typename MM::Frag dsf = MM::pack(ds[0], ds[G::TPS - 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = MM::mma(TrFrag<T>::ld(sDO, G::ROWB, s * MM::KSTEP, dt * 16, lane), pf, dv[dt]);
+        dk[dt] = MM::mma(TrFrag<T>::ld(sQ, G::ROWB, s * MM::KSTEP, dt * 16, lane), dsf, dk[dt]);
+      }
+    }
+    if (key < a.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        Store4<T>::st(dkb + (size_t)key * ldq + dt * 16 + g * 4, dk[dt]);
+        Store4<T>::st(dvb + (size_t)key * ldq + dt * 16 + g * 4, dv[dt]);
+      }
+    }
+  }
+}
+
+template <typename T, int NT16> int launch(const AttnArgs& a, int which, hipStream_t st) {
+  const int NP = NT16 * 16;
+  size_t sh = (size_t)2 * NP * Geom<T>::ROWB;
+  const int grid = a.B * a.H;
+  hipError_t e = hipSuccess;
+  if (which == 0) {
+    if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+    k_attn_fwd<T, NT16><<<grid, 256, sh, st>>>(a);
+  } else if (which == 1) {
+    if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_bwd_dq<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+    k_attn_bwd_dq<T, NT16><<<grid, 256, sh, st>>>(a);
+  } else {
+    sh += (size_t)2 * NP * sizeof(float);
+    if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_bwd_dkv<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+    k_attn_bwd_dkv<T, NT16><<<grid, 256, sh, st>>>(a);
+  }
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+template <typename T> int dispatch(const AttnArgs& a, int which, hipStream_t st) {
+  const int nt = (a.N + 15) / 16;
+  if (nt <= 2) return launch<T, 2>(a, which, st);
+  if (nt <= 4) return launch<T, 4>(a, which, st);
+  if (nt <= 8) return launch<T, 8>(a, which, st);
+  if (nt <= 14) return launch<T, 14>(a, which, st);
+  if (nt <= 16) return launch<T, 16>(a, which, st);
+  return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "attention: sequence length > 256 not supported");
+}
+
+int check(const uvc_attn_args* p, bool bwd) {
+  if (!p || !p->qkv || !p->o || !p->lse) return uvc_set_error_msg(UVC_ERR_ARG, "attention: null pointer");
+  if (bwd && (!p->dout || !p->dqkv || !p->delta)) return uvc_set_error_msg(UVC_ERR_ARG, "attention backward: null pointer");
+  if (p->head_dim != HD) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "attention: head_dim must be 64");
+  if (p->B <= 0 || p->N <= 0 || p->H <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "attention: empty problem");
+  if (p->dtype != UVC_F32 && p->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "attention: bad dtype");
+  return UVC_OK;
+}
+
+AttnArgs conv(const uvc_attn_args* p) {
+  AttnArgs a;
+  a.qkv = p->qkv; a.o = p->o; a.lse = p->lse; a.dout = p->dout; a.dqkv = p->dqkv; a.delta = p->delta;
+  a.B = p->B; a.N = p->N; a.H = p->H; a.scale = p->scale;
+  return a;
+}
+
+}  // namespace
+
+extern "C" int uvc_attention_fwd(const uvc_attn_args* p, void* stream) {
+  if (int e = check(p, false)) return e;
+  const AttnArgs a = conv(p);
+  return p->dtype == UVC_F32 ? dispatch<float>(a, 0, (hipStream_t)stream) : dispatch<bf16_t>(a, 0, (hipStream_t)stream);
+}
+
+extern "C" int uvc_attention_bwd(const uvc_attn_args* p, void* stream) {
+  if (int e = check(p, true)) return e;
+  const AttnArgs a = conv(p);
+  hipStream_t st = (hipStream_t)stream;
+  if (p->dtype == UVC_F32) {
+    if (int e = dispatch<float>(a, 1, st)) return e;
+    return dispatch<float>(a, 2, st);
+  }
+  if (int e = dispatch<bf16_t>(a, 1, st)) return e;
+  return dispatch<bf16_t>(a, 2, st);
+}

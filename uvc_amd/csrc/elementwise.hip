@@ -1,0 +1,282 @@
+// Layout / elementwise / small-reduction kernels of the DeiT step on gfx950 (all HBM-bound).
+// Reference lines are cited at each entry point.
+#include "common.h"
+#include "../../include/uvc_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------- patchify
+template <typename T>
+__global__ __launch_bounds__(256) void k_patchify(const float* __restrict__ x, T* __restrict__ out, int B, int C, int S, int P) {
+  const int G = S / P, K = C * P * P, K4 = K / 4, P4 = P / 4;
+  const int64_t total = (int64_t)B * G * G * K4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int k4 = (int)(idx % K4);
+    const int64_t r = idx / K4;
+    const int px = (int)(r % G), py = (int)((r / G) % G), b = (int)(r / ((int64_t)G * G));
+    const int kx4 = k4 % P4, ky = (k4 / P4) % P, c = k4 / (P4 * P);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * C + c) * S + (py * P + ky)) * S + px * P + kx4 * 4);
+    T* o = out + (size_t)r * K + k4 * 4;
+    if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(o) = v;
+    else { u32x2 q; q[0] = pack_bf16x2(v[0], v[1]); q[1] = pack_bf16x2(v[2], v[3]); *reinterpret_cast<u32x2*>(o) = q; }
+  }
+}
+
+// ---------------------------------------------------------------------------- token assembly
+__global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ pe, const float* __restrict__ cls,
+                                                  const float* __restrict__ dist, const float* __restrict__ pos,
+                                                  const float* __restrict__ mask, float* __restrict__ tok, int B, int P, int D,
+                                                  int ntok) {
+  const int N = P + ntok, D4 = D / 4;
+  const int64_t total = (int64_t)B * N * D4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int d4 = (int)(idx % D4);
+    const int t = (int)((idx / D4) % N), b = (int)(idx / ((int64_t)D4 * N));
+    f32x4 v;
+    if (t < ntok) v = *reinterpret_cast<const f32x4*>((t == 0 ? cls : dist) + d4 * 4);
+    else {
+      v = *reinterpret_cast<const f32x4*>(pe + ((size_t)b * P + (t - ntok)) * D + d4 * 4);
+      if (mask) { const float m = mask[(size_t)b * P + (t - ntok)]; v[0] *= m; v[1] *= m; v[2] *= m; v[3] *= m; }
+    }
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (size_t)t * D + d4 * 4);
+    v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+    *reinterpret_cast<f32x4*>(tok + ((size_t)b * N + t) * D + d4 * 4) = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_assemble_bwd_dpe(const float* __restrict__ dtok, const float* __restrict__ mask,
+                                                          T* __restrict__ dpe, int B, int P, int D, int ntok) {
+  const int N = P + ntok, D4 = D / 4;
+  const int64_t total = (int64_t)B * P * D4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int d4 = (int)(idx % D4);
+    const int i = (int)((idx / D4) % P), b = (int)(idx / ((int64_t)D4 * P));
+    f32x4 v = *reinterpret_cast<const f32x4*>(dtok + ((size_t)b * N + ntok + i) * D + d4 * 4);
+    if (mask) { const float m = mask[(size_t)b * P + i]; v[0] *= m; v[1] *= m; v[2] *= m; v[3] *= m; }
+    T* o = dpe + ((size_t)b * P + i) * D + d4 * 4;
+    if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(o) = v;
+    else { u32x2 q; q[0] = pack_bf16x2(v[0], v[1]); q[1] = pack_bf16x2(v[2], v[3]); *reinterpret_cast<u32x2*>(o) = q; }
+  }
+}
+
+// dpos[t,d] = sum_b dtok[b,t,d]; the class / dist token gradients are rows 0 / 1 of the same sum
+__global__ __launch_bounds__(256) void k_assemble_bwd_dpos(const float* __restrict__ dtok, float* __restrict__ dpos,
+                                                           float* __restrict__ dcls, float* __restrict__ ddist, int B, int N,
+                                                           int D, int ntok, float beta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * D) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dtok[(size_t)b * N * D + i];
+  dpos[i] = (beta != 0.f ? beta * dpos[i] : 0.f) + s;
+  const int t = i / D, d = i % D;
+  if (t == 0) dcls[d] = (beta != 0.f ? beta * dcls[d] : 0.f) + s;
+  if (t == 1 && ntok == 2 && ddist) ddist[d] = (beta != 0.f ? beta * ddist[d] : 0.f) + s;
+}
+
+// dmask[b,i] = <dtok[b, ntok+i, :], pe[b, i, :]>  (one wave per row)
+__global__ __launch_bounds__(256) void k_assemble_bwd_dmask(const float* __restrict__ dtok, const float* __restrict__ pe,
+                                                            float* __restrict__ dmask, int B, int P, int D, int ntok) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * P) return;
+  const int b = row / P, i = row % P, N = P + ntok;
+  const float* a = dtok + ((size_t)b * N + ntok + i) * D;
+  const float* c = pe + (size_t)row * D;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += a[d] * c[d];
+  s = wave_sum(s);
+  if (lane == 0) dmask[row] = s;
+}
+
+// ---------------------------------------------------------------------------- column sums
+constexpr int CS_ROWS = 256;
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ X, int M, int N, int ldx, float* __restrict__ partial) {
+  __shared__ float red[4][64 * VEC];
+  const int c0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * VEC, sl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+  if (c0 < N) {
+    for (int r = r0 + sl; r < r1; r += 4) {
+      const T* p = X + (size_t)r * ldx + c0;
+      if (VEC == 4) {
+        if (sizeof(T) == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p); s[0] += v[0]; s[1 % VEC] += v[1]; s[2 % VEC] += v[2]; s[3 % VEC] += v[3]; }
+        else {
+          const u32x2 q = *reinterpret_cast<const u32x2*>(p);
+          s[0] += __uint_as_float(q[0] << 16); s[1 % VEC] += __uint_as_float(q[0] & 0xffff0000u);
+          s[2 % VEC] += __uint_as_float(q[1] << 16); s[3 % VEC] += __uint_as_float(q[1] & 0xffff0000u);
+        }
+      } else s[0] += ElemIO<T>::load(p);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[sl][(threadIdx.x & 63) * VEC + e] = s[e];
+  __syncthreads();
+  if (sl == 0 && c0 < N) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int k = (threadIdx.x & 63) * VEC + e;
+      if (c0 + e < N) partial[(size_t)blockIdx.y * N + c0 + e] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_colsum_reduce(const float* __restrict__ partial, int nb, int N, float* __restrict__ out,
+                                                       float alpha, const float* alpha_ptr, float beta) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < N)
+    for (int b = sl; b < nb; b += 4) s += partial[(size_t)b * N + c];
+  red[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < N) {
+    const int t = threadIdx.x;
+    if (alpha_ptr) alpha *= *alpha_ptr;
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + alpha * (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]);
+  }
+}
+
+// ---------------------------------------------------------------------------- weight shadows
+// 32x32 tiles through LDS: dst[r,c] = cast(src[r,c]); dstT[c,r] = cast(src[r,c])
+template <typename T>
+__global__ __launch_bounds__(256) void k_cast_transpose(const float* __restrict__ W, int R, int C, T* __restrict__ w, T* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    const float v = (r < R && c < C) ? W[(size_t)r * C + c] : 0.f;
+    tile[i][tx] = v;
+    if (w && r < R && c < C) ElemIO<T>::store(w + (size_t)r * C + c, v);
+  }
+  __syncthreads();
+  if (wt)
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (r < R && c < C) ElemIO<T>::store(wt + (size_t)c * R + r, tile[tx][i]);
+    }
+}
+
+// ---------------------------------------------------------------------------- gates
+// mode 0: warm-up (.5,.5); 1: soft Gumbel-softmax tau=.5; 2: softL0 g1^2/(g1^2+eps); 3: hard Gumbel (one-hot)
+__global__ void k_gate_distrib(const float* g, const float* e, float* d, int L, int mode, float eps) {
+  const int l = threadIdx.x;
+  if (l >= L) return;
+  float d0 = 0.5f, d1 = 0.5f;
+  if (mode == 1 || mode == 3) {
+    const float u0 = (g[2 * l] + (-__logf(e[2 * l]))) / 0.5f, u1 = (g[2 * l + 1] + (-__logf(e[2 * l + 1]))) / 0.5f;
+    const float m = fmaxf(u0, u1);
+    const float e0 = __expf(u0 - m), e1 = __expf(u1 - m);
+    d0 = e0 / (e0 + e1); d1 = e1 / (e0 + e1);
+    if (mode == 3) { const bool one = d1 > d0; d0 = one ? 0.f : 1.f; d1 = one ? 1.f : 0.f; }
+  } else if (mode == 2) {
+    const float t = g[2 * l + 1] * g[2 * l + 1];
+    d1 = t / (t + eps); d0 = 1.0f - d1;
+  }
+  d[2 * l] = d0; d[2 * l + 1] = d1;
+}
+// out = d1*x2 + d0*x  =>  dL/dd1 - dL/dd0 = <gA, x2 - x> = (<gA,out> - <gA,x>) / d1.
+__global__ void k_gate_grad(const float* g, const float* d, const float* dots, float* dg, int L, int mode, float eps, float beta) {
+  const int l = threadIdx.x;
+  if (l >= L) return;
+  const float A = dots[2 * l], Bv = dots[2 * l + 1];
+  float g0 = 0.f, g1 = 0.f;
+  if (mode == 1) {               // softmax((g+G)/tau): dg1 = d0*d1/tau * <gA, x2-x> = d0/tau * (A - B)
+    g1 = d[2 * l] / 0.5f * (A - Bv);
+    g0 = -g1;
+  } else if (mode == 2) {        // d1 = t/(t+eps), d0 = 1-d1: dg1 = 2 g1 eps/(t+eps)^2 * (A-B)/d1 = 2 eps/(g1 (t+eps)) (A-B)
+    const float x = g[2 * l + 1], t = x * x;
+    g1 = x != 0.f ? 2.0f * eps / (x * (t + eps)) * (A - Bv) : 0.f;
+  }
+  dg[2 * l] = (beta != 0.f ? beta * dg[2 * l] : 0.f) + g0;
+  dg[2 * l + 1] = (beta != 0.f ? beta * dg[2 * l + 1] : 0.f) + g1;
+}
+
+inline int grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+}  // namespace
+
+extern "C" int uvc_patchify(const float* x, void* out, int32_t B, int32_t C, int32_t S, int32_t P, int32_t dtype, void* stream) {
+  if (!x || !out || B <= 0 || C <= 0 || S <= 0 || P <= 0 || S % P || P % 4) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_patchify: bad argument");
+  const int64_t total = (int64_t)B * (S / P) * (S / P) * C * P * P / 4;
+  if (dtype == UVC_F32) k_patchify<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, (float*)out, B, C, S, P);
+  else k_patchify<bf16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)out, B, C, S, P);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_assemble_tokens(const float* pe, const float* cls, const float* dist, const float* pos, const float* row_mask,
+                                   float* tok, int32_t B, int32_t P, int32_t D, int32_t ntok, void* stream) {
+  if (!pe || !cls || !pos || !tok || (ntok == 2 && !dist) || (ntok != 1 && ntok != 2) || D % 4) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_assemble_tokens: bad argument");
+  k_assemble<<<grid_for((int64_t)B * (P + ntok) * D / 4), 256, 0, (hipStream_t)stream>>>(pe, cls, dist, pos, row_mask, tok, B, P, D, ntok);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_assemble_tokens_bwd(const float* dtok, const float* pe, const float* row_mask, void* dpe, float* dpos, float* dcls,
+                                       float* ddist, float* dmask, int32_t B, int32_t P, int32_t D, int32_t ntok, int32_t dtype,
+                                       int32_t dpe_is_f32, float beta_acc, void* stream) {
+  if (!dtok || !dpe || !dpos || !dcls || D % 4 || (ntok != 1 && ntok != 2)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_assemble_tokens_bwd: bad argument");
+  if (dmask && !pe) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_assemble_tokens_bwd: dmask needs pe");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UVC_F32 || dpe_is_f32) k_assemble_bwd_dpe<float><<<grid_for((int64_t)B * P * D / 4), 256, 0, st>>>(dtok, row_mask, (float*)dpe, B, P, D, ntok);
+  else k_assemble_bwd_dpe<bf16_t><<<grid_for((int64_t)B * P * D / 4), 256, 0, st>>>(dtok, row_mask, (bf16_t*)dpe, B, P, D, ntok);
+  UVC_CHECK_LAUNCH();
+  k_assemble_bwd_dpos<<<ceil_div((P + ntok) * D, 256), 256, 0, st>>>(dtok, dpos, dcls, ddist, B, P + ntok, D, ntok, beta_acc);
+  UVC_CHECK_LAUNCH();
+  if (dmask) {
+    k_assemble_bwd_dmask<<<ceil_div(B * P, 4), 256, 0, st>>>(dtok, pe, dmask, B, P, D, ntok);
+    UVC_CHECK_LAUNCH();
+  }
+  return UVC_OK;
+}
+
+extern "C" int uvc_colsum_blocks(int32_t M) { return ceil_div(M, CS_ROWS); }
+
+extern "C" int uvc_colsum(const void* X, int32_t M, int32_t N, int32_t ldx, int32_t dtype, int32_t x_is_f32, float* partial, float* out,
+                          float alpha, const float* alpha_ptr, float beta, void* stream) {
+  if (!X || !partial || !out || M <= 0 || N <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_colsum: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = ceil_div(M, CS_ROWS);
+  const bool f32 = (dtype == UVC_F32) || x_is_f32;
+  const bool vec = (N % 4 == 0) && (ldx % 4 == 0);
+  if (vec) {
+    dim3 grid(ceil_div(N, 256), nb);
+    if (f32) k_colsum<float, 4><<<grid, 256, 0, st>>>((const float*)X, M, N, ldx, partial);
+    else k_colsum<bf16_t, 4><<<grid, 256, 0, st>>>((const bf16_t*)X, M, N, ldx, partial);
+  } else {
+    dim3 grid(ceil_div(N, 64), nb);
+    if (f32) k_colsum<float, 1><<<grid, 256, 0, st>>>((const float*)X, M, N, ldx, partial);
+    else k_colsum<bf16_t, 1><<<grid, 256, 0, st>>>((const bf16_t*)X, M, N, ldx, partial);
+  }
+  UVC_CHECK_LAUNCH();
+  k_colsum_reduce<<<ceil_div(N, 64), 256, 0, st>>>(partial, nb, N, out, alpha, alpha_ptr, beta);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_cast_transpose(const float* W, int32_t R, int32_t C, void* w_cast, void* wt, int32_t dtype, void* stream) {
+  if (!W || R <= 0 || C <= 0 || (!w_cast && !wt)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_cast_transpose: bad argument");
+  dim3 grid(ceil_div(C, 32), ceil_div(R, 32));
+  if (dtype == UVC_F32) k_cast_transpose<float><<<grid, 256, 0, (hipStream_t)stream>>>(W, R, C, (float*)w_cast, (float*)wt);
+  else k_cast_transpose<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(W, R, C, (bf16_t*)w_cast, (bf16_t*)wt);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_gate_distrib(const float* g, const float* e, float* d, int32_t L, int32_t mode, float eps, void* stream) {
+  if (!g || !d || L <= 0 || L > 64 || mode < 0 || mode > 3 || ((mode == 1 || mode == 3) && !e)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gate_distrib: bad argument");
+  k_gate_distrib<<<1, 64, 0, (hipStream_t)stream>>>(g, e, d, L, mode, eps);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_gate_grad(const float* g, const float* d, const float* dots, float* dg, int32_t L, int32_t mode, float eps,
+                             float beta_acc, void* stream) {
+  if (!g || !d || !dots || !dg || L <= 0 || L > 64) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gate_grad: bad argument");
+  k_gate_grad<<<1, 64, 0, (hipStream_t)stream>>>(g, d, dots, dg, L, mode, eps, beta_acc);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}

@@ -1,0 +1,463 @@
+// MFMA GEMMs for the DeiT step on gfx950.
+//   uvc_gemm_nt : C[M,N] = epi( A[M,K] . B[N,K]^T )       forward Linear / dgrad (with W^T copies)
+//   uvc_gemm_tn : C[N1,N2] = beta*C + alpha * A[M,N1]^T . B[M,N2]   wgrad, split over M, deterministic
+// Compute type T = bf16 (v_mfma_f32_16x16x32_bf16, fp32 accumulate) or float
+// (v_mfma_f32_16x16x4_f32, bit-exact fmaf chain) -- the latter is the 1e-3 parity mode.
+//
+// Tiling (64-wide wavefronts): 256 threads = 4 waves as 2x2; the block tile is staged through
+// LDS in 16-byte chunks with register prefetch of the next K tile; rows are padded by 16 B (NT)
+// or 32 B (TN) so ds_read_b128 / ds_read_b64_tr_b16 fragment reads are bank-conflict free.
+// Operands are swapped in the MFMA (a = B-fragment, b = A-fragment) so every lane ends up with 4
+// CONSECUTIVE output columns of one row -> 16-byte (fp32) / 8-byte (bf16) epilogue accesses.
+#include "common.h"
+#include "../../include/uvc_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int CH = 8;     // elements per 16-byte chunk
+  static constexpr int KSTEP = 32; // k elements per MFMA step (4 lane groups x 1 chunk)
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int CH = 4;
+  static constexpr int KSTEP = 16;
+  typedef f32x4 Frag;
+  static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+  }
+};
+
+// 16-byte chunk of compute type T loaded from a global array of type TS (convert on load)
+template <typename TS, typename T> struct ChunkLoad;
+template <typename T> struct ChunkLoad<T, T> {
+  static __device__ __forceinline__ u32x4 ld(const T* p) { return *reinterpret_cast<const u32x4*>(p); }
+};
+template <> struct ChunkLoad<float, bf16_t> {   // 8 floats -> 8 bf16
+  static __device__ __forceinline__ u32x4 ld(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    u32x4 r;
+    r[0] = pack_bf16x2(a[0], a[1]); r[1] = pack_bf16x2(a[2], a[3]);
+    r[2] = pack_bf16x2(b[0], b[1]); r[3] = pack_bf16x2(b[2], b[3]);
+    return r;
+  }
+};
+
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag lds_frag(const char* p) {
+  return *reinterpret_cast<const typename Mma<T>::Frag*>(p);
+}
+
+// ================================================================================================
+//                                            NT
+// ================================================================================================
+constexpr int NT_BM = 128, NT_BN = 128;
+constexpr int NT_ROWB = 128 + 16;          // LDS row stride in bytes (8 chunks + 16 B pad)
+
+template <typename T> struct OutIO;
+template <> struct OutIO<float> {
+  static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+  static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+};
+template <> struct OutIO<bf16_t> {
+  static __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
+    u32x2 r; r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p) = r;
+  }
+  static __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+    const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+    f32x4 v; v[0] = __uint_as_float(r[0] << 16); v[1] = __uint_as_float(r[0] & 0xffff0000u);
+    v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
+    return v;
+  }
+};
+
+struct NtArgs {
+  const void* A; const void* B; void* C; void* C2;
+  const float* bias; const float* R; const float* R2; const void* aux; const float* dptr;
+  int M, N, K, lda, ldb, ldc, ldr, ldaux;
+  float alpha;
+  const float* alpha_ptr;   // optional device scalar multiplied into alpha
+};
+
+template <typename TA, typename T, typename TC, int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
+  typedef Mma<T> MM;
+  constexpr int CH = MM::CH;
+  constexpr int BK = 8 * CH;                    // elements per K tile (128 B of T per row)
+  __shared__ __attribute__((aligned(16))) char sA[NT_BM * NT_ROWB];
+  __shared__ __attribute__((aligned(16))) char sB[NT_BN * NT_ROWB];
+  const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(g.B);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  // XCD-aware tile order: consecutive M tiles (which share no operand but stream A once) stay put;
+  // all N tiles of one M tile run back to back on the same XCD so A is fetched from HBM once.
+  const int ntn = (g.N + NT_BN - 1) / NT_BN;
+  const int bm = blockIdx.x / ntn, bn = blockIdx.x % ntn;
+  const int m0 = bm * NT_BM, n0 = bn * NT_BN;
+  const int lc = tid & 7, lr = tid >> 3;        // chunk column / first row of this thread's loads
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+    const int kc = k0 + lc * CH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lr + 32 * i;
+      const int m = m0 + row, n = n0 + row;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ra[i] = (m < g.M && kc < g.K) ? ChunkLoad<TA, T>::ld(A + (size_t)m * g.lda + kc) : z;
+      rb[i] = (n < g.N && kc < g.K) ? ChunkLoad<T, T>::ld(B + (size_t)n * g.ldb + kc) : z;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lr + 32 * i;
+      *reinterpret_cast<u32x4*>(sA + row * NT_ROWB + lc * 16) = ra[i];
+      *reinterpret_cast<u32x4*>(sB + row * NT_ROWB + lc * 16) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + BK - 1) / BK;
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typename MM::Frag fa[4], fb[4];
+      const int coff = (ks * 4 + (lane >> 4)) * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = lds_frag<T>(sA + (wm * 64 + i * 16 + (lane & 15)) * NT_ROWB + coff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = lds_frag<T>(sB + (wn * 64 + j * 16 + (lane & 15)) * NT_ROWB + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fb[j], fa[i], acc[i][j]);
+    }
+    if (kt + 1 < nk) {
+      __syncthreads();
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane owns row m = .. + (lane&15), columns n = .. + (lane>>4)*4 + {0..3}
+  TC* __restrict__ C = reinterpret_cast<TC*>(g.C);
+  float alpha = g.alpha;
+  if (g.alpha_ptr) alpha *= *g.alpha_ptr;
+  float d0 = 0.f, d1 = 1.f;
+  if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
+  const bool vec = ((g.ldc & 3) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= g.M) continue;
+    const size_t mo = (size_t)m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (n >= g.N) continue;
+      f32x4 v = acc[i][j];
+      const bool full = vec && (n + 3 < g.N);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= alpha;
+      if (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] += g.bias[n + e];
+      }
+      if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
+        const float* rp = g.R + mo * g.ldr + n;
+        if (full && (g.ldr & 3) == 0) { const f32x4 r4 = OutIO<float>::ld4(rp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += r4[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] += rp[e];
+        }
+      }
+      if (EPI == UVC_EPI_BIAS_RESID_GATE) {
+        const float* rp = g.R2 + mo * g.ldr + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] = d1 * v[e] + d0 * rp[e];
+      }
+      if (EPI == UVC_EPI_DGELU) {
+        const T* ap = reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] *= gelu_grad_f(ElemIO<T>::load(ap + e));
+      }
+      TC* cp = C + mo * g.ldc + n;
+      if (EPI == UVC_EPI_BIAS_GELU) {
+        TC* c2 = reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n;
+        f32x4 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = gelu_f(v[e]);
+        if (full) { OutIO<TC>::st4(cp, v); OutIO<TC>::st4(c2, u); }
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) { ElemIO<TC>::store(cp + e, v[e]); ElemIO<TC>::store(c2 + e, u[e]); }
+        }
+      } else {
+        if (full) OutIO<TC>::st4(cp, v);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) ElemIO<TC>::store(cp + e, v[e]);
+        }
+      }
+    }
+  }
+}
+
+template <typename TA, typename T, typename TC>
+static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
+  const int grid = ceil_div(a.M, NT_BM) * ceil_div(a.N, NT_BN);
+#define NT_CASE(E) case E: k_gemm_nt<TA, T, TC, E><<<grid, 256, 0, st>>>(a); break;
+  switch (epi) {
+    NT_CASE(UVC_EPI_NONE) NT_CASE(UVC_EPI_BIAS) NT_CASE(UVC_EPI_BIAS_GELU) NT_CASE(UVC_EPI_BIAS_RESID)
+    NT_CASE(UVC_EPI_BIAS_RESID_GATE) NT_CASE(UVC_EPI_DGELU)
+    default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
+  }
+#undef NT_CASE
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
+  if (!p || !p->A || !p->B || !p->C) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: null pointer");
+  if (p->M <= 0 || p->N <= 0 || p->K <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: empty problem");
+  const int ch = (p->dtype == UVC_F32) ? 4 : 8;
+  if (p->K % ch || p->lda % ch || p->ldb % ch) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: K, lda, ldb must be multiples of a 16-byte chunk");
+  const int e = p->epilogue;
+  if ((e == UVC_EPI_BIAS || e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && !p->bias)
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue needs bias");
+  if ((e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && (!p->R || !p->c_is_f32))
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: residual epilogue needs R and a float32 C");
+  if (e == UVC_EPI_BIAS_RESID_GATE && (!p->R2 || !p->gate)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: gate epilogue needs R2 and gate");
+  if (e == UVC_EPI_BIAS_GELU && !p->C2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: GELU epilogue needs C2");
+  if (e == UVC_EPI_DGELU && !p->aux) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dGELU epilogue needs aux");
+  NtArgs a;
+  a.A = p->A; a.B = p->B; a.C = p->C; a.C2 = p->C2; a.bias = p->bias; a.R = p->R; a.R2 = p->R2; a.aux = p->aux;
+  a.dptr = p->gate; a.M = p->M; a.N = p->N; a.K = p->K; a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
+  a.ldr = p->ldr ? p->ldr : p->ldc; a.ldaux = p->ldaux ? p->ldaux : p->ldc; a.alpha = p->alpha; a.alpha_ptr = p->alpha_ptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->dtype == UVC_F32) {
+    if (!p->a_is_f32 || !p->c_is_f32) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: float32 mode needs float32 A and C");
+    return launch_nt_epi<float, float, float>(a, e, st);
+  }
+  if (p->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dtype must be UVC_F32 or UVC_BF16");
+  if (p->a_is_f32) {
+    if ((p->lda % 8) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: lda");
+    return p->c_is_f32 ? launch_nt_epi<float, bf16_t, float>(a, e, st) : launch_nt_epi<float, bf16_t, bf16_t>(a, e, st);
+  }
+  return p->c_is_f32 ? launch_nt_epi<bf16_t, bf16_t, float>(a, e, st) : launch_nt_epi<bf16_t, bf16_t, bf16_t>(a, e, st);
+}
+
+// ================================================================================================
+//                                            TN (wgrad)
+// ================================================================================================
+// C[n1,n2] = beta*C + alpha * sum_m A[m,n1] * B[m,n2].  Block tile 128(n1) x 64(n2), reduction tile
+// 64 rows of m.  The LDS image keeps the global [m][n] orientation; MFMA fragments are gathered with
+// ds_read_b64_tr_b16 (bf16) or ds_read_b32 (float32).  Each block reduces one slice of M and writes
+// a float32 partial tile; k_tn_reduce sums the slices in a fixed order (deterministic).
+constexpr int TN_B1 = 128, TN_B2 = 64, TN_BM = 64;
+
+template <typename T> struct TnGeom;
+template <> struct TnGeom<bf16_t> { static constexpr int LD1 = TN_B1 * 2 + 32, LD2 = TN_B2 * 2 + 32; };
+template <> struct TnGeom<float>  { static constexpr int LD1 = TN_B1 * 4 + 32, LD2 = TN_B2 * 4 + 32; };
+
+// fragment of 16 columns (c0..c0+15) x one MFMA k-step starting at tile row k0, from an [m][n] LDS tile
+template <typename T> struct TrFrag;
+template <> struct TrFrag<bf16_t> {
+  // k-slot map: group g slots 0-3 <-> rows k0+4g+{0..3}, slots 4-7 <-> rows k0+16+4g+{0..3}
+  static __device__ __forceinline__ bf16x8 ld(const char* tile, int ld, int k0, int c0, int lane) {
+    const int i = lane & 15, gq = lane >> 4;
+    const char* p = tile + (k0 + 4 * gq + (i >> 2)) * ld + (c0 + (i & 3) * 4) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(p + 16 * ld));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+template <> struct TrFrag<float> {
+  // k-slot map: MFMA j of the step uses row k0 + 4g + j
+  static __device__ __forceinline__ f32x4 ld(const char* tile, int ld, int k0, int c0, int lane) {
+    const int i = lane & 15, gq = lane >> 4;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float*>(tile + (k0 + 4 * gq + j) * ld + (c0 + i) * 4);
+    return v;
+  }
+};
+
+struct TnArgs {
+  const void* A; const void* B; float* part;
+  int M, N1, N2, lda, ldb, rows_per_split;
+};
+
+template <typename TA, typename T>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn(TnArgs g) {
+  typedef Mma<T> MM;
+  constexpr int CH = MM::CH;
+  constexpr int LD1 = TnGeom<T>::LD1, LD2 = TnGeom<T>::LD2;
+  constexpr int C1 = TN_B1 / CH, C2 = TN_B2 / CH;           // chunks per tile row
+  constexpr int NLA = TN_BM * C1 / 256, NLB = TN_BM * C2 / 256;
+  constexpr int KSUB = TN_BM / MM::KSTEP;                   // MFMA k-steps per reduction tile
+  __shared__ __attribute__((aligned(16))) char sA[TN_BM * LD1];
+  __shared__ __attribute__((aligned(16))) char sB[TN_BM * LD2];
+  const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(g.B);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int w1 = w >> 1, w2 = w & 1;                        // wave tile: 64 (n1) x 32 (n2)
+  const int n10 = blockIdx.x * TN_B1, n20 = blockIdx.y * TN_B2;
+  const int mbeg = blockIdx.z * g.rows_per_split;
+  const int mend = min(g.M, mbeg + g.rows_per_split);
+
+  u32x4 ra[NLA], rb[NLB];
+  auto gload = [&](int m0) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      const int id = tid + 256 * i, row = id / C1, c = id % C1;
+      const int m = m0 + row, n = n10 + c * CH;
+      ra[i] = (m < mend && n < g.N1) ? ChunkLoad<TA, T>::ld(A + (size_t)m * g.lda + n) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int id = tid + 256 * i, row = id / C2, c = id % C2;
+      const int m = m0 + row, n = n20 + c * CH;
+      rb[i] = (m < mend && n < g.N2) ? ChunkLoad<T, T>::ld(B + (size_t)m * g.ldb + n) : z;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      const int id = tid + 256 * i, row = id / C1, c = id % C1;
+      *reinterpret_cast<u32x4*>(sA + row * LD1 + c * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int id = tid + 256 * i, row = id / C2, c = id % C2;
+      *reinterpret_cast<u32x4*>(sB + row * LD2 + c * 16) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (mbeg < mend) {
+    gload(mbeg);
+    lstore();
+    __syncthreads();
+    for (int m0 = mbeg; m0 < mend; m0 += TN_BM) {
+      const bool more = m0 + TN_BM < mend;
+      if (more) gload(m0 + TN_BM);
+#pragma unroll
+      for (int ks = 0; ks < KSUB; ++ks) {
+        typename MM::Frag fa[4], fb[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = TrFrag<T>::ld(sA, LD1, ks * MM::KSTEP, w1 * 64 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = TrFrag<T>::ld(sB, LD2, ks * MM::KSTEP, w2 * 32 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = MM::mma(fb[j], fa[i], acc[i][j]);
+      }
+      if (more) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+      }
+    }
+  }
+  // partial[z][n1][n2]: lane owns n1 = .. + (lane&15), n2 = .. + (lane>>4)*4 + {0..3}
+  float* P = g.part + (size_t)blockIdx.z * g.N1 * g.N2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n1 = n10 + w1 * 64 + i * 16 + (lane & 15);
+    if (n1 >= g.N1) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n2 = n20 + w2 * 32 + j * 16 + (lane >> 4) * 4;
+      if (n2 + 3 < g.N2 && (g.N2 & 3) == 0) *reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n2 + e < g.N2) P[(size_t)n1 * g.N2 + n2 + e] = acc[i][j][e];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ part, float* __restrict__ C, int n, int ldc,
+                                                   int N2, int splits, float alpha, const float* alpha_ptr, float beta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(size_t)z * n + i];
+  if (alpha_ptr) alpha *= *alpha_ptr;
+  float* c = C + (size_t)(i / N2) * ldc + (i % N2);
+  *c = (beta != 0.f ? beta * *c : 0.f) + alpha * s;
+}
+
+extern "C" int uvc_gemm_tn_workspace_bytes(int M, int N1, int N2, int64_t* bytes, int* splits_out) {
+  if (!bytes) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn_workspace_bytes: null");
+  const int tiles = ceil_div(N1, TN_B1) * ceil_div(N2, TN_B2);
+  int splits = ceil_div(1024, tiles);                       // ~4 blocks per CU
+  const int max_splits = ceil_div(M, TN_BM);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  *bytes = (int64_t)splits * N1 * N2 * 4;
+  if (splits_out) *splits_out = splits;
+  return UVC_OK;
+}
+
+extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
+  if (!p || !p->A || !p->B || !p->C || !p->workspace) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: null pointer");
+  if (p->M <= 0 || p->N1 <= 0 || p->N2 <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: empty problem");
+  const int ch = (p->dtype == UVC_F32) ? 4 : 8;
+  if (p->N1 % ch || p->N2 % ch || p->lda % ch || p->ldb % ch)
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: N1, N2, lda, ldb must be multiples of a 16-byte chunk");
+  int64_t need; int splits;
+  uvc_gemm_tn_workspace_bytes(p->M, p->N1, p->N2, &need, &splits);
+  if (p->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: workspace too small");
+  TnArgs a;
+  a.A = p->A; a.B = p->B; a.part = (float*)p->workspace; a.M = p->M; a.N1 = p->N1; a.N2 = p->N2; a.lda = p->lda; a.ldb = p->ldb;
+  int rps = ceil_div(p->M, splits);
+  rps = ceil_div(rps, TN_BM) * TN_BM;
+  splits = ceil_div(p->M, rps);
+  a.rows_per_split = rps;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ceil_div(p->N1, TN_B1), ceil_div(p->N2, TN_B2), splits);
+  if (p->dtype == UVC_F32) {
+    if (!p->a_is_f32) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: float32 mode needs float32 A");
+    k_gemm_tn<float, float><<<grid, 256, 0, st>>>(a);
+  } else if (p->dtype == UVC_BF16) {
+    if (p->a_is_f32) k_gemm_tn<float, bf16_t><<<grid, 256, 0, st>>>(a);
+    else k_gemm_tn<bf16_t, bf16_t><<<grid, 256, 0, st>>>(a);
+  } else return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: dtype must be UVC_F32 or UVC_BF16");
+  UVC_CHECK_LAUNCH();
+  const int n = p->N1 * p->N2;
+  k_tn_reduce<<<ceil_div(n, 256), 256, 0, st>>>(a.part, p->C, n, p->ldc, p->N2, splits, p->alpha, p->alpha_ptr, p->beta);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}

@@ -1,0 +1,188 @@
+// LayerNorm forward/backward for gfx950 (HBM-bound; one 64-lane wave per token row, the row lives in
+// registers, row reductions are wave shuffles).  Reference: nn.LayerNorm(D, eps=1e-6) in
+// UVC/models/model_distilled.py:199,204,288 (eps from joint_train.py:138), biased variance.
+// Algorithmic bytes/row: fwd 4D read + sizeof(T)*D write; bwd (4 + sizeof(Tdy))*D read (+4D per
+// addend) + 4D write.
+#include "common.h"
+#include "../../include/uvc_kernels.h"
+
+namespace {
+
+constexpr int LN_ROWS_PER_BLOCK = 128;   // backward: rows per block (32 per wave)
+
+__device__ __forceinline__ size_t row_off(int r, int rpg, int64_t gs, int D) {
+  return (size_t)(r / rpg) * gs + (size_t)(r % rpg) * D;
+}
+
+template <typename TY, int NV>
+__global__ __launch_bounds__(256) void k_ln_fwd(uvc_ln_args a) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + w;
+  if (r >= a.rows) return;
+  const float* x = a.x + row_off(r, a.rows_per_group, a.group_stride, a.D);
+  float v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < a.D ? x[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)a.D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    const float d = c < a.D ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)a.D + a.eps);
+  TY* y = reinterpret_cast<TY*>(a.y) + (size_t)r * a.D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < a.D) ElemIO<TY>::store(y + c, (v[i] - mean) * rstd * a.gamma[c] + a.beta[c]);
+  }
+  if (lane == 0) { a.mean[r] = mean; a.rstd[r] = rstd; }
+}
+
+template <typename TDY, int NV>
+__global__ __launch_bounds__(256) void k_ln_bwd(uvc_ln_args a) {
+  __shared__ float red[4][2 * 64 * NV + 2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float gam[NV], dgam[NV], dbet[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    gam[i] = c < a.D ? a.gamma[c] : 0.f;
+    dgam[i] = 0.f; dbet[i] = 0.f;
+  }
+  const float a1 = a.a1 ? *a.a1 : 1.f, a2 = a.a2 ? *a.a2 : 1.f;
+  float dotA = 0.f, dotB = 0.f;
+  const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
+  const int r1 = min(a.rows, r0 + LN_ROWS_PER_BLOCK);
+  const float invD = 1.0f / (float)a.D;
+  for (int r = r0 + w; r < r1; r += 4) {
+    const size_t off = row_off(r, a.rows_per_group, a.group_stride, a.D);
+    const float* x = a.x + off;
+    const TDY* dy = reinterpret_cast<const TDY*>(a.dy) + (size_t)r * a.D;
+    const float mean = a.mean[r], rstd = a.rstd[r];
+    float xh[NV], gy[NV];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = c < a.D;
+      const float d = ok ? ElemIO<TDY>::load(dy + c) : 0.f;
+      xh[i] = ok ? (x[c] - mean) * rstd : 0.f;
+      gy[i] = d * gam[i];
+      dgam[i] += d * xh[i];
+      dbet[i] += d;
+      c1 += gy[i];
+      c2 += gy[i] * xh[i];
+    }
+    c1 = wave_sum(c1) * invD;
+    c2 = wave_sum(c2) * invD;
+    float* dx = a.dx + off;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < a.D) {
+        float o = rstd * (gy[i] - c1 - xh[i] * c2);
+        const float xv = x[c];
+        if (a.add1) o += a1 * a.add1[off + c];
+        if (a.add2) { const float t = a.add2[off + c]; o += a2 * t; dotB += t * xv; }
+        dx[c] = o;
+        dotA += o * xv;
+      }
+    }
+  }
+  // cross-wave reduction in fixed order
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { red[w][lane + 64 * i] = dgam[i]; red[w][64 * NV + lane + 64 * i] = dbet[i]; }
+  dotA = wave_sum(dotA); dotB = wave_sum(dotB);
+  if (lane == 0) { red[w][2 * 64 * NV] = dotA; red[w][2 * 64 * NV + 1] = dotB; }
+  __syncthreads();
+  float* P = a.partial + (size_t)blockIdx.x * (2 * a.D + 2);
+  for (int c = threadIdx.x; c < 64 * NV; c += 256) {
+    if (c < a.D) {
+      P[c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+      P[a.D + c] = ((red[0][64 * NV + c] + red[1][64 * NV + c]) + red[2][64 * NV + c]) + red[3][64 * NV + c];
+    }
+  }
+  if (threadIdx.x < 2) {
+    const int c = 2 * 64 * NV + threadIdx.x;
+    P[2 * a.D + threadIdx.x] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+  }
+}
+
+// sum the per-block partials: 256 threads = 64 columns x 4 slices of blocks
+__global__ __launch_bounds__(256) void k_ln_bwd_reduce(uvc_ln_args a, int nblocks) {
+  __shared__ float red[4][64];
+  const int W = 2 * a.D + 2;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < W)
+    for (int b = sl; b < nblocks; b += 4) s += a.partial[(size_t)b * W + c];
+  red[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < W) {
+    const int t = threadIdx.x;
+    const float tot = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    if (c < a.D) a.dgamma[c] = (a.beta_acc != 0.f ? a.beta_acc * a.dgamma[c] : 0.f) + tot;
+    else if (c < 2 * a.D) a.dbeta[c - a.D] = (a.beta_acc != 0.f ? a.beta_acc * a.dbeta[c - a.D] : 0.f) + tot;
+    else if (a.dots) a.dots[c - 2 * a.D] = tot;
+  }
+}
+
+int check(const uvc_ln_args* p) {
+  if (!p || !p->x || !p->gamma || !p->mean || !p->rstd) return uvc_set_error_msg(UVC_ERR_ARG, "layernorm: null pointer");
+  if (p->rows <= 0 || p->D <= 0 || p->D > 1024) return uvc_set_error_msg(UVC_ERR_ARG, "layernorm: need 0 < D <= 1024");
+  if (p->rows_per_group <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "layernorm: rows_per_group");
+  return UVC_OK;
+}
+
+template <typename T> int launch_fwd(const uvc_ln_args& a, hipStream_t st) {
+  const int grid = ceil_div(a.rows, 4);
+  const int nv = ceil_div(a.D, 64);
+  if (nv <= 2) k_ln_fwd<T, 2><<<grid, 256, 0, st>>>(a);
+  else if (nv <= 3) k_ln_fwd<T, 3><<<grid, 256, 0, st>>>(a);
+  else if (nv <= 6) k_ln_fwd<T, 6><<<grid, 256, 0, st>>>(a);
+  else if (nv <= 12) k_ln_fwd<T, 12><<<grid, 256, 0, st>>>(a);
+  else k_ln_fwd<T, 16><<<grid, 256, 0, st>>>(a);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
+  const int grid = ceil_div(a.rows, LN_ROWS_PER_BLOCK);
+  const int nv = ceil_div(a.D, 64);
+  if (nv <= 2) k_ln_bwd<T, 2><<<grid, 256, 0, st>>>(a);
+  else if (nv <= 3) k_ln_bwd<T, 3><<<grid, 256, 0, st>>>(a);
+  else if (nv <= 6) k_ln_bwd<T, 6><<<grid, 256, 0, st>>>(a);
+  else if (nv <= 12) k_ln_bwd<T, 12><<<grid, 256, 0, st>>>(a);
+  else k_ln_bwd<T, 16><<<grid, 256, 0, st>>>(a);
+  UVC_CHECK_LAUNCH();
+  k_ln_bwd_reduce<<<ceil_div(2 * a.D + 2, 64), 256, 0, st>>>(a, grid);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+}  // namespace
+
+extern "C" int uvc_layernorm_bwd_blocks(int32_t rows) { return ceil_div(rows, LN_ROWS_PER_BLOCK); }
+
+extern "C" int uvc_layernorm_fwd(const uvc_ln_args* p, void* stream) {
+  if (int e = check(p)) return e;
+  if (!p->y || !p->beta) return uvc_set_error_msg(UVC_ERR_ARG, "layernorm_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (p->y_is_f32 || p->dtype == UVC_F32) return launch_fwd<float>(*p, st);
+  return launch_fwd<bf16_t>(*p, st);
+}
+
+extern "C" int uvc_layernorm_bwd(const uvc_ln_args* p, void* stream) {
+  if (int e = check(p)) return e;
+  if (!p->dy || !p->dx || !p->partial || !p->dgamma || !p->dbeta) return uvc_set_error_msg(UVC_ERR_ARG, "layernorm_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (p->dy_is_f32 || p->dtype == UVC_F32) return launch_bwd<float>(*p, st);
+  return launch_bwd<bf16_t>(*p, st);
+}

@@ -1,0 +1,205 @@
+"""Thin tensor-level wrappers over the C-ABI kernels (include/uvc_kernels.h).  They check
+devices/dtypes/contiguity, fill the argument structs and enqueue on torch's current HIP
+stream.  No arithmetic happens in Python and there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_NONE, UVC_BF16,
+                   UVC_F32)
+
+__all__ = ["EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RESID", "EPI_BIAS_RESID_GATE", "EPI_DGELU", "UVC_F32",
+           "UVC_BF16"]
+
+
+def tdtype(dtype: int) -> torch.dtype:
+    return torch.float32 if dtype == UVC_F32 else torch.bfloat16
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        L.require_cuda(t)
+        if not t.is_contiguous():
+            raise L.UvcHipError("kernel operands must be contiguous")
+
+
+def _is_f32(t) -> int:
+    return int(t.dtype == torch.float32)
+
+
+def gemm_nt(A, B, C_, *, dtype, epilogue=EPI_NONE, bias=None, R=None, R2=None, aux=None, gate=None, C2=None, alpha=1.0,
+            alpha_ptr=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
+    """C[M,N] = epi(A[M,K] . B[N,K]^T)."""
+    _chk(A, B, C_, bias, R, R2, aux, gate, C2, alpha_ptr)
+    a = L.uvc_gemm_nt_args()
+    a.A, a.B, a.C, a.C2 = L.ptr(A), L.ptr(B), L.ptr(C_), L.ptr(C2)
+    a.bias, a.R, a.R2, a.aux, a.gate, a.alpha_ptr = L.ptr(bias), L.ptr(R), L.ptr(R2), L.ptr(aux), L.ptr(gate), L.ptr(alpha_ptr)
+    a.alpha = alpha
+    a.M = M if M is not None else A.shape[0]
+    a.K = K if K is not None else A.shape[-1]
+    a.N = N if N is not None else B.shape[0]
+    a.lda = lda if lda is not None else a.K
+    a.ldb = ldb if ldb is not None else a.K
+    a.ldc = ldc if ldc is not None else a.N
+    a.ldr = a.ldc
+    a.ldaux = a.ldc
+    a.dtype, a.a_is_f32, a.c_is_f32, a.epilogue = dtype, _is_f32(A), _is_f32(C_), epilogue
+    L.check(L.lib().uvc_gemm_nt(C.byref(a), L.cur_stream()), "uvc_gemm_nt")
+
+
+def gemm_tn_workspace_bytes(M, N1, N2) -> int:
+    b = C.c_int64()
+    s = C.c_int32()
+    L.check(L.lib().uvc_gemm_tn_workspace_bytes(M, N1, N2, C.byref(b), C.byref(s)), "uvc_gemm_tn_workspace_bytes")
+    return int(b.value)
+
+
+def gemm_tn(A, B, C_, workspace, *, dtype, alpha=1.0, alpha_ptr=None, beta=0.0, M=None, N1=None, N2=None, lda=None,
+            ldb=None):
+    """C[N1,N2] = beta*C + alpha * A[M,N1]^T . B[M,N2]."""
+    _chk(A, B, C_, workspace, alpha_ptr)
+    a = L.uvc_gemm_tn_args()
+    a.A, a.B, a.C, a.workspace = L.ptr(A), L.ptr(B), L.ptr(C_), L.ptr(workspace)
+    a.workspace_bytes = workspace.numel() * workspace.element_size()
+    a.alpha_ptr, a.alpha, a.beta = L.ptr(alpha_ptr), alpha, beta
+    a.M = M if M is not None else A.shape[0]
+    a.N1 = N1 if N1 is not None else A.shape[1]
+    a.N2 = N2 if N2 is not None else B.shape[1]
+    a.lda = lda if lda is not None else a.N1
+    a.ldb = ldb if ldb is not None else a.N2
+    a.ldc = a.N2
+    a.dtype, a.a_is_f32 = dtype, _is_f32(A)
+    L.check(L.lib().uvc_gemm_tn(C.byref(a), L.cur_stream()), "uvc_gemm_tn")
+
+
+def _attn_args(qkv, o, lse, B, N, H, dtype, dout=None, dqkv=None, delta=None):
+    _chk(qkv, o, lse, dout, dqkv, delta)
+    a = L.uvc_attn_args()
+    a.qkv, a.o, a.lse, a.dout, a.dqkv, a.delta = (L.ptr(t) for t in (qkv, o, lse, dout, dqkv, delta))
+    a.B, a.N, a.H, a.head_dim, a.dtype = B, N, H, 64, dtype
+    a.scale = 64 ** -0.5
+    return a
+
+
+def attention_fwd(qkv, o, lse, B, N, H, dtype):
+    a = _attn_args(qkv, o, lse, B, N, H, dtype)
+    L.check(L.lib().uvc_attention_fwd(C.byref(a), L.cur_stream()), "uvc_attention_fwd")
+
+
+def attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype):
+    a = _attn_args(qkv, o, lse, B, N, H, dtype, dout, dqkv, delta)
+    L.check(L.lib().uvc_attention_bwd(C.byref(a), L.cur_stream()), "uvc_attention_bwd")
+
+
+def _ln_args(x, gamma, beta, rows, D, dtype, rows_per_group=1, group_stride=None):
+    a = L.uvc_ln_args()
+    a.x, a.gamma, a.beta = L.ptr(x), L.ptr(gamma), L.ptr(beta)
+    a.rows, a.D, a.rows_per_group, a.dtype = rows, D, rows_per_group, dtype
+    a.group_stride = group_stride if group_stride is not None else D * rows_per_group
+    a.eps = 1e-6
+    return a
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, dtype, rows_per_group=1, group_stride=None):
+    _chk(x, gamma, beta, y, mean, rstd)
+    a = _ln_args(x, gamma, beta, rows, D, dtype, rows_per_group, group_stride)
+    a.y, a.mean, a.rstd, a.y_is_f32 = L.ptr(y), L.ptr(mean), L.ptr(rstd), _is_f32(y)
+    L.check(L.lib().uvc_layernorm_fwd(C.byref(a), L.cur_stream()), "uvc_layernorm_fwd")
+
+
+def layernorm_bwd_blocks(rows) -> int:
+    return int(L.lib().uvc_layernorm_bwd_blocks(rows))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, rows, D, dtype, *, add1=None, a1=None, add2=None,
+                  a2=None, dots=None, beta_acc=0.0, rows_per_group=1, group_stride=None):
+    _chk(dy, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, add1, a1, add2, a2, dots)
+    a = _ln_args(x, gamma, None, rows, D, dtype, rows_per_group, group_stride)
+    a.mean, a.rstd, a.dy, a.dx = L.ptr(mean), L.ptr(rstd), L.ptr(dy), L.ptr(dx)
+    a.add1, a.a1, a.add2, a.a2 = L.ptr(add1), L.ptr(a1), L.ptr(add2), L.ptr(a2)
+    a.partial, a.dgamma, a.dbeta, a.dots = L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dots)
+    a.beta_acc, a.dy_is_f32 = beta_acc, _is_f32(dy)
+    L.check(L.lib().uvc_layernorm_bwd(C.byref(a), L.cur_stream()), "uvc_layernorm_bwd")
+
+
+def distill_loss(o, o_kd, y_soft, teacher, loss, d_o, d_okd, row_scratch, alpha, tau, kind=1):
+    _chk(o, o_kd, y_soft, teacher, loss, d_o, d_okd, row_scratch)
+    a = L.uvc_loss_args()
+    a.o, a.o_kd, a.y_soft, a.teacher = L.ptr(o), L.ptr(o_kd), L.ptr(y_soft), L.ptr(teacher)
+    a.loss, a.d_o, a.d_okd, a.row_scratch = L.ptr(loss), L.ptr(d_o), L.ptr(d_okd), L.ptr(row_scratch)
+    a.alpha, a.tau, a.B, a.C, a.kind = alpha, tau, o.shape[0], o.shape[1], kind
+    L.check(L.lib().uvc_distill_loss(C.byref(a), L.cur_stream()), "uvc_distill_loss")
+
+
+def grad_sqnorm(g, partial, sq, accumulate=False, n=None):
+    _chk(g, partial, sq)
+    L.check(L.lib().uvc_grad_sqnorm(L.ptr(g), n if n is not None else g.numel(), L.ptr(partial), L.ptr(sq),
+                                    int(accumulate), L.cur_stream()), "uvc_grad_sqnorm")
+
+
+def adamw_step(p, g, m, v, sq, *, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, max_norm=1.0,
+               p_shadow=None, gnorm_out=None, n=None):
+    _chk(p, g, m, v, sq, p_shadow, gnorm_out)
+    a = L.uvc_adamw_args()
+    a.p, a.g, a.m, a.v, a.p_shadow, a.sq, a.gnorm_out = (L.ptr(t) for t in (p, g, m, v, p_shadow, sq, gnorm_out))
+    a.n = n if n is not None else p.numel()
+    a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.max_norm, a.step = lr, beta1, beta2, eps, weight_decay, max_norm, step
+    L.check(L.lib().uvc_adamw_step(C.byref(a), L.cur_stream()), "uvc_adamw_step")
+
+
+def scale_by_clip(g, sq, max_norm):
+    _chk(g, sq)
+    L.check(L.lib().uvc_scale_by_clip(L.ptr(g), g.numel(), L.ptr(sq), max_norm, L.cur_stream()), "uvc_scale_by_clip")
+
+
+def patchify(x, out, P, dtype):
+    _chk(x, out)
+    B, Cc, S, _ = x.shape
+    L.check(L.lib().uvc_patchify(L.ptr(x), L.ptr(out), B, Cc, S, P, dtype, L.cur_stream()), "uvc_patchify")
+
+
+def assemble_tokens(pe, cls, dist, pos, row_mask, tok, B, P, D, ntok):
+    _chk(pe, cls, dist, pos, row_mask, tok)
+    L.check(L.lib().uvc_assemble_tokens(L.ptr(pe), L.ptr(cls), L.ptr(dist), L.ptr(pos), L.ptr(row_mask), L.ptr(tok), B, P,
+                                        D, ntok, L.cur_stream()), "uvc_assemble_tokens")
+
+
+def assemble_tokens_bwd(dtok, pe, row_mask, dpe, dpos, dcls, ddist, dmask, B, P, D, ntok, dtype, beta_acc=0.0):
+    _chk(dtok, pe, row_mask, dpe, dpos, dcls, ddist, dmask)
+    L.check(L.lib().uvc_assemble_tokens_bwd(L.ptr(dtok), L.ptr(pe), L.ptr(row_mask), L.ptr(dpe), L.ptr(dpos), L.ptr(dcls),
+                                            L.ptr(ddist), L.ptr(dmask), B, P, D, ntok, dtype, _is_f32(dpe), beta_acc,
+                                            L.cur_stream()), "uvc_assemble_tokens_bwd")
+
+
+def colsum_blocks(M) -> int:
+    return int(L.lib().uvc_colsum_blocks(M))
+
+
+def colsum(X, partial, out, dtype, *, M=None, N=None, ldx=None, alpha=1.0, alpha_ptr=None, beta=0.0):
+    _chk(X, partial, out, alpha_ptr)
+    M = M if M is not None else X.shape[0]
+    N = N if N is not None else X.shape[1]
+    L.check(L.lib().uvc_colsum(L.ptr(X), M, N, ldx if ldx is not None else N, dtype, _is_f32(X), L.ptr(partial), L.ptr(out),
+                               alpha, L.ptr(alpha_ptr), beta, L.cur_stream()), "uvc_colsum")
+
+
+def cast_transpose(W, R, Cc, w_cast, wt, dtype):
+    _chk(W, w_cast, wt)
+    L.check(L.lib().uvc_cast_transpose(L.ptr(W), R, Cc, L.ptr(w_cast), L.ptr(wt), dtype, L.cur_stream()), "uvc_cast_transpose")
+
+
+def gate_distrib(g, e, d, Lb, mode, eps):
+    _chk(g, e, d)
+    L.check(L.lib().uvc_gate_distrib(L.ptr(g), L.ptr(e), L.ptr(d), Lb, mode, eps, L.cur_stream()), "uvc_gate_distrib")
+
+
+def gate_grad(g, d, dots, dg, Lb, mode, eps, beta_acc=0.0):
+    _chk(g, d, dots, dg)
+    L.check(L.lib().uvc_gate_grad(L.ptr(g), L.ptr(d), L.ptr(dots), L.ptr(dg), Lb, mode, eps, beta_acc, L.cur_stream()),
+            "uvc_gate_grad")

@@ -153,8 +153,9 @@ int uvc_colsum_blocks(int32_t M);
 int uvc_cast_transpose(const float* W, int32_t R, int32_t C, void* w_bf16, void* wt, int32_t dtype, void* stream);
 /* block-gate distributions (model_distilled.py:480-488): d[L,2] from g[L,2] and Exp(1) draws. */
 int uvc_gate_distrib(const float* g, const float* e, float* d, int32_t L, int32_t mode, float eps, void* stream);
-/* gradient of the gate logits from the two dot products per block:
- * dots [L,2] = { <gA, out>, <gA, x> }; dg written as beta_acc*old + grad. */
+/* gradient of the gate logits from the dot products the LayerNorm-backward kernels leave behind
+ * (DESIGN.md): dots [L+1,2], row l = { <dL/dx_l, x_l>, <dL/dout_l, x_l> } (row L: final norm), so
+ * <dL/dout_l, out_l> = dots[l+1][0]; dg written as beta_acc*old + grad. */
 int uvc_gate_grad(const float* g, const float* d, const float* dots, float* dg, int32_t L, int32_t mode, float eps,
                   float beta_acc, void* stream);
 

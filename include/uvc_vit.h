@@ -1,0 +1,85 @@
+/* C-ABI of the DeiT (DistilledVisionTransformer) forward / backward sequencer on MI355X.
+ *
+ * Replaces, for the Stage-1 hot path, what the reference runs through autograd over
+ * UVC/models/model_distilled.py:429-531 (forward_features + heads) -- one call enqueues the
+ * whole forward (or backward) as a fixed sequence of the kernels of uvc_kernels.h on `stream`.
+ * Parameters live in ONE flat float32 buffer (layout from uvc_vit_layout) so the optimiser,
+ * the gradient all-reduce and the UVC engine address them without per-tensor launches; the
+ * Python module (uvc_amd/model_distilled.py) exposes them under the reference's state_dict
+ * names as views.
+ *
+ * No allocation inside: the caller provides `workspace` (uvc_vit_workspace_bytes) which holds
+ * the activations saved for backward and all scratch.
+ */
+#ifndef UVC_VIT_H
+#define UVC_VIT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVC_VIT_MAX_DEPTH 32
+
+typedef struct uvc_vit_cfg {
+  int32_t img_size, patch_size, in_chans, num_classes, embed_dim, depth, num_heads, hidden;
+  int32_t ntok;    /* 1, or 2 with the distillation token (enable_dist) */
+  int32_t dtype;   /* UVC_F32 (exact float32 MFMA) or UVC_BF16 */
+} uvc_vit_cfg;
+
+/* element offsets into the flat parameter / gradient buffers (every tensor 16-byte aligned) */
+typedef struct uvc_vit_offsets {
+  int64_t cls_token, dist_token, pos_embed, patch_w, patch_b;
+  /* per block: norm1.w norm1.b qkv.w qkv.b proj.w proj.b norm2.w norm2.b fc1.w fc1.b fc2.w fc2.b */
+  int64_t blk[UVC_VIT_MAX_DEPTH][12];
+  int64_t norm_w, norm_b, head_w, head_b, headd_w, headd_b;
+  int64_t n_main;        /* [0, n_main) always receives gradients in Stage-1 */
+  int64_t gate;          /* block_skip_gating [L,2] (no gradient during warm-up) */
+  int64_t gumbel_w, gumbel_b;   /* patch-gating scorer (gradient only in patch-gating mode 2) */
+  int64_t patch_gating;  /* [P] (mode 1) */
+  int64_t skip[UVC_VIT_MAX_DEPTH][2];  /* attn_skip_gating, mlp_skip_gating: never get gradients */
+  int64_t n_total;
+} uvc_vit_offsets;
+
+/* element offsets (in units of T) into the shadow buffer: cast copies W and transposed copies W^T */
+typedef struct uvc_vit_shadow_offsets {
+  int64_t patch_w;
+  int64_t blk_w[UVC_VIT_MAX_DEPTH][4];    /* qkv proj fc1 fc2   [out,in] */
+  int64_t blk_wt[UVC_VIT_MAX_DEPTH][4];   /* transposed          [in,out] */
+  int64_t head_w, head_wt, headd_w, headd_wt;
+  int64_t n_total;
+} uvc_vit_shadow_offsets;
+
+int uvc_vit_layout(const uvc_vit_cfg* cfg, uvc_vit_offsets* off, uvc_vit_shadow_offsets* soff);
+int64_t uvc_vit_workspace_bytes(const uvc_vit_cfg* cfg, int32_t batch, int32_t training);
+
+/* refresh the T-typed shadows (W and W^T) from the float32 master weights */
+int uvc_vit_update_shadows(const uvc_vit_cfg* cfg, const float* params, void* shadow, void* stream);
+
+typedef struct uvc_vit_io {
+  const float* params;      /* flat float32 parameters */
+  void* shadow;             /* flat T shadows */
+  float* grads;             /* flat float32 gradients (backward) */
+  void* workspace; int64_t workspace_bytes;
+  const float* x;           /* [B, C, S, S] float32 */
+  float* logits;            /* [B, num_classes] */
+  float* logits_dist;       /* [B, num_classes], only with ntok == 2 */
+  const float* d_logits;    /* backward inputs */
+  const float* d_logits_dist;
+  const float* gate_d;      /* device [L,2] block-gate distributions (model_distilled.py:480-488) or NULL */
+  const int32_t* run_block; /* HOST [L] 0/1: hard block skip when gate_d is NULL (:496-500); NULL = run all */
+  const float* patch_mask;  /* device [B,P] token mask (patch gating) or NULL */
+  float* d_patch_mask;      /* backward: optional [B,P] gradient wrt patch_mask */
+  int32_t batch;
+  int32_t training;         /* forward: keep activations for backward */
+  int32_t gate_mode;        /* 0 warm-up / none, 1 soft Gumbel, 2 softL0: selects d(gate logits) formula */
+  float gate_eps;           /* softL0 eps */
+  float accumulate;         /* backward: 0 = overwrite gradients, 1 = add (gradient accumulation) */
+} uvc_vit_io;
+
+int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);
+int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -79,9 +79,9 @@ def param_shapes(cfg: VitConfig, enable_patch_gating: int = 0) -> "Dict[str, Tup
     D, Fh, C = cfg.embed_dim, cfg.hidden, cfg.num_classes
     shapes: Dict[str, Tuple[int, ...]] = {}
     shapes["cls_token"] = (1, 1, D)
-    if cfg.enable_dist:
-        shapes["dist_token"] = (1, 1, D)
     shapes["pos_embed"] = (1, cfg.seq_len, D)
+    if cfg.enable_dist:                 # registered after pos_embed (model_distilled.py:277 is None, :393 re-registers)
+        shapes["dist_token"] = (1, 1, D)
     shapes["block_skip_gating"] = (cfg.depth, 2)
     if enable_patch_gating == 1:
         shapes["patch_gating"] = (1, cfg.num_patches, 1)

@@ -37,9 +37,9 @@ SCENARIOS = {
 }
 
 MODELS = {
-    "micro": dict(img_size=64, patch_size=16, num_classes=10, embed_dim=128, depth=2, num_heads=2,
+    "micro": dict(img_size=64, patch_size=16, num_classes=16, embed_dim=128, depth=2, num_heads=2,
                   mlp_ratio=4.0, enable_dist=0, weight_gain=3.0),
-    "micro_dist": dict(img_size=64, patch_size=16, num_classes=10, embed_dim=128, depth=2, num_heads=2,
+    "micro_dist": dict(img_size=64, patch_size=16, num_classes=16, embed_dim=128, depth=2, num_heads=2,
                        mlp_ratio=4.0, enable_dist=1, weight_gain=3.0),
     "deit_tiny": dict(img_size=224, patch_size=16, num_classes=1000, embed_dim=192, depth=12,
                       num_heads=3, mlp_ratio=4.0, enable_dist=0, weight_gain=2.0),

@@ -15,7 +15,7 @@ def declared_symbols():
     for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
         src = open(h).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        for m in re.finditer(r"^\s*(?:int|const char\*)\s+(uvc_\w+)\s*\(", src, flags=re.M):
+        for m in re.finditer(r"^\s*(?:int|int64_t|const char\*)\s+(uvc_\w+)\s*\(", src, flags=re.M):
             names.append(m.group(1))
     return names
 

@@ -307,7 +307,10 @@ def test_gate_distrib_and_grad():
         gx2, gx = rnd(Lb, seed=72).double(), rnd(Lb, seed=73).double()       # <gA,x2>, <gA,x> per block
         (dd[:, 1] * gx2 + dd[:, 0] * gx).sum().backward()
         A = (dd[:, 1] * gx2 + dd[:, 0] * gx).detach()
-        dots = torch.stack([A, gx], 1).float().contiguous()
+        dots = torch.zeros(Lb + 1, 2, dtype=torch.float64, device=dev())
+        dots[1:, 0] = A            # <gA_l, out_l> is left by block l+1's norm1 backward (row l+1, col 0)
+        dots[:Lb, 1] = gx          # <gA_l, x_l> by block l's own (row l, col 1)
+        dots = dots.float().contiguous()
         ops.gate_distrib(g, e, d, Lb, mode, 0.1)
         dg = torch.empty(Lb, 2, device=dev())
         ops.gate_grad(g, d, dots, dg, Lb, mode, 0.1)

@@ -99,21 +99,25 @@ def test_known_answers_deit_tiny():
     assert abs(total - 5.652864) < 1e-9 and abs(float(gold["total_param"]) - total) < 1e-6
 
 
-def test_state_dict_layout_matches_reference():
-    """Checkpoint layout = bare state_dict incl. mask buffers."""
-    gold = load_golden("tiny8_train")
+@pytest.mark.parametrize("name,nkeys", [("tiny8_train", 255), ("micro_deit", None), ("micro_patch1", None)])
+def test_state_dict_layout_matches_reference(name, nkeys):
+    """Checkpoint layout = bare state_dict incl. mask buffers: key order and shapes."""
+    import json
+    from helpers import vit_config
+    gold = load_golden(name)
+    r = SC.recipe(name)
     keys = [str(k) for k in gold["state_dict_keys"]]
-    shapes = OV.param_shapes(OV.VitConfig())
+    shapes = OV.param_shapes(vit_config(r), r["enable_patch_gating"])
     pkeys = [k for k in keys if not k.endswith(".mask")]
     assert pkeys == list(shapes.keys())
-    import json
     for k, sh in zip(keys, gold["state_dict_shapes"]):
         sh = tuple(json.loads(str(sh)))
         if k.endswith(".mask"):
             assert sh == tuple(shapes[k[:-5] + ".weight"])
         else:
             assert sh == tuple(shapes[k])
-    assert len(keys) == 255
+    if nkeys:
+        assert len(keys) == nkeys
 
 
 def test_zlr_schedule_and_eps_decay_known_answers():

@@ -115,8 +115,12 @@ _SIGNATURES = {
 }
 
 
+# include/uvc_vit.h (bound in uvc_amd/model_distilled.py next to its ctypes structures)
+VIT_SYMBOLS = ["uvc_vit_layout", "uvc_vit_workspace_bytes", "uvc_vit_update_shadows", "uvc_vit_forward", "uvc_vit_backward"]
+
+
 def exported_symbols():
-    return list(_SIGNATURES) + ["uvc_last_error"]
+    return list(_SIGNATURES) + ["uvc_last_error"] + VIT_SYMBOLS
 
 
 def lib():

@@ -177,11 +177,13 @@ __global__ void k_gate_distrib(const float* g, const float* e, float* d, int L, 
   }
   d[2 * l] = d0; d[2 * l + 1] = d1;
 }
-// out = d1*x2 + d0*x  =>  dL/dd1 - dL/dd0 = <gA, x2 - x> = (<gA,out> - <gA,x>) / d1.
+// out = d1*x2 + d0*x  =>  dL/dd1 - dL/dd0 = <gA, x2 - x> = (<gA,out> - <gA,x>) / d1 = (A - B) / d1.
 __global__ void k_gate_grad(const float* g, const float* d, const float* dots, float* dg, int L, int mode, float eps, float beta) {
   const int l = threadIdx.x;
   if (l >= L) return;
-  const float A = dots[2 * l], Bv = dots[2 * l + 1];
+  // raw layout written by the LayerNorm-backward kernels: row l = block l's norm1 backward
+  // { <dL/dx_l, x_l>, <gA_l, x_l> }, row L = final norm.  A_l = <gA_l, x_{l+1}> = row l+1, col 0.
+  const float A = dots[2 * (l + 1)], Bv = dots[2 * l + 1];
   float g0 = 0.f, g1 = 0.f;
   if (mode == 1) {               // softmax((g+G)/tau): dg1 = d0*d1/tau * <gA, x2-x> = d0/tau * (A - B)
     g1 = d[2 * l] / 0.5f * (A - Bv);

@@ -1,0 +1,353 @@
+// DeiT forward / backward sequencer: enqueues the fixed kernel sequence of one
+// DistilledVisionTransformer pass (UVC/models/model_distilled.py:429-531) on a HIP stream.
+// Host code only; every arithmetic step is one of the kernels behind uvc_kernels.h.
+#include "common.h"
+#include "../../include/uvc_kernels.h"
+#include "../../include/uvc_vit.h"
+#include <string.h>
+
+namespace {
+
+struct Dims {
+  int B, S, P, C, D, L, H, F, NC, ntok, np, N, M, K0, dtype;
+  size_t tsz;
+};
+Dims dims_of(const uvc_vit_cfg& c, int B) {
+  Dims d;
+  d.B = B; d.S = c.img_size; d.P = c.patch_size; d.C = c.in_chans; d.D = c.embed_dim; d.L = c.depth; d.H = c.num_heads;
+  d.F = c.hidden; d.NC = c.num_classes; d.ntok = c.ntok; d.np = (c.img_size / c.patch_size) * (c.img_size / c.patch_size);
+  d.N = d.np + d.ntok; d.M = B * d.N; d.K0 = c.in_chans * c.patch_size * c.patch_size; d.dtype = c.dtype;
+  d.tsz = c.dtype == UVC_F32 ? 4 : 2;
+  return d;
+}
+
+int check_cfg(const uvc_vit_cfg* c) {
+  if (!c) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: null cfg");
+  if (c->depth <= 0 || c->depth > UVC_VIT_MAX_DEPTH) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: depth out of range");
+  if (c->embed_dim != c->num_heads * 64) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit: head_dim must be 64");
+  if (c->embed_dim % 64 || c->hidden % 64 || c->embed_dim > 1024) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit: embed_dim/hidden must be multiples of 64, embed_dim <= 1024");
+  if (c->img_size % c->patch_size || c->patch_size % 4) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: img_size/patch_size");
+  if (c->ntok != 1 && c->ntok != 2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: ntok must be 1 or 2");
+  if (c->dtype != UVC_F32 && c->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: dtype");
+  if (c->num_classes <= 0 || c->num_classes % 8) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit: num_classes must be a positive multiple of 8");
+  const int np = (c->img_size / c->patch_size) * (c->img_size / c->patch_size);
+  if (np + c->ntok > 256) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit: sequence length > 256");
+  return UVC_OK;
+}
+
+inline int64_t al4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+
+// ---- workspace carving ---------------------------------------------------------------------------
+struct Carver {
+  char* base; int64_t off;
+  void* take(int64_t bytes) { void* p = base ? base + off : nullptr; off += (bytes + 255) & ~(int64_t)255; return p; }
+};
+
+struct BlockBufs {
+  float* x; void* h1; void* qkv; void* o; float* lse; float* mean1; float* rstd1;
+  float* x1; void* h2; float* mean2; float* rstd2; void* a; void* u;
+};
+struct Work {
+  void* patches; float* pe; BlockBufs blk[UVC_VIT_MAX_DEPTH]; float* xL;
+  void* hc; float* meanf; float* rstdf;
+  // backward scratch
+  float* gA; float* gB; void* dA; void* dH; void* dqkv; float* delta; float* ln_partial; float* cs_partial;
+  void* tn_ws; int64_t tn_ws_bytes; float* dotsraw; void* dhc; void* dpe;
+};
+
+int64_t max_tn_ws(const Dims& d) {
+  int64_t best = 0, b; int s;
+  const int shapes[6][3] = {{d.M, d.D, d.F}, {d.M, d.F, d.D}, {d.M, d.D, d.D}, {d.M, 3 * d.D, d.D}, {d.B, d.NC, d.D}, {d.B * d.np, d.D, d.K0}};
+  for (auto& sh : shapes) { uvc_gemm_tn_workspace_bytes(sh[0], sh[1], sh[2], &b, &s); if (b > best) best = b; }
+  return best;
+}
+
+int64_t carve(const Dims& d, int training, char* base, Work& w) {
+  Carver c{base, 0};
+  const int64_t MD = (int64_t)d.M * d.D, MF = (int64_t)d.M * d.F;
+  w.patches = c.take((int64_t)d.B * d.np * d.K0 * d.tsz);
+  w.pe = (float*)c.take((int64_t)d.B * d.np * d.D * 4);
+  const int nb = training ? d.L : 1;
+  for (int l = 0; l < nb; ++l) {
+    BlockBufs& b = w.blk[l];
+    b.x = (float*)c.take(MD * 4);
+    b.h1 = c.take(MD * d.tsz); b.qkv = c.take(3 * MD * d.tsz); b.o = c.take(MD * d.tsz);
+    b.lse = (float*)c.take((int64_t)d.B * d.H * d.N * 4);
+    b.mean1 = (float*)c.take((int64_t)d.M * 4); b.rstd1 = (float*)c.take((int64_t)d.M * 4);
+    b.x1 = (float*)c.take(MD * 4);
+    b.h2 = c.take(MD * d.tsz);
+    b.mean2 = (float*)c.take((int64_t)d.M * 4); b.rstd2 = (float*)c.take((int64_t)d.M * 4);
+    b.a = c.take(MF * d.tsz); b.u = c.take(MF * d.tsz);
+  }
+  w.xL = (float*)c.take(MD * 4);
+  if (!training) {                       // inference: every block reuses block 0's buffers, x ping-pongs with xL
+    for (int l = 1; l < d.L; ++l) { w.blk[l] = w.blk[0]; }
+  }
+  w.hc = c.take((int64_t)d.B * d.ntok * d.D * d.tsz);
+  w.meanf = (float*)c.take((int64_t)d.B * d.ntok * 4); w.rstdf = (float*)c.take((int64_t)d.B * d.ntok * 4);
+  if (training) {
+    w.gA = (float*)c.take(MD * 4); w.gB = (float*)c.take(MD * 4);
+    w.dA = c.take(MF * d.tsz); w.dH = c.take(MD * d.tsz); w.dqkv = c.take(3 * MD * d.tsz);
+    w.delta = (float*)c.take((int64_t)d.B * d.H * d.N * 4);
+    w.ln_partial = (float*)c.take((int64_t)uvc_layernorm_bwd_blocks(d.M) * (2 * d.D + 2) * 4);
+    const int maxN = d.F > 3 * d.D ? d.F : 3 * d.D;
+    w.cs_partial = (float*)c.take((int64_t)uvc_colsum_blocks(d.M) * (maxN > d.NC ? maxN : d.NC) * 4);
+    w.tn_ws_bytes = max_tn_ws(d);
+    w.tn_ws = c.take(w.tn_ws_bytes);
+    w.dotsraw = (float*)c.take((int64_t)(d.L + 1) * 2 * 4);
+    w.dhc = c.take((int64_t)d.B * d.ntok * d.D * d.tsz);
+    w.dpe = c.take((int64_t)d.B * d.np * d.D * d.tsz);
+  }
+  return c.off;
+}
+
+// ---- small helpers around the kernel entry points -----------------------------------------------
+struct Ctx { const uvc_vit_cfg* cfg; Dims d; uvc_vit_offsets off; uvc_vit_shadow_offsets soff; const uvc_vit_io* io; void* st; Work w; };
+
+const void* sh(const Ctx& c, int64_t off) { return (const char*)c.io->shadow + off * c.d.tsz; }
+// GEMM B operand [out,in]: float32 mode reads the master weights directly
+const void* wmat(const Ctx& c, int64_t poff, int64_t soff) { return c.d.dtype == UVC_F32 ? (const void*)(c.io->params + poff) : sh(c, soff); }
+
+int nt(const Ctx& c, const void* A, int a_f32, const void* B, void* C, int c_f32, int M, int N, int K, int epi, const float* bias = nullptr,
+       const float* R = nullptr, const float* R2 = nullptr, const void* aux = nullptr, const float* gate = nullptr, void* C2 = nullptr,
+       const float* alpha_ptr = nullptr, int lda = 0, int ldc = 0) {
+  uvc_gemm_nt_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.R = R; a.R2 = R2; a.aux = aux; a.gate = gate; a.alpha_ptr = alpha_ptr;
+  a.alpha = 1.0f; a.M = M; a.N = N; a.K = K; a.lda = lda ? lda : K; a.ldb = K; a.ldc = ldc ? ldc : N; a.ldr = a.ldc; a.ldaux = a.ldc;
+  a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32; a.c_is_f32 = c_f32 || c.d.dtype == UVC_F32; a.epilogue = epi;
+  return uvc_gemm_nt(&a, c.st);
+}
+int tn(const Ctx& c, const void* A, int a_f32, const void* B, float* C, int M, int N1, int N2, const float* alpha_ptr = nullptr, int lda = 0, int ldb = 0) {
+  uvc_gemm_tn_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.B = B; a.C = C; a.workspace = c.w.tn_ws; a.workspace_bytes = c.w.tn_ws_bytes; a.alpha_ptr = alpha_ptr; a.alpha = 1.0f;
+  a.beta = c.io->accumulate; a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda ? lda : N1; a.ldb = ldb ? ldb : N2; a.ldc = N2;
+  a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32;
+  return uvc_gemm_tn(&a, c.st);
+}
+int csum(const Ctx& c, const void* X, int x_f32, float* out, int M, int N, const float* alpha_ptr = nullptr, int ldx = 0) {
+  return uvc_colsum(X, M, N, ldx ? ldx : N, c.d.dtype, x_f32 || c.d.dtype == UVC_F32, c.w.cs_partial, out, 1.0f, alpha_ptr, c.io->accumulate, c.st);
+}
+int ln_fwd(const Ctx& c, const float* x, int64_t pw, int64_t pb, void* y, float* mean, float* rstd, int rows, int rpg, int64_t gs) {
+  uvc_ln_args a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.gamma = c.io->params + pw; a.beta = c.io->params + pb; a.y = y; a.mean = mean; a.rstd = rstd; a.eps = 1e-6f;
+  a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
+  return uvc_layernorm_fwd(&a, c.st);
+}
+int ln_bwd(const Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, float* dx,
+           const float* add1, const float* a1, const float* add2, const float* a2, float* dots, int rows, int rpg, int64_t gs) {
+  uvc_ln_args a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.gamma = c.io->params + pw; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx; a.add1 = add1; a.a1 = a1;
+  a.add2 = add2; a.a2 = a2; a.partial = c.w.ln_partial; a.dgamma = c.io->grads + pw; a.dbeta = c.io->grads + pb; a.dots = dots;
+  a.eps = 1e-6f; a.beta_acc = c.io->accumulate; a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
+  return uvc_layernorm_bwd(&a, c.st);
+}
+int attn(const Ctx& c, const BlockBufs& b, bool bwd) {
+  uvc_attn_args a;
+  memset(&a, 0, sizeof(a));
+  a.qkv = b.qkv; a.o = b.o; a.lse = b.lse; a.dout = c.w.dH; a.dqkv = c.w.dqkv; a.delta = c.w.delta;
+  a.B = c.d.B; a.N = c.d.N; a.H = c.d.H; a.head_dim = 64; a.dtype = c.d.dtype; a.scale = 0.125f;
+  return bwd ? uvc_attention_bwd(&a, c.st) : uvc_attention_fwd(&a, c.st);
+}
+
+#define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
+
+int setup(Ctx& c, const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream, bool bwd) {
+  TRY(check_cfg(cfg));
+  if (!io || !io->params || !io->workspace || io->batch <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: null io member");
+  if (cfg->dtype == UVC_BF16 && !io->shadow) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: bf16 mode needs the shadow buffer");
+  if (!io->shadow) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: shadow buffer (W^T copies) missing");
+  c.cfg = cfg; c.io = io; c.st = stream; c.d = dims_of(*cfg, io->batch);
+  TRY(uvc_vit_layout(cfg, &c.off, &c.soff));
+  const int64_t need = carve(c.d, bwd ? 1 : io->training, (char*)io->workspace, c.w);
+  if (io->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: workspace too small");
+  return UVC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int uvc_vit_layout(const uvc_vit_cfg* cfg, uvc_vit_offsets* off, uvc_vit_shadow_offsets* soff) {
+  TRY(check_cfg(cfg));
+  const Dims d = dims_of(*cfg, 1);
+  if (off) {
+    memset(off, 0xff, sizeof(*off));
+    int64_t o = 0;
+    auto put = [&](int64_t& slot, int64_t n) { slot = o; o += al4(n); };
+    put(off->cls_token, d.D);
+    if (d.ntok == 2) put(off->dist_token, d.D);
+    put(off->pos_embed, (int64_t)d.N * d.D);
+    put(off->patch_w, (int64_t)d.D * d.K0); put(off->patch_b, d.D);
+    for (int l = 0; l < d.L; ++l) {
+      int64_t* b = off->blk[l];
+      put(b[0], d.D); put(b[1], d.D); put(b[2], (int64_t)3 * d.D * d.D); put(b[3], 3 * d.D); put(b[4], (int64_t)d.D * d.D); put(b[5], d.D);
+      put(b[6], d.D); put(b[7], d.D); put(b[8], (int64_t)d.F * d.D); put(b[9], d.F); put(b[10], (int64_t)d.D * d.F); put(b[11], d.D);
+    }
+    put(off->norm_w, d.D); put(off->norm_b, d.D);
+    put(off->head_w, (int64_t)d.NC * d.D); put(off->head_b, d.NC);
+    if (d.ntok == 2) { put(off->headd_w, (int64_t)d.NC * d.D); put(off->headd_b, d.NC); }
+    off->n_main = o;
+    put(off->gate, 2 * d.L);
+    put(off->gumbel_w, d.D); put(off->gumbel_b, 1);
+    put(off->patch_gating, d.np);
+    for (int l = 0; l < d.L; ++l) { put(off->skip[l][0], 2); put(off->skip[l][1], 2); }
+    off->n_total = o;
+  }
+  if (soff) {
+    memset(soff, 0xff, sizeof(*soff));
+    int64_t o = 0;
+    auto put = [&](int64_t& slot, int64_t n) { slot = o; o += (n + 7) & ~(int64_t)7; };
+    put(soff->patch_w, (int64_t)d.D * d.K0);
+    const int64_t sz[4] = {(int64_t)3 * d.D * d.D, (int64_t)d.D * d.D, (int64_t)d.F * d.D, (int64_t)d.D * d.F};
+    for (int l = 0; l < d.L; ++l)
+      for (int j = 0; j < 4; ++j) { put(soff->blk_w[l][j], sz[j]); put(soff->blk_wt[l][j], sz[j]); }
+    put(soff->head_w, (int64_t)d.NC * d.D); put(soff->head_wt, (int64_t)d.NC * d.D);
+    if (d.ntok == 2) { put(soff->headd_w, (int64_t)d.NC * d.D); put(soff->headd_wt, (int64_t)d.NC * d.D); }
+    soff->n_total = o;
+  }
+  return UVC_OK;
+}
+
+extern "C" int64_t uvc_vit_workspace_bytes(const uvc_vit_cfg* cfg, int32_t batch, int32_t training) {
+  if (check_cfg(cfg) || batch <= 0) return -1;
+  Work w;
+  return carve(dims_of(*cfg, batch), training, nullptr, w);
+}
+
+extern "C" int uvc_vit_update_shadows(const uvc_vit_cfg* cfg, const float* params, void* shadow, void* stream) {
+  TRY(check_cfg(cfg));
+  if (!params || !shadow) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_update_shadows: null pointer");
+  const Dims d = dims_of(*cfg, 1);
+  uvc_vit_offsets off; uvc_vit_shadow_offsets so;
+  TRY(uvc_vit_layout(cfg, &off, &so));
+  char* S = (char*)shadow;
+  const bool f32 = d.dtype == UVC_F32;           // float32 mode: only the transposed copies are needed
+  auto one = [&](int64_t p, int R, int C, int64_t sw, int64_t swt) -> int {
+    return uvc_cast_transpose(params + p, R, C, (f32 || sw < 0) ? nullptr : S + sw * d.tsz, swt < 0 ? nullptr : S + swt * d.tsz, d.dtype, stream);
+  };
+  if (!f32) TRY(one(off.patch_w, d.D, d.K0, so.patch_w, -1));
+  const int RC[4][2] = {{3 * d.D, d.D}, {d.D, d.D}, {d.F, d.D}, {d.D, d.F}};
+  const int pi[4] = {2, 4, 8, 10};
+  for (int l = 0; l < d.L; ++l)
+    for (int j = 0; j < 4; ++j) TRY(one(off.blk[l][pi[j]], RC[j][0], RC[j][1], so.blk_w[l][j], so.blk_wt[l][j]));
+  TRY(one(off.head_w, d.NC, d.D, so.head_w, so.head_wt));
+  if (d.ntok == 2) TRY(one(off.headd_w, d.NC, d.D, so.headd_w, so.headd_wt));
+  return UVC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream) {
+  Ctx c;
+  memset(&c.w, 0, sizeof(c.w));
+  TRY(setup(c, cfg, io, stream, false));
+  if (!io->x || !io->logits || (cfg->ntok == 2 && !io->logits_dist)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_forward: null io member");
+  const Dims& d = c.d;
+  const float* P = io->params;
+  const uvc_vit_offsets& o = c.off;
+  Work& w = c.w;
+  const int rows_p = d.B * d.np;
+  // patch embedding (PatchEmbed.forward :145-153) + token assembly (:434-471)
+  TRY(uvc_patchify(io->x, w.patches, d.B, d.C, d.S, d.P, d.dtype, stream));
+  TRY(nt(c, w.patches, 0, wmat(c, o.patch_w, c.soff.patch_w), w.pe, 1, rows_p, d.D, d.K0, UVC_EPI_BIAS, P + o.patch_b));
+  float* x0 = w.blk[0].x;
+  TRY(uvc_assemble_tokens(w.pe, P + o.cls_token, d.ntok == 2 ? P + o.dist_token : nullptr, P + o.pos_embed, io->patch_mask, x0, d.B, d.np,
+                          d.D, d.ntok, stream));
+  float* xin = x0;
+  for (int l = 0; l < d.L; ++l) {
+    float* xout = io->training ? (l + 1 < d.L ? w.blk[l + 1].x : w.xL) : (xin == w.blk[0].x ? w.xL : w.blk[0].x);
+    if (!io->gate_d && io->run_block && !io->run_block[l]) {        // hard skip (:496-500)
+      if (io->training) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit_forward: hard block skip is an inference path");
+      continue;
+    }
+    const BlockBufs& b = w.blk[l];
+    const int64_t* q = o.blk[l];
+    TRY(ln_fwd(c, xin, q[0], q[1], b.h1, b.mean1, b.rstd1, d.M, 1, d.D));
+    TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, UVC_EPI_BIAS, P + q[3]));
+    TRY(attn(c, b, false));
+    TRY(nt(c, b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), b.x1, 1, d.M, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xin));
+    TRY(ln_fwd(c, b.x1, q[6], q[7], b.h2, b.mean2, b.rstd2, d.M, 1, d.D));
+    TRY(nt(c, b.h2, 0, wmat(c, q[8], c.soff.blk_w[l][2]), b.a, 0, d.M, d.F, d.D, UVC_EPI_BIAS_GELU, P + q[9], nullptr, nullptr, nullptr, nullptr, b.u));
+    if (io->gate_d)
+      TRY(nt(c, b.u, 0, wmat(c, q[10], c.soff.blk_w[l][3]), xout, 1, d.M, d.D, d.F, UVC_EPI_BIAS_RESID_GATE, P + q[11], b.x1, xin, nullptr, io->gate_d + 2 * l));
+    else
+      TRY(nt(c, b.u, 0, wmat(c, q[10], c.soff.blk_w[l][3]), xout, 1, d.M, d.D, d.F, UVC_EPI_BIAS_RESID, P + q[11], b.x1));
+    xin = xout;
+  }
+  if (io->training && xin != w.xL) return uvc_set_error_msg(UVC_ERR_LAUNCH, "uvc_vit_forward: internal buffer chain broken");
+  // final norm on the class(/dist) token rows only (:507-508), then the head(s) (:522-526)
+  TRY(ln_fwd(c, xin, o.norm_w, o.norm_b, w.hc, w.meanf, w.rstdf, d.B * d.ntok, d.ntok, (int64_t)d.N * d.D));
+  TRY(nt(c, w.hc, 0, wmat(c, o.head_w, c.soff.head_w), io->logits, 1, d.B, d.NC, d.D, UVC_EPI_BIAS, P + o.head_b, nullptr, nullptr, nullptr, nullptr,
+         nullptr, nullptr, d.ntok * d.D));
+  if (d.ntok == 2)
+    TRY(nt(c, (const char*)w.hc + (size_t)d.D * d.tsz, 0, wmat(c, o.headd_w, c.soff.headd_w), io->logits_dist, 1, d.B, d.NC, d.D, UVC_EPI_BIAS,
+           P + o.headd_b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d.ntok * d.D));
+  return UVC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream) {
+  Ctx c;
+  memset(&c.w, 0, sizeof(c.w));
+  TRY(setup(c, cfg, io, stream, true));
+  if (!io->grads || !io->d_logits || (cfg->ntok == 2 && !io->d_logits_dist)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_backward: null io member");
+  const Dims& d = c.d;
+  const float* P = io->params;
+  float* G = io->grads;
+  const uvc_vit_offsets& o = c.off;
+  const uvc_vit_shadow_offsets& so = c.soff;
+  Work& w = c.w;
+  hipStream_t hs = (hipStream_t)stream;
+  const int rh = d.B * d.ntok;
+  // heads: dhc = dlogits . W ; dW = dlogits^T . hc ; db = colsum(dlogits)
+  TRY(nt(c, io->d_logits, 1, sh(c, so.head_wt), w.dhc, 0, d.B, d.D, d.NC, UVC_EPI_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+         d.ntok * d.D));
+  TRY(tn(c, io->d_logits, 1, w.hc, G + o.head_w, d.B, d.NC, d.D, nullptr, 0, d.ntok * d.D));
+  TRY(csum(c, io->d_logits, 1, G + o.head_b, d.B, d.NC));
+  if (d.ntok == 2) {
+    TRY(nt(c, io->d_logits_dist, 1, sh(c, so.headd_wt), (char*)w.dhc + (size_t)d.D * d.tsz, 0, d.B, d.D, d.NC, UVC_EPI_NONE, nullptr, nullptr, nullptr,
+           nullptr, nullptr, nullptr, nullptr, 0, d.ntok * d.D));
+    TRY(tn(c, io->d_logits_dist, 1, (const char*)w.hc + (size_t)d.D * d.tsz, G + o.headd_w, d.B, d.NC, d.D, nullptr, 0, d.ntok * d.D));
+    TRY(csum(c, io->d_logits_dist, 1, G + o.headd_b, d.B, d.NC));
+  }
+  // final norm backward -> gA = dL/dx_L (zero except the token rows)
+  hipError_t he = hipMemsetAsync(w.gA, 0, (size_t)d.M * d.D * 4, hs);
+  if (he != hipSuccess) return uvc_set_error(he, __FILE__, __LINE__);
+  TRY(ln_bwd(c, w.dhc, w.xL, o.norm_w, o.norm_b, w.meanf, w.rstdf, w.gA, nullptr, nullptr, nullptr, nullptr, w.dotsraw + 2 * d.L, rh, d.ntok,
+             (int64_t)d.N * d.D));
+  for (int l = d.L - 1; l >= 0; --l) {
+    const BlockBufs& b = w.blk[l];
+    const int64_t* q = o.blk[l];
+    const float* g0 = io->gate_d ? io->gate_d + 2 * l : nullptr;       // d0
+    const float* g1 = io->gate_d ? io->gate_d + 2 * l + 1 : nullptr;   // d1
+    // MLP: out = d1*(x1 + fc2(u)) + d0*x
+    TRY(nt(c, w.gA, 1, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
+    TRY(tn(c, w.gA, 1, b.u, G + q[10], d.M, d.D, d.F, g1));
+    TRY(csum(c, w.gA, 1, G + q[11], d.M, d.D, g1));
+    TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
+    TRY(tn(c, w.dA, 0, b.h2, G + q[8], d.M, d.F, d.D));
+    TRY(csum(c, w.dA, 0, G + q[9], d.M, d.F));
+    TRY(ln_bwd(c, w.dH, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr, d.M, 1, d.D));   // gB = dL/dx1
+    // attention
+    TRY(nt(c, w.gB, 1, sh(c, so.blk_wt[l][1]), w.dH, 0, d.M, d.D, d.D, UVC_EPI_NONE));                                      // dO
+    TRY(tn(c, w.gB, 1, b.o, G + q[4], d.M, d.D, d.D));
+    TRY(csum(c, w.gB, 1, G + q[5], d.M, d.D));
+    TRY(attn(c, b, true));
+    TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));
+    TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], d.M, 3 * d.D, d.D));
+    TRY(csum(c, w.dqkv, 0, G + q[3], d.M, 3 * d.D));
+    // gA <- dL/dx_l = LN1'(dH) + gB + d0*gA ; dots: <new gA, x_l>, <old gA, x_l>
+    TRY(ln_bwd(c, w.dH, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0, w.dotsraw + 2 * l, d.M, 1, d.D));
+  }
+  // gate logits (block_skip_gating) gradient
+  if (io->gate_d && io->gate_mode != 0)
+    TRY(uvc_gate_grad(P + o.gate, io->gate_d, w.dotsraw, G + o.gate, d.L, io->gate_mode, io->gate_eps, io->accumulate, stream));
+  // token assembly + patch embedding
+  TRY(uvc_assemble_tokens_bwd(w.gA, w.pe, io->patch_mask, w.dpe, G + o.pos_embed, G + o.cls_token, d.ntok == 2 ? G + o.dist_token : nullptr,
+                              io->d_patch_mask, d.B, d.np, d.D, d.ntok, d.dtype, 0, io->accumulate, stream));
+  TRY(tn(c, w.dpe, 0, w.patches, G + o.patch_w, d.B * d.np, d.D, d.K0));
+  TRY(csum(c, w.dpe, 0, G + o.patch_b, d.B * d.np, d.D));
+  return UVC_OK;
+}

@@ -1,0 +1,73 @@
+"""MI355X mirror of ``UVC/utils/losses.py``: ``DistillationLoss(base_criterion, teacher_model,
+distillation_type, alpha, tau)`` with ``criterion(inputs, outputs, labels) -> scalar``.  Loss value
+and its gradient w.r.t. the logits come from ONE fused HIP kernel (uvc_distill_loss); the teacher
+forward runs under no_grad through the same engine as the student."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+class SoftTargetCrossEntropy(torch.nn.Module):
+    """timm.loss.SoftTargetCrossEntropy (joint_train.py:940): mean_b sum_c -y log_softmax(x).
+    Marker class: DistillationLoss fuses it into the HIP loss kernel."""
+
+    def forward(self, x, target):
+        raise L.UvcHipError("SoftTargetCrossEntropy runs fused inside uvc_amd.losses.DistillationLoss on the HIP path")
+
+
+class _LossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, o, o_kd, y, teacher, alpha, tau, kind):
+        B, Cc = o.shape
+        dev = o.device
+        same = o_kd is o or o_kd.data_ptr() == o.data_ptr()
+        loss = torch.empty(1, device=dev)
+        d_o = torch.empty(B, Cc, device=dev)
+        d_k = d_o if same else torch.empty(B, Cc, device=dev)
+        scratch = torch.empty(B, device=dev)
+        ops.distill_loss(o.contiguous(), o_kd.contiguous(), y.contiguous(), teacher, loss, d_o, d_k, scratch, alpha, tau, kind)
+        ctx.save_for_backward(d_o, d_k)
+        ctx.same = same
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d_o, d_k = ctx.saved_tensors
+        if ctx.same:
+            return d_o * g, None, None, None, None, None, None
+        return d_o * g, d_k * g, None, None, None, None, None
+
+
+class DistillationLoss(torch.nn.Module):
+    """utils/losses.py:10-65.  'soft' and 'none' run on the HIP path; 'hard' (argmax CE) is not used by
+    the README command and raises."""
+
+    def __init__(self, base_criterion, teacher_model, distillation_type: str, alpha: float, tau: float):
+        super().__init__()
+        assert distillation_type in ['none', 'soft', 'hard']
+        if not isinstance(base_criterion, SoftTargetCrossEntropy):
+            raise NotImplementedError("the HIP loss kernel implements the soft-target CE base criterion (mixup > 0, joint_train.py:938-940)")
+        if distillation_type == 'hard':
+            raise NotImplementedError("distillation_type='hard' is not on the README hot path")
+        self.base_criterion = base_criterion
+        self.teacher_model = teacher_model
+        self.distillation_type = distillation_type
+        self.alpha = alpha
+        self.tau = tau
+
+    def forward(self, inputs, outputs, labels):
+        outputs_kd = None
+        if not isinstance(outputs, torch.Tensor):
+            outputs, outputs_kd = outputs
+        L.require_cuda(outputs, labels)
+        if self.distillation_type == 'none':
+            return _LossFunction.apply(outputs, outputs, labels, None, 0.0, 1.0, 0)
+        if outputs_kd is None:
+            raise ValueError("When knowledge distillation is enabled, the model is expected to return a "
+                             "Tuple[Tensor, Tensor] with the output of the class_token and the dist_token")
+        with torch.no_grad():
+            teacher_outputs, _ = self.teacher_model(inputs)           # losses.py:47-49
+        return _LossFunction.apply(outputs, outputs_kd, labels, teacher_outputs.contiguous(), float(self.alpha), float(self.tau), 1)

@@ -1,0 +1,421 @@
+"""MI355X mirror of ``UVC/models/model_distilled.py``: ``DistilledVisionTransformer`` with the
+reference's constructor, attributes, ``forward(x, tau=-1, number=0.9)`` contract and
+state_dict keys, executing as the HIP kernel sequence of ``uvc_vit_forward`` /
+``uvc_vit_backward`` (include/uvc_vit.h).
+
+Parameters are views into ONE flat float32 buffer (and ``.grad`` into one flat gradient
+buffer), which is what the fused clip+AdamW, the RCCL gradient all-reduce and the UVC engine
+operate on.  ``loss.backward()`` works through a single autograd node for the whole model.
+There is no CPU path: constructing the model needs an MI355X.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from functools import partial
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+__all__ = ["DistilledVisionTransformer", "PatchEmbed", "Attention", "Mlp", "Block"]
+
+
+class uvc_vit_cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("img_size", "patch_size", "in_chans", "num_classes", "embed_dim", "depth",
+                                         "num_heads", "hidden", "ntok", "dtype")]
+
+
+MAXD = 32
+
+
+class uvc_vit_offsets(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("cls_token", "dist_token", "pos_embed", "patch_w", "patch_b")] + \
+               [("blk", (C.c_int64 * 12) * MAXD)] + \
+               [(n, C.c_int64) for n in ("norm_w", "norm_b", "head_w", "head_b", "headd_w", "headd_b", "n_main", "gate",
+                                         "gumbel_w", "gumbel_b", "patch_gating")] + \
+               [("skip", (C.c_int64 * 2) * MAXD), ("n_total", C.c_int64)]
+
+
+class uvc_vit_shadow_offsets(C.Structure):
+    _fields_ = [("patch_w", C.c_int64), ("blk_w", (C.c_int64 * 4) * MAXD), ("blk_wt", (C.c_int64 * 4) * MAXD)] + \
+               [(n, C.c_int64) for n in ("head_w", "head_wt", "headd_w", "headd_wt", "n_total")]
+
+
+class uvc_vit_io(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("shadow", C.c_void_p), ("grads", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_int64), ("x", C.c_void_p), ("logits", C.c_void_p), ("logits_dist", C.c_void_p),
+                ("d_logits", C.c_void_p), ("d_logits_dist", C.c_void_p), ("gate_d", C.c_void_p),
+                ("run_block", C.POINTER(C.c_int32)), ("patch_mask", C.c_void_p), ("d_patch_mask", C.c_void_p),
+                ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
+                ("accumulate", C.c_float)]
+
+
+def _bind():
+    lib = L.lib()
+    if getattr(lib, "_vit_bound", False):
+        return lib
+    lib.uvc_vit_layout.argtypes = [C.POINTER(uvc_vit_cfg), C.POINTER(uvc_vit_offsets), C.POINTER(uvc_vit_shadow_offsets)]
+    lib.uvc_vit_layout.restype = C.c_int
+    lib.uvc_vit_workspace_bytes.argtypes = [C.POINTER(uvc_vit_cfg), C.c_int32, C.c_int32]
+    lib.uvc_vit_workspace_bytes.restype = C.c_int64
+    lib.uvc_vit_update_shadows.argtypes = [C.POINTER(uvc_vit_cfg), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.uvc_vit_update_shadows.restype = C.c_int
+    for n in ("uvc_vit_forward", "uvc_vit_backward"):
+        f = getattr(lib, n)
+        f.argtypes = [C.POINTER(uvc_vit_cfg), C.POINTER(uvc_vit_io), C.c_void_p]
+        f.restype = C.c_int
+    lib._vit_bound = True
+    return lib
+
+
+VIT_SYMBOLS = ["uvc_vit_layout", "uvc_vit_workspace_bytes", "uvc_vit_update_shadows", "uvc_vit_forward", "uvc_vit_backward"]
+
+
+# --------------------------------------------------------------------------------------------------
+# module tree with the reference's names (so get_uvc_layers / state_dict / masks work unchanged)
+class PatchEmbed(nn.Module):
+    """model_distilled.py:129-153 (parameter holder; the conv runs as patchify + MFMA GEMM)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
+        self.attn_skip_gating = nn.Parameter(torch.Tensor([-1, 1]))      # :213-214 (unused unless part gating)
+        self.mlp_skip_gating = nn.Parameter(torch.Tensor([-1, 1]))
+
+
+class _VitFunction(torch.autograd.Function):
+    """One autograd node for the whole model.  Gradients of the parameters are written straight into
+    the flat gradient buffer (the ``.grad`` views); only the patch-mask gradient flows through autograd."""
+
+    @staticmethod
+    def forward(ctx, model, x, anchor, patch_mask):
+        logits, logits_dist = model._run_forward(x, patch_mask, training=True)
+        ctx.model = model
+        ctx.has_mask = patch_mask is not None
+        ctx.two = logits_dist is not None
+        return (logits, logits_dist) if ctx.two else logits
+
+    @staticmethod
+    def backward(ctx, *grads):
+        model = ctx.model
+        dmask = model._run_backward(grads[0], grads[1] if ctx.two else None, ctx.has_mask)
+        return None, None, None, dmask
+
+
+class DistilledVisionTransformer(nn.Module):
+    """Same call surface as the reference class (model_distilled.py:390-531)."""
+
+    def __init__(self, enable_dist, enable_jumping=0, enable_block_gating=0, enable_part_gating=0,
+                 enable_patch_gating=0, gumbel_hard=True, use_gumbel=False, eps=0.1, enable_warmup=False,
+                 patch_hard=False, *, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768,
+                 depth=12, num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., norm_layer=None, act_layer=None, weight_init='',
+                 precision="bf16", device=None):
+        super().__init__()
+        if drop_rate or attn_drop_rate or drop_path_rate or representation_size:
+            raise NotImplementedError("dropout / drop-path / representation layer are 0/None on the UVC path "
+                                      "(joint_train.py:137-138) and are not implemented")
+        if not qkv_bias:
+            raise NotImplementedError("qkv_bias=False (T2T blocks) is not on the DeiT hot path")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' (throughput) or 'fp32' (exact float32 MFMA, parity mode)")
+        dev = torch.device(device if device is not None else "cuda")
+        if dev.type != "cuda":
+            raise L.UvcHipError("uvc_amd models run on MI355X only (no CPU fallback)")
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 2 if enable_dist else 1
+        self.precision = precision
+        self.gumbel_hard = gumbel_hard
+        self.patch_hard = patch_hard
+        self.enable_block_gating = enable_block_gating
+        self.enable_part_gating = enable_part_gating
+        self.enable_jumping = enable_jumping
+        self.enable_patch_gating = enable_patch_gating
+        self.use_gumbel = use_gumbel
+        self.eps = eps
+        self.enable_warmup = enable_warmup
+        self.frozen_weights = False          # set on the teacher: shadows are refreshed once
+        self.grad_accumulate = False         # True: backward adds into .grad (gradient_accumulation_steps > 1)
+        # --- registration order follows the reference so state_dict keys line up
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, (img_size // patch_size) ** 2 + self.num_tokens, embed_dim))
+        self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if enable_dist else None
+        self.block_skip_gating = nn.Parameter(torch.Tensor([-1, 1]).expand(depth, 2).contiguous())
+        self.patch_gating = nn.Parameter(torch.zeros(1, (img_size // patch_size) ** 2, 1)) if enable_patch_gating == 1 else None
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        self.pos_drop = nn.Dropout(p=0.0)
+        self.blocks = nn.Sequential(*[Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(embed_dim, num_classes)
+        self.head_dist = nn.Linear(embed_dim, num_classes) if enable_dist else None
+        self.gumbel = nn.Linear(embed_dim, 1)
+        if self.enable_block_gating:
+            print("=====> Block gating enabled <=====")
+        self._init_weights()
+        # --- engine state
+        self._cfg = uvc_vit_cfg(img_size, patch_size, in_chans, num_classes, embed_dim, depth, num_heads,
+                                int(embed_dim * mlp_ratio), self.num_tokens, ops.UVC_F32 if precision == "fp32" else ops.UVC_BF16)
+        self._off = uvc_vit_offsets()
+        self._soff = uvc_vit_shadow_offsets()
+        L.check(_bind().uvc_vit_layout(C.byref(self._cfg), C.byref(self._off), C.byref(self._soff)), "uvc_vit_layout")
+        self._flat = None
+        self._flat_grad = None
+        self._ws = {}
+        self._shadow = None
+        self._last = None
+        self._run_block_host = None
+        self.exp_source = lambda shape: torch.empty(shape, device=self._flat.device, dtype=torch.float32).exponential_()
+        self.to(dev)
+
+    # -- init ----------------------------------------------------------------------------------------
+    def _init_weights(self):
+        """model_distilled.py:65-97,311-319,423-427: trunc_normal(.02) weights/tokens, zero biases, LN 1/0."""
+        for t in (self.pos_embed, self.cls_token, self.dist_token):
+            if t is not None:
+                nn.init.trunc_normal_(t, std=.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.zeros_(m.bias)
+                nn.init.ones_(m.weight)
+
+    # -- flat storage ---------------------------------------------------------------------------------
+    def _slots(self):
+        """(parameter, offset) pairs of the canonical flat layout (uvc_vit_layout)."""
+        o = self._off
+        out = [(self.cls_token, o.cls_token), (self.pos_embed, o.pos_embed), (self.patch_embed.proj.weight, o.patch_w),
+               (self.patch_embed.proj.bias, o.patch_b)]
+        if self.dist_token is not None:
+            out.append((self.dist_token, o.dist_token))
+        for l, blk in enumerate(self.blocks):
+            q = o.blk[l]
+            out += [(blk.norm1.weight, q[0]), (blk.norm1.bias, q[1]), (blk.attn.qkv.weight, q[2]), (blk.attn.qkv.bias, q[3]),
+                    (blk.attn.proj.weight, q[4]), (blk.attn.proj.bias, q[5]), (blk.norm2.weight, q[6]), (blk.norm2.bias, q[7]),
+                    (blk.mlp.fc1.weight, q[8]), (blk.mlp.fc1.bias, q[9]), (blk.mlp.fc2.weight, q[10]), (blk.mlp.fc2.bias, q[11]),
+                    (blk.attn_skip_gating, o.skip[l][0]), (blk.mlp_skip_gating, o.skip[l][1])]
+        out += [(self.norm.weight, o.norm_w), (self.norm.bias, o.norm_b), (self.head.weight, o.head_w), (self.head.bias, o.head_b),
+                (self.block_skip_gating, o.gate), (self.gumbel.weight, o.gumbel_w), (self.gumbel.bias, o.gumbel_b)]
+        if self.head_dist is not None:
+            out += [(self.head_dist.weight, o.headd_w), (self.head_dist.bias, o.headd_b)]
+        if self.patch_gating is not None:
+            out.append((self.patch_gating, o.patch_gating))
+        return out
+
+    def _flatten(self, device):
+        """(Re)build the flat parameter/gradient buffers and point every Parameter at its slice."""
+        n = self._off.n_total
+        flat = torch.zeros(n, device=device, dtype=torch.float32)
+        grad = torch.zeros(n, device=device, dtype=torch.float32)
+        for p, off in self._slots():
+            k = p.numel()
+            flat[off:off + k].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = flat[off:off + k].view(p.shape)
+            p.grad = None
+        self._flat, self._flat_grad = flat, grad
+        tsz = 4 if self.precision == "fp32" else 2
+        self._shadow = torch.zeros(self._soff.n_total * tsz, device=device, dtype=torch.uint8)
+        self._ws = {}
+        self._shadow_fresh = False
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        dev = self.cls_token.device
+        if dev.type == "cuda" and hasattr(self, "_off"):
+            self._flatten(dev)
+        return self
+
+    def _check_flat(self):
+        if self._flat is None or self.cls_token.data_ptr() != self._flat.data_ptr() + 4 * self._off.cls_token or \
+                self.head.weight.data_ptr() != self._flat.data_ptr() + 4 * self._off.head_w:
+            self._flatten(self.cls_token.device)
+        # the UVC minimax object swaps in its own patch_gating parameter (uvc_utils.py:286-288)
+        if self.patch_gating is not None and self.patch_gating.data_ptr() != self._flat.data_ptr() + 4 * self._off.patch_gating:
+            off, k = self._off.patch_gating, self.patch_gating.numel()
+            self._flat[off:off + k].copy_(self.patch_gating.data.reshape(-1))
+            self.patch_gating.data = self._flat[off:off + k].view(self.patch_gating.shape)
+
+    def grad_views(self, patch_mode2=False):
+        """Point .grad of every parameter that receives a gradient at its slice of the flat gradient
+        buffer (idempotent).  Like autograd in the reference, tensors the loss does not reach keep
+        .grad = None: attn/mlp_skip_gating always, gumbel.* unless patch-gating mode 2 ran,
+        block_skip_gating in warm-up (requires_grad False / constant .5,.5 gates)."""
+        o = self._off
+        dead = {o.skip[l][j] for l in range(self._cfg.depth) for j in (0, 1)}
+        if not patch_mode2:
+            dead |= {o.gumbel_w, o.gumbel_b}
+        if not self.block_skip_gating.requires_grad or self._gate_mode() == 0:
+            dead.add(o.gate)
+        for p, off in self._slots():
+            if off in dead:
+                continue
+            if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
+                p.grad = self._flat_grad[off:off + p.numel()].view(p.shape)
+
+    def mark_weights_changed(self):
+        self._shadow_fresh = False
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.mark_weights_changed()
+        return r
+
+    # -- engine calls ---------------------------------------------------------------------------------
+    def _workspace(self, B, training):
+        key = (B, bool(training))
+        if key not in self._ws:
+            nbytes = _bind().uvc_vit_workspace_bytes(C.byref(self._cfg), B, int(training))
+            if nbytes < 0:
+                raise L.UvcHipError(f"uvc_vit_workspace_bytes: {L.lib().uvc_last_error().decode()}")
+            self._ws = {k: v for k, v in self._ws.items() if k[1] != bool(training)}   # keep one per mode
+            self._ws[key] = torch.empty(nbytes, device=self._flat.device, dtype=torch.uint8)
+        return self._ws[key]
+
+    def _gate_mode(self):
+        if not self.enable_block_gating or self.enable_warmup:
+            return 0
+        return 1 if self.use_gumbel == 1 else 2
+
+    def _io(self, B, training):
+        io = uvc_vit_io()
+        ws = self._workspace(B, training)
+        io.params, io.shadow, io.grads = L.ptr(self._flat), L.ptr(self._shadow), L.ptr(self._flat_grad)
+        io.workspace, io.workspace_bytes = L.ptr(ws), ws.numel()
+        io.batch, io.training = B, int(training)
+        io.gate_mode, io.gate_eps = self._gate_mode(), float(self.eps)
+        io.accumulate = 1.0 if self.grad_accumulate else 0.0
+        return io
+
+    def _run_forward(self, x, patch_mask, training):
+        L.require_cuda(x)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.contiguous().float()
+        B = x.shape[0]
+        cfg = self._cfg
+        if tuple(x.shape[1:]) != (cfg.in_chans, cfg.img_size, cfg.img_size):
+            raise AssertionError(f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model ({cfg.img_size}*{cfg.img_size}).")
+        self._check_flat()
+        lib = _bind()
+        stream = L.cur_stream()
+        if not (self.frozen_weights and self._shadow_fresh):
+            L.check(lib.uvc_vit_update_shadows(C.byref(cfg), L.ptr(self._flat), L.ptr(self._shadow), stream), "uvc_vit_update_shadows")
+            self._shadow_fresh = True
+        io = self._io(B, training)
+        dev = self._flat.device
+        logits = torch.empty(B, cfg.num_classes, device=dev)
+        logits_dist = torch.empty(B, cfg.num_classes, device=dev) if self.num_tokens == 2 else None
+        gate_d = None
+        run_block = None
+        if self.enable_block_gating:                                   # model_distilled.py:479-494
+            gate_d = torch.empty(cfg.depth, 2, device=dev)
+            if self.enable_warmup:
+                mode, e = 0, None
+            elif self.use_gumbel == 1:
+                mode, e = (3 if self.gumbel_hard else 1), self.exp_source((cfg.depth, 2))
+            else:
+                mode, e = 2, None
+            ops.gate_distrib(self.block_skip_gating.data, e, gate_d, cfg.depth, mode, float(self.eps))
+        else:                                                          # :496-500 hard skip by logit order
+            if self._run_block_host is None or not self.frozen_weights:
+                g = self.block_skip_gating.detach().cpu()
+                self._run_block_host = (C.c_int32 * cfg.depth)(*[int(g[i, 1] > g[i, 0]) for i in range(cfg.depth)])
+            run_block = self._run_block_host
+            if training and not all(run_block):
+                raise NotImplementedError("hard block skipping inside a training forward is the Stage-2 path")
+        io.x, io.logits, io.logits_dist = L.ptr(x), L.ptr(logits), L.ptr(logits_dist)
+        io.gate_d = L.ptr(gate_d)
+        io.run_block = run_block if run_block is not None else None
+        io.patch_mask = L.ptr(patch_mask)
+        L.check(lib.uvc_vit_forward(C.byref(cfg), C.byref(io), stream), "uvc_vit_forward")
+        self._last = dict(x=x, gate_d=gate_d, patch_mask=patch_mask, B=B) if training else None
+        self.last_distrib = gate_d
+        return logits, logits_dist
+
+    def _run_backward(self, d_logits, d_logits_dist, want_dmask):
+        st = self._last
+        if st is None:
+            raise RuntimeError("backward without a training forward")
+        self.grad_views()
+        io = self._io(st["B"], True)
+        d_logits = d_logits.contiguous()
+        io.d_logits = L.ptr(d_logits)
+        if self.num_tokens == 2:
+            d_logits_dist = d_logits_dist.contiguous()
+            io.d_logits_dist = L.ptr(d_logits_dist)
+        io.gate_d = L.ptr(st["gate_d"])
+        io.patch_mask = L.ptr(st["patch_mask"])
+        dmask = None
+        if want_dmask:
+            dmask = torch.empty_like(st["patch_mask"])
+            io.d_patch_mask = L.ptr(dmask)
+        L.check(_bind().uvc_vit_backward(C.byref(self._cfg), C.byref(io), L.cur_stream()), "uvc_vit_backward")
+        return dmask
+
+    # -- reference API ----------------------------------------------------------------------------------
+    def macs(self, B):
+        """MAC bookkeeping of the reference forward (model_distilled.py:115,121,177,182,185,189,460)."""
+        c = self._cfg
+        P = (c.img_size // c.patch_size) ** 2
+        N, D, F, H = P + self.num_tokens, c.embed_dim, c.hidden, c.num_heads
+        embed = B * P * D * c.patch_size * c.patch_size * c.in_chans
+        blk = [B * 3 * D * N * D, N * B * H * N * 64, N * B * H * N * 64, B * N * D * D, F * B * N * D, D * B * N * F]
+        return embed, [list(blk) for _ in range(c.depth)]
+
+    def _patch_mask(self, B, tau, ratio):
+        if self.enable_patch_gating == 1 or tau > 0:
+            raise NotImplementedError("patch gating (modes 1/2) is not wired into the HIP engine yet")
+        return None
+
+    def forward(self, x, tau=-1, number=0.9):
+        if self.enable_jumping:
+            raise NotImplementedError("enable_jumping is off on the UVC hot path")
+        B = x.shape[0]
+        macs = self.macs(B)
+        patch_mask = self._patch_mask(B, tau, number)
+        if self.training and torch.is_grad_enabled():
+            out = _VitFunction.apply(self, x, self.cls_token, patch_mask)
+            return (out if self.num_tokens == 2 else (out, out)), macs       # x_dist = x without the dist token (:523-524)
+        o, od = self._run_forward(x, patch_mask, training=False)
+        if od is None:
+            od = o
+        if self.training:
+            return (o, od), macs
+        return (o + od) / 2, macs

@@ -1,0 +1,114 @@
+"""Fused global-norm clip + AdamW over the model's flat parameter buffer (mirror of
+``torch.nn.utils.clip_grad_norm_`` + ``torch.optim.AdamW`` as used at joint_train.py:271,428-429).
+
+``FusedAdamW`` is a ``torch.optim.Optimizer`` (so LambdaLR schedulers and ``param_groups[0]['lr']``
+readers such as prox_w work unchanged); its ``step()`` is two HIP launches over the always-active
+segment plus tiny launches for conditionally-active tensors (block_skip_gating after warm-up,
+gumbel.* / patch_gating with patch gating), each with its own step count like torch's per-parameter
+state.  Parameters whose gradient is None are skipped entirely (no decay), as in torch.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def clip_grad_norm_(model_or_params, max_norm: float):
+    """Drop-in for ``torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)`` on a uvc_amd model:
+    computes the global L2 norm of all live gradients on the device and ARMS the clip; the scaling is
+    applied inside ``FusedAdamW.step()`` (same arithmetic, one pass less over the gradients), which also
+    rescales block_skip_gating.grad in place because uvc_optimizer reads it afterwards.  Returns the
+    (lazy, device) total norm."""
+    model = model_or_params if hasattr(model_or_params, "_flat_grad") else getattr(model_or_params, "_uvc_model", None)
+    if model is None:
+        raise L.UvcHipError("clip_grad_norm_: pass the uvc_amd model (or the generator from model.parameters() wrapped by FusedAdamW)")
+    segs = _live_segments(model)
+    st = _clip_state(model)
+    first = True
+    for off, n in segs:
+        ops.grad_sqnorm(model._flat_grad[off:off + n], st["partial"], st["sq"], accumulate=not first)
+        first = False
+    st["armed"] = float(max_norm)
+    return torch.sqrt(st["sq"][0])
+
+
+def _clip_state(model):
+    if not hasattr(model, "_clip"):
+        dev = model._flat.device
+        model._clip = dict(partial=torch.empty(1024, device=dev), sq=torch.zeros(1, device=dev), armed=None,
+                           gnorm=torch.zeros(1, device=dev))
+    return model._clip
+
+
+def _small_tensors(model):
+    """(name, parameter, offset) of the conditionally-active tensors."""
+    o = model._off
+    out = [("gate", model.block_skip_gating, o.gate), ("gumbel_w", model.gumbel.weight, o.gumbel_w),
+           ("gumbel_b", model.gumbel.bias, o.gumbel_b)]
+    if model.patch_gating is not None:
+        out.append(("patch_gating", model.patch_gating, o.patch_gating))
+    return out
+
+
+def _live_segments(model):
+    segs = [(0, model._off.n_main)]
+    for _, p, off in _small_tensors(model):
+        if p.grad is not None:
+            segs.append((off, p.numel()))
+    return segs
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_grad_norm=None):
+        if not hasattr(model, "_flat"):
+            raise L.UvcHipError("FusedAdamW needs a uvc_amd DistilledVisionTransformer (flat parameter buffer)")
+        model._check_flat()
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.model = model
+        self.max_grad_norm = max_grad_norm
+        dev = model._flat.device
+        n = model._off.n_total
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        self.steps = {"main": 0}
+
+    def zero_grad(self, set_to_none: bool = True):
+        """Gradients are overwritten by the next backward (beta = 0), so nothing has to be cleared; keeps
+        torch's contract that conditionally-active tensors read None again."""
+        m = self.model
+        if m.grad_accumulate:
+            m._flat_grad.zero_()
+        for _, p, _ in _small_tensors(m):
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        m = self.model
+        g = self.param_groups[0]
+        st = _clip_state(m)
+        max_norm = st["armed"] if st["armed"] is not None else self.max_grad_norm
+        if max_norm is None:
+            max_norm = float("inf")
+            st["sq"].zero_()
+        elif st["armed"] is None:
+            clip_grad_norm_(m, max_norm)
+        st["armed"] = None
+        b1, b2 = g["betas"]
+        common = dict(lr=float(g["lr"]), beta1=b1, beta2=b2, eps=g["eps"], weight_decay=g["weight_decay"], max_norm=float(max_norm))
+        self.steps["main"] += 1
+        n = m._off.n_main
+        ops.adamw_step(m._flat[:n], m._flat_grad[:n], self.exp_avg[:n], self.exp_avg_sq[:n], st["sq"], step=self.steps["main"],
+                       gnorm_out=st["gnorm"], **common)
+        for name, p, off in _small_tensors(m):
+            if p.grad is None:
+                continue
+            self.steps[name] = self.steps.get(name, 0) + 1
+            k = p.numel()
+            ops.adamw_step(m._flat[off:off + k], m._flat_grad[off:off + k], self.exp_avg[off:off + k],
+                           self.exp_avg_sq[off:off + k], st["sq"], step=self.steps[name], **common)
+            if name == "gate" and max_norm != float("inf"):
+                ops.scale_by_clip(m._flat_grad[off:off + k], st["sq"], float(max_norm))   # uvc_optimizer.py:90 reads the clipped grad
+        m.mark_weights_changed()
+        return None

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the UVC Stage-1 step on MI355X (BASELINE.json metric: images/sec, DeiT-Tiny,
+budget 0.5, per-GPU batch 512, bf16 MFMA compute, 1/2/4/8 GPUs weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = the full UVC-train step of joint_train.py:395-450 on one batch of synthetic
+ImageNet-shaped inputs already resident in HBM: student forward + teacher forward + distillation
+loss + student backward + gradient all-reduce + clip + AdamW + scheduler + uvc_optimizer (prox, scores,
+ranks, primal/dual update).  Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how
+`roofline` and `cpu_baseline` are defined.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic FLOPs per image per step = 2*(3E + 4*L*Bk + 4*C)
+GFLOP_PER_IMG = {"deit_tiny_patch16_224": 9.972, "deit_small_patch16_224": 36.675, "deit_base_patch16_224": 140.28}
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE config 2)")
+    p.add_argument("--model_type", default="deit_tiny_patch16_224")
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--cpu_steps", type=int, default=6)
+    return p.parse_args()
+
+
+def pruned_state(tr, seed=731):
+    """Non-trivial primal/dual start so prox / rank / mask kernels do real work."""
+    import numpy as np
+    mm = tr.minimax
+    L, H, F = mm.n_layers, mm.num_heads, mm.dims.F
+    rs = np.random.RandomState(seed)
+    s = np.zeros((L, 2), np.float32)
+    s[:, 0] = rs.uniform(0, 0.6 * (H - 1) + 0.3, L)
+    s[:, 1] = rs.uniform(0, 0.5 * F, L)
+    r = rs.uniform(0, 30.0, (L, H)).astype(np.float32)
+    mm.s.data.copy_(torch.from_numpy(s)); mm.r.data.copy_(torch.from_numpy(r))
+    mm.y.data.fill_(1.0); mm.p.data.fill_(1.0); mm.z.data.fill_(2.0)
+
+
+def kernel_roofline(tr, args, iters=30):
+    """Dominant kernel (rocprof: the fc1 GEMM with fused bias+GELU, profiles/): algorithmic FLOPs of one
+    launch / its average duration measured with HIP events on the launch stream."""
+    from uvc_amd import ops
+    m = tr.model
+    cfg = m._cfg
+    B = args.batch
+    N = (cfg.img_size // cfg.patch_size) ** 2 + cfg.ntok
+    M, D, F = B * N, cfg.embed_dim, cfg.hidden
+    dt = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    dev = m._flat.device
+    A = torch.randn(M, D, device=dev).to(dt)
+    W = (torch.randn(F, D, device=dev) * 0.02).to(dt)
+    bias = torch.zeros(F, device=dev)
+    a_out, u_out = torch.empty(M, F, device=dev, dtype=dt), torch.empty(M, F, device=dev, dtype=dt)
+    dtype = ops.UVC_BF16 if args.precision == "bf16" else ops.UVC_F32
+    for _ in range(3):
+        ops.gemm_nt(A, W, a_out, dtype=dtype, epilogue=ops.EPI_BIAS_GELU, bias=bias, C2=u_out)
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        ops.gemm_nt(A, W, a_out, dtype=dtype, epilogue=ops.EPI_BIAS_GELU, bias=bias, C2=u_out)
+    e1.record(st)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * D * F
+    esz = 2 if args.precision == "bf16" else 4
+    bytes_alg = (M * D + F * D + 2 * M * F) * esz
+    tf = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+    return {"bound": "mfma", "kernel": "k_gemm_nt<bf16,bias+GELU> (mlp.fc1)", "achieved": round(tf, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None, "launch_ms": round(ms, 4),
+            "algorithmic_GBps": round(bytes_alg / (ms * 1e-3) / 1e9, 1)}
+
+
+def cpu_baseline(args):
+    """The oracle (a PyTorch-CPU restatement of the reference step, pinned to the reference's golden
+    vectors) timed on the host cores on a bounded sample: DeiT-Tiny, batch 8, a few steps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import scenarios as SC
+    from helpers import build_oracle, load_golden, split_draws
+    from oracle import step as OS
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    name = "tiny8_pruned"
+    gold = load_golden(name)
+    r, S = build_oracle(name)
+    x_all, y_all = SC.make_inputs(r)
+    md, e1, e2 = split_draws(r, gold, 0, S.cfg.depth)
+    x, y = torch.from_numpy(x_all[0]), torch.from_numpy(y_all[0])
+    OS.stage1_step(S, x, y, list(md), e1, e2)          # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < args.cpu_steps and time.perf_counter() - t0 < 40:
+        OS.stage1_step(S, x, y, list(md), e1, e2)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(8 * n / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle Stage-1 step, DeiT-Tiny batch 8, {n} steps, torch CPU fp32 {threads} threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    from uvc_amd.stage1 import Stage1Trainer, default_args
+    torch.manual_seed(730)
+    a = default_args(model_type=args.model_type, precision=args.precision, train_batch_size=args.batch, local_rank=local)
+    tr = Stage1Trainer(a, device=f"cuda:{local}", distributed=world > 1)
+    pruned_state(tr)
+    tr.begin_epoch(a.warmup_epochs + 1)                 # UVC-train phase (post warm-up), SURVEY.md §8d
+    dev = torch.device("cuda", local)
+    g = torch.Generator(device=dev).manual_seed(730 + rank)
+    x = torch.randn(args.batch, 3, a.img_size, a.img_size, device=dev, generator=g)
+    y = torch.softmax(torch.randn(args.batch, a.num_classes, device=dev, generator=g), -1)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(x, y)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.step(x, y)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(out["loss"])
+    if rank == 0:
+        imgs = world * args.batch * args.steps / dt
+        gf = GFLOP_PER_IMG.get(args.model_type)
+        line = {"metric": "images/sec UVC Stage-1 step, DeiT-Tiny budget=0.5", "value": round(imgs, 1), "unit": "images/sec",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+                "config": {"workload": f"{args.model_type} Stage-1 UVC-train step, budget 0.5, per-GPU batch {args.batch}, "
+                                       f"224x224x3 synthetic, soft distillation alpha 0.1, block gating on",
+                           "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+                "step_tflops_per_gpu": round(imgs / world * gf / 1e3, 2) if gf else None,
+                "step_frac_of_bf16_mfma_peak": round(imgs / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,
+                "final_loss": round(loss, 4), "cur_resource": round(float(out["cur"]), 4)}
+        line["roofline"] = kernel_roofline(tr, args)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,11 @@ typedef struct uvc_vit_io {
   int32_t gate_mode;        /* 0 warm-up / none, 1 soft Gumbel, 2 softL0: selects d(gate logits) formula */
   float gate_eps;           /* softL0 eps */
   float accumulate;         /* backward: 0 = overwrite gradients, 1 = add (gradient accumulation) */
+  /* backward stages [stage_begin, stage_end): 0 = heads + final norm, 1..L = blocks L-1..0,
+   * L+1 = gate logits + token assembly + patch embedding.  0,0 = everything.  Lets the host cut the
+   * backward at gradient-bucket boundaries and start the RCCL all-reduce of a finished bucket on a
+   * second stream while the rest of the backward runs. */
+  int32_t stage_begin, stage_end;
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the bucketed mean all-reduce of the flat gradient buffer
+(uvc_amd.ddp.FlatGradReducer / bucket_plan) -- every element reduced exactly once, result = mean over
+ranks, dual scalar slot carried in the tail bucket."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _Off:
+    def __init__(self, depth, per_block, embed, head, small):
+        self.blk = [[embed + l * per_block] * 12 for l in range(depth)]
+        self.n_main = embed + depth * per_block + head
+        self.n_total = self.n_main + small
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, depth, nb, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uvc_amd.ddp import FlatGradReducer, bucket_plan
+    off = _Off(depth, per_block=1000, embed=300, head=500, small=40)
+    n_extra = 4
+    plan = bucket_plan(off, depth, n_extra, nb)
+    # coverage: every index of [0, n_total + n_extra) in exactly one bucket
+    cover = torch.zeros(off.n_total + n_extra, dtype=torch.int32)
+    for _, ranges in plan:
+        for o, n in ranges:
+            cover[o:o + n] += 1
+    assert bool((cover == 1).all()), "bucket plan must tile the flat buffer"
+    ends = [p[0] for p in plan]
+    assert ends == sorted(ends) and ends[-1] == depth + 2
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(off.n_total + n_extra, generator=g)
+    flat[off.n_total] = 3.25                      # the dual scalar: identical on every rank
+    mine = flat.clone()
+    red = FlatGradReducer(flat, [p[1] for p in plan])
+    for i in range(len(plan)):
+        red.launch(i)
+    red.finish()
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    mean = torch.stack(gathered).mean(0)
+    ok = torch.allclose(flat, mean, rtol=1e-6, atol=1e-7) and float(flat[off.n_total]) == 3.25
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_bucketed_mean_allreduce_gloo_world2():
+    for depth, nb in ((12, 4), (12, 1), (2, 4), (14, 3)):
+        port = _free_port()
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, port, depth, nb, out), nprocs=2, join=True)
+        assert out[0] and out[1], (depth, nb)

@@ -301,6 +301,9 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   Work& w = c.w;
   hipStream_t hs = (hipStream_t)stream;
   const int rh = d.B * d.ntok;
+  const int sb = io->stage_begin, se = (io->stage_begin == 0 && io->stage_end == 0) ? d.L + 2 : io->stage_end;
+  if (sb < 0 || se > d.L + 2 || sb >= se) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_backward: bad stage range");
+  if (sb == 0) {
   // heads: dhc = dlogits . W ; dW = dlogits^T . hc ; db = colsum(dlogits)
   TRY(nt(c, io->d_logits, 1, sh(c, so.head_wt), w.dhc, 0, d.B, d.D, d.NC, UVC_EPI_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
          d.ntok * d.D));
@@ -317,7 +320,10 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   if (he != hipSuccess) return uvc_set_error(he, __FILE__, __LINE__);
   TRY(ln_bwd(c, w.dhc, w.xL, o.norm_w, o.norm_b, w.meanf, w.rstdf, w.gA, nullptr, nullptr, nullptr, nullptr, w.dotsraw + 2 * d.L, rh, d.ntok,
              (int64_t)d.N * d.D));
+  }
   for (int l = d.L - 1; l >= 0; --l) {
+    const int stage = d.L - l;
+    if (stage < sb || stage >= se) continue;
     const BlockBufs& b = w.blk[l];
     const int64_t* q = o.blk[l];
     const float* g0 = io->gate_d ? io->gate_d + 2 * l : nullptr;       // d0
@@ -341,6 +347,7 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     // gA <- dL/dx_l = LN1'(dH) + gB + d0*gA ; dots: <new gA, x_l>, <old gA, x_l>
     TRY(ln_bwd(c, w.dH, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0, w.dotsraw + 2 * l, d.M, 1, d.D));
   }
+  if (se < d.L + 2) return UVC_OK;
   // gate logits (block_skip_gating) gradient
   if (io->gate_d && io->gate_mode != 0)
     TRY(uvc_gate_grad(P + o.gate, io->gate_d, w.dotsraw, G + o.gate, d.L, io->gate_mode, io->gate_eps, io->accumulate, stream));

@@ -51,7 +51,7 @@ class uvc_vit_io(C.Structure):
                 ("d_logits", C.c_void_p), ("d_logits_dist", C.c_void_p), ("gate_d", C.c_void_p),
                 ("run_block", C.POINTER(C.c_int32)), ("patch_mask", C.c_void_p), ("d_patch_mask", C.c_void_p),
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
-                ("accumulate", C.c_float)]
+                ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32)]
 
 
 def _bind():
@@ -138,6 +138,9 @@ class _VitFunction(torch.autograd.Function):
 
 class DistilledVisionTransformer(nn.Module):
     """Same call surface as the reference class (model_distilled.py:390-531)."""
+
+    N_EXTRA = 4      # spare floats behind the flat gradient buffer (all-reduce piggy-back slots)
+    _ddp = None
 
     def __init__(self, enable_dist, enable_jumping=0, enable_block_gating=0, enable_part_gating=0,
                  enable_patch_gating=0, gumbel_hard=True, use_gumbel=False, eps=0.1, enable_warmup=False,
@@ -244,7 +247,7 @@ class DistilledVisionTransformer(nn.Module):
         """(Re)build the flat parameter/gradient buffers and point every Parameter at its slice."""
         n = self._off.n_total
         flat = torch.zeros(n, device=device, dtype=torch.float32)
-        grad = torch.zeros(n, device=device, dtype=torch.float32)
+        grad = torch.zeros(n + self.N_EXTRA, device=device, dtype=torch.float32)   # + comm scratch (dual scalar)
         for p, off in self._slots():
             k = p.numel()
             flat[off:off + k].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
@@ -386,7 +389,20 @@ class DistilledVisionTransformer(nn.Module):
         if want_dmask:
             dmask = torch.empty_like(st["patch_mask"])
             io.d_patch_mask = L.ptr(dmask)
-        L.check(_bind().uvc_vit_backward(C.byref(self._cfg), C.byref(io), L.cur_stream()), "uvc_vit_backward")
+        ddp = self._ddp
+        if ddp is None or ddp.world == 1:
+            L.check(_bind().uvc_vit_backward(C.byref(self._cfg), C.byref(io), L.cur_stream()), "uvc_vit_backward")
+            return dmask
+        begin = 0
+        for i, end in enumerate(ddp.stage_ends):                       # cut at gradient-bucket boundaries
+            io.stage_begin, io.stage_end = begin, end
+            L.check(_bind().uvc_vit_backward(C.byref(self._cfg), C.byref(io), L.cur_stream()), "uvc_vit_backward")
+            if i == len(ddp.stage_ends) - 1:
+                ddp.pack_dual()
+            ddp.reducer.launch(i)                                       # RCCL on the side stream, overlaps the next stages
+            begin = end
+        ddp.reducer.finish()
+        ddp.unpack_dual()
         return dmask
 
     # -- reference API ----------------------------------------------------------------------------------

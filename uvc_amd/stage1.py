@@ -1,0 +1,143 @@
+"""Stage-1 set-up and step body (mirror of ``UVC/joint_train.py`` ``main()`` :881-1026 and the loop body
+:395-450) on the MI355X engine.  ``Stage1Trainer`` is what the CLI, ``bench.py`` and the parity tests
+drive; it composes the drop-in pieces (model, DistillationLoss, FusedAdamW, schedulers,
+build_minimax_model / uvc_optimizer, DDP) exactly in the reference's order.
+"""
+from __future__ import annotations
+
+from argparse import Namespace
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from .ddp import DistributedDataParallel
+from .joint_train import count_mask, get_uvc_layers, register_masks
+from .losses import DistillationLoss, SoftTargetCrossEntropy
+from .model_distilled import DistilledVisionTransformer
+from .optim import FusedAdamW, clip_grad_norm_
+from .scheduler import PresetLRScheduler, WarmupCosineSchedule, WarmupLinearSchedule
+from .uvc_optimizer import build_minimax_model, uvc_optimizer
+from .uvc_utils import prune_w_mask
+
+# models/configs.py:112-165 -- dims of the DeiT family the reference instantiates
+CONFIGS = {
+    "deit_tiny_patch16_224": dict(patch_size=16, embed_dim=192, depth=12, num_heads=3),
+    "deit_small_patch16_224": dict(patch_size=16, embed_dim=384, depth=12, num_heads=6),
+    "deit_base_patch16_224": dict(patch_size=16, embed_dim=768, depth=12, num_heads=12),
+}
+
+
+def default_args(**over) -> Namespace:
+    """The argparse defaults of joint_train.py:684-879 overlaid with the README command
+    (run_uvc_train.sh:4-38); keyword arguments override."""
+    a = dict(model_type="deit_tiny_patch16_224", img_size=224, num_classes=1000, train_batch_size=512, learning_rate=1e-4,
+             weight_decay=0.05, num_epochs=30, decay_type="cosine", warmup_steps=500, max_grad_norm=1.0,
+             gradient_accumulation_steps=1, seed=730, uvc_train=True, soptim="sgd", roptim="sgd",
+             zlr_schedule_list="1,5,9,13,17", ylr=1e-4, plr=1e-4, slr=0.02, rlr=0.02, glr=0.1, log_interval=1000,
+             budget=0.5, sl2wd=0.0, distillation_type="soft", distillation_alpha=0.1, distillation_tau=1.0,
+             flops_with_mhsa=1, enable_block_gating=1, enable_part_gating=0, enable_jumping=0, enable_deit=0,
+             enable_pruning=1, enable_patch_gating=0, patch_ratio=0.9, z_grad_clip=0.5, gating_interval=50,
+             gating_weight=5e-4, use_gumbel=1, eps=0.1, eps_decay=0.92, enable_warmup=1, warmup_epochs=5, warmup_lr=1e-4,
+             warmup_reset=0, local_rank=-1, steps_per_epoch=5005, precision="bf16", output_dir="output", name="debug")
+    a.update(over)
+    return Namespace(**a)
+
+
+class Stage1Trainer:
+    def __init__(self, args: Namespace, device="cuda", student_state=None, teacher_state=None, distributed=False):
+        if not args.enable_pruning:
+            raise TypeError("enable_pruning=0 raises in the reference (uvc_optimizer_gating signature, SURVEY.md Q7)")
+        self.args = args
+        cfg = dict(CONFIGS[args.model_type]) if args.model_type in CONFIGS else dict(args.model_cfg)
+        args.head_size = cfg["embed_dim"] // cfg["num_heads"]              # joint_train.py:883-885
+        args.num_heads = cfg["num_heads"]
+        args.budget = float(args.budget)
+        kw = dict(patch_size=cfg["patch_size"], embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"],
+                  mlp_ratio=cfg.get("mlp_ratio", 4), qkv_bias=True, drop_rate=0, img_size=args.img_size,
+                  num_classes=args.num_classes, precision=args.precision, device=device)
+        model = DistilledVisionTransformer(enable_dist=args.enable_deit, gumbel_hard=False,
+                                           enable_patch_gating=args.enable_patch_gating, **kw)      # :135-140
+        if student_state is not None:
+            model.load_state_dict(student_state, strict=False)
+        register_masks(model)                                                                       # :169-171
+        args.total_param = count_mask(model)
+        teacher = None
+        if args.distillation_type != "none":                                                        # :948-981
+            teacher = DistilledVisionTransformer(enable_dist=args.enable_deit, **kw)
+            src = teacher_state if teacher_state is not None else {k: v for k, v in model.state_dict().items()
+                                                                   if not k.endswith(".mask") and k != "patch_gating"}
+            teacher.load_state_dict(src, strict=False)
+            teacher.eval()
+            teacher.frozen_weights = True
+        self.model, self.teacher = model, teacher
+        self.criterion = DistillationLoss(SoftTargetCrossEntropy(), teacher, args.distillation_type,
+                                          args.distillation_alpha, args.distillation_tau)          # :986-988
+        if isinstance(args.zlr_schedule_list, str):                                                 # :999-1005
+            lst = [int(v) for v in args.zlr_schedule_list.split(",")]
+            gap = args.num_epochs // len(lst)
+            args.zlr_schedule = {i * gap: v for i, v in enumerate(lst)}
+            args.zlr_schedule_list = lst
+        names, self.uvc_layers, ldict = get_uvc_layers(model, args)                                 # :1007
+        with torch.no_grad():                                                                       # :1010-1012
+            model.eval()
+            _, flops_list = model(torch.ones(1, 3, args.img_size, args.img_size, device=device), number=args.patch_ratio)
+        self.flops_list = flops_list
+        (self.minimax, self.dual_opt, self.s_opt, self.r_opt, self.g_opt) = build_minimax_model(
+            model, names, self.uvc_layers, ldict, args, flops_list)                                 # :1014
+        prune_w_mask(self.minimax)                                                                  # :1026
+        # train(): optimiser, schedule, DDP (:271-295)
+        self.optimizer = FusedAdamW(model, lr=args.learning_rate, weight_decay=args.weight_decay)
+        self.t_total = args.steps_per_epoch * args.num_epochs
+        sched = WarmupCosineSchedule if args.decay_type == "cosine" else WarmupLinearSchedule
+        self.scheduler = sched(self.optimizer, warmup_steps=args.warmup_steps, t_total=self.t_total)
+        self.zlr_scheduler = PresetLRScheduler(getattr(args, "zlr_schedule", {}))
+        self.ddp = DistributedDataParallel(model, message_size=250000000, gradient_predivide_factor=1.0,
+                                           dual_scalar=self.minimax.z) if distributed else None
+        model.train()
+        self.global_step = 0
+        self.epoch = 0
+        self.gating_grad_list = []
+
+    # -- epoch header (joint_train.py:335-386)
+    def begin_epoch(self, epoch: int):
+        a, mm = self.args, self.minimax
+        self.epoch = epoch
+        self.gating_grad_list = []
+        if epoch <= a.warmup_epochs and a.enable_warmup:
+            mm.model.enable_warmup = 1
+            mm.model.block_skip_gating.requires_grad = False
+            for g in self.optimizer.param_groups:
+                g["lr"] = a.warmup_lr
+        else:
+            mm.model.enable_warmup = 0
+            a.enable_warmup = 0
+            mm.model.block_skip_gating.requires_grad = True
+        prune_w_mask(mm, self.optimizer)
+        if not mm.model.enable_warmup:
+            mm.update_eps()
+
+    def get_tau(self):
+        if self.args.enable_patch_gating == 2:                                                      # :83-85,404-407
+            return 0.1 + (10 - 0.1) * self.global_step / self.t_total
+        return -1
+
+    # -- one step (joint_train.py:395-450), x / y already mixed
+    def step(self, x, y, tau=None, zero_grad=True):
+        a = self.args
+        outputs, _ = self.model(x, self.get_tau() if tau is None else tau, a.patch_ratio)
+        loss = self.criterion(x, outputs, y)
+        loss.backward()
+        gnorm = clip_grad_norm_(self.model, a.max_grad_norm)
+        self.optimizer.step()
+        self.scheduler.step()
+        self.global_step += 1
+        if not self.minimax.model.enable_warmup:
+            self.zlr_scheduler(self.dual_opt, self.epoch, "zlr")
+        self.minimax.update_gating()
+        cur, s, r, g, self.gating_grad_list = uvc_optimizer(
+            self.optimizer, self.minimax, self.s_opt, self.r_opt, self.g_opt, self.dual_opt, a, {"global_step": self.global_step},
+            [], self.flops_list, a.z_grad_clip, self.global_step, a.gating_interval, self.gating_grad_list)
+        if zero_grad:
+            self.optimizer.zero_grad()
+        return dict(loss=loss.detach(), outputs=outputs, gnorm=gnorm, cur=cur, s=s, r=r, g=g)

@@ -56,6 +56,7 @@ typedef struct uvc_gemm_tn_args {
   void* workspace;     /* >= uvc_gemm_tn_workspace_bytes() */
   int64_t workspace_bytes;
   const float* alpha_ptr;
+  float* colsum_out;   /* optional [N1]: beta*old + alpha * column sums of A (the bias gradient, same pass) */
   float alpha, beta;
   int32_t M, N1, N2, lda, ldb, ldc;
   int32_t dtype, a_is_f32;

@@ -92,10 +92,12 @@ def test_gemm_tn(dtype, M, N1, N2):
         Bt = to_t(B, dtype)
         Aeff = A.to(torch.bfloat16) if dtype == BF16 else A
         Cc.copy_(C0)
-        ops.gemm_tn(At, Bt, Cc, ws, dtype=dtype, alpha=2.0, alpha_ptr=alpha, beta=1.0)
+        cs = torch.ones(N1, device=dev())
+        ops.gemm_tn(At, Bt, Cc, ws, dtype=dtype, alpha=2.0, alpha_ptr=alpha, beta=1.0, colsum_out=cs)
         ref = C0.double() + Aeff.double().t() @ Bt.double()
         t = dict(rtol=2e-5, atol=2e-4) if dtype == F32 else dict(rtol=2e-2, atol=5e-2)
         torch.testing.assert_close(Cc.double(), ref, **t)
+        torch.testing.assert_close(cs.double(), 1 + Aeff.double().sum(0), rtol=1e-4, atol=2e-3)   # fused bias gradient
     # determinism: two runs bit-identical
     C1, C2 = torch.empty(N1, N2, device=dev()), torch.empty(N1, N2, device=dev())
     ops.gemm_tn(to_t(A, dtype), to_t(B, dtype), C1, ws, dtype=dtype)

@@ -66,12 +66,37 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
-// exact-erf GELU and its derivative (nn.GELU default, model_distilled.py:108,118)
+// exact-erf GELU and its derivative (nn.GELU default, model_distilled.py:108,118) -- float32 parity mode
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// bf16 mode: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16's 2^-9) with the
+// hardware exp/rcp -- ~4x fewer VALU instructions than ocml erff in the GEMM epilogues, and the
+// derivative reuses the same exponential: erf(x/sqrt2) = 1 - poly(t) * exp(-x^2/2).
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  e = __expf(-z * z);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float erfz = 1.0f - poly * e;                 // erf(|x|/sqrt2)
+  cdf = 0.5f * (1.0f + copysignf(erfz, x));
+}
+__device__ __forceinline__ float gelu_fast(float x) { float c, e; gelu_parts_fast(x, c, e); return x * c; }
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  float c, e; gelu_parts_fast(x, c, e);
+  return c + x * (0.39894228040143267794f * e);
+}
+template <typename T> struct Gelu;
+template <> struct Gelu<float> {
+  static __device__ __forceinline__ float f(float x) { return gelu_f(x); }
+  static __device__ __forceinline__ float g(float x) { return gelu_grad_f(x); }
+};
+template <> struct Gelu<bf16_t> {
+  static __device__ __forceinline__ float f(float x) { return gelu_fast(x); }
+  static __device__ __forceinline__ float g(float x) { return gelu_grad_fast(x); }
+};
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

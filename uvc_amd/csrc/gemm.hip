@@ -85,22 +85,58 @@ struct NtArgs {
   const float* alpha_ptr;   // optional device scalar multiplied into alpha
 };
 
+// vector of VN consecutive outputs in the coalesced epilogue layout
+template <typename TC> struct OutVec;
+template <> struct OutVec<float> {
+  static constexpr int VN = 4;
+  static __device__ __forceinline__ void st(float* p, const float* v) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+};
+template <> struct OutVec<bf16_t> {
+  static constexpr int VN = 8;
+  static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
+    u32x4 r;
+    r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]); r[2] = pack_bf16x2(v[4], v[5]); r[3] = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<u32x4*>(p) = r;
+  }
+};
+template <typename T, int VN> __device__ __forceinline__ void load_vec(const T* p, float* v);
+template <> __device__ __forceinline__ void load_vec<float, 4>(const float* p, float* v) {
+  const f32x4 r = *reinterpret_cast<const f32x4*>(p); v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+}
+template <> __device__ __forceinline__ void load_vec<float, 8>(const float* p, float* v) { load_vec<float, 4>(p, v); load_vec<float, 4>(p + 4, v + 4); }
+template <> __device__ __forceinline__ void load_vec<bf16_t, 8>(const bf16_t* p, float* v) {
+  const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(r[e] << 16); v[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void load_vec<bf16_t, 4>(const bf16_t* p, float* v) {
+  const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+  v[0] = __uint_as_float(r[0] << 16); v[1] = __uint_as_float(r[0] & 0xffff0000u);
+  v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
+}
+
+constexpr int EP_LD = 68;   // floats per staged accumulator row (64 + 4 pad: conflict-free 16-byte LDS writes)
+
 template <typename TA, typename T, typename TC, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
   typedef Mma<T> MM;
   constexpr int CH = MM::CH;
   constexpr int BK = 8 * CH;                    // elements per K tile (128 B of T per row)
-  __shared__ __attribute__((aligned(16))) char sA[NT_BM * NT_ROWB];
-  __shared__ __attribute__((aligned(16))) char sB[NT_BN * NT_ROWB];
+  __shared__ __attribute__((aligned(16))) char smem[(NT_BM + NT_BN) * NT_ROWB];
+  char* sA = smem;
+  char* sB = smem + NT_BM * NT_ROWB;
   const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A);
   const T* __restrict__ B = reinterpret_cast<const T*>(g.B);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
-  // XCD-aware tile order: consecutive M tiles (which share no operand but stream A once) stay put;
-  // all N tiles of one M tile run back to back on the same XCD so A is fetched from HBM once.
+  // XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8),
+  // each with a private L2.  All N tiles of one M tile get block ids that are congruent mod 8 and
+  // adjacent in dispatch order, so the A panel is fetched from HBM once and re-read from that XCD's L2.
   const int ntn = (g.N + NT_BN - 1) / NT_BN;
-  const int bm = blockIdx.x / ntn, bn = blockIdx.x % ntn;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int bn = q % ntn, bm = (q / ntn) * 8 + xcd;
   const int m0 = bm * NT_BM, n0 = bn * NT_BN;
+  if (m0 >= g.M) return;
   const int lc = tid & 7, lr = tid >> 3;        // chunk column / first row of this thread's loads
 
   u32x4 ra[4], rb[4];
@@ -156,75 +192,103 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
     }
   }
 
-  // ---- epilogue: lane owns row m = .. + (lane&15), columns n = .. + (lane>>4)*4 + {0..3}
+  // ---- epilogue.  The MFMA leaves lane (l) with row m = (l&15), columns (l>>4)*4+{0..3} of each 16x16
+  // tile.  Each wave transposes its 64x64 sub-tile through LDS, 32 rows at a time, so that global
+  // accesses are whole 128-byte (bf16) / 256-byte (fp32) row segments: 16 bytes per lane.
+  constexpr int VN = OutVec<TC>::VN;
+  constexpr int LPR = 64 / VN;                  // lanes per 64-column row
+  constexpr int RPI = 64 / LPR;                 // rows per wave instruction
   TC* __restrict__ C = reinterpret_cast<TC*>(g.C);
   float alpha = g.alpha;
   if (g.alpha_ptr) alpha *= *g.alpha_ptr;
   float d0 = 0.f, d1 = 1.f;
   if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
-  const bool vec = ((g.ldc & 3) == 0);
+  float* stg = reinterpret_cast<float*>(smem) + w * (32 * EP_LD);
+  const int cc = (lane % LPR) * VN;
+  const int n = n0 + wn * 64 + cc;
+  const bool nfull = (n + VN <= g.N) && ((g.ldc % VN) == 0);
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-    if (m >= g.M) continue;
-    const size_t mo = (size_t)m;
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      if (n >= g.N) continue;
-      f32x4 v = acc[i][j];
-      const bool full = vec && (n + 3 < g.N);
+    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= alpha;
-      if (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(stg + (ii * 16 + (lane & 15)) * EP_LD + j * 16 + (lane >> 4) * 4) = acc[2 * h + ii][j];
+    __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] += g.bias[n + e];
-      }
-      if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
-        const float* rp = g.R + mo * g.ldr + n;
-        if (full && (g.ldr & 3) == 0) { const f32x4 r4 = OutIO<float>::ld4(rp);
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int r = it * RPI + lane / LPR;
+      const int m = m0 + wm * 64 + h * 32 + r;
+      float v[VN];
+      load_vec<float, VN>(stg + r * EP_LD + cc, v);
+      if (m < g.M && n < g.N) {
+        const size_t mo = (size_t)m;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += r4[e];
-        } else {
+        for (int e = 0; e < VN; ++e) v[e] *= alpha;
+        if (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] += rp[e];
+          for (int e = 0; e < VN; ++e) if (n + e < g.N) v[e] += g.bias[n + e];
         }
-      }
-      if (EPI == UVC_EPI_BIAS_RESID_GATE) {
-        const float* rp = g.R2 + mo * g.ldr + n;
+        if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
+          const float* rp = g.R + mo * g.ldr + n;
+          float rv[VN];
+          if (nfull && (g.ldr % VN) == 0) load_vec<float, VN>(rp, rv);
+          else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] = d1 * v[e] + d0 * rp[e];
-      }
-      if (EPI == UVC_EPI_DGELU) {
-        const T* ap = reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n;
+            for (int e = 0; e < VN; ++e) rv[e] = (n + e < g.N) ? rp[e] : 0.f;
+          }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] *= gelu_grad_f(ElemIO<T>::load(ap + e));
-      }
-      TC* cp = C + mo * g.ldc + n;
-      if (EPI == UVC_EPI_BIAS_GELU) {
-        TC* c2 = reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n;
-        f32x4 u;
+          for (int e = 0; e < VN; ++e) v[e] += rv[e];
+        }
+        if (EPI == UVC_EPI_BIAS_RESID_GATE) {
+          const float* rp = g.R2 + mo * g.ldr + n;
+          float rv[VN];
+          if (nfull && (g.ldr % VN) == 0) load_vec<float, VN>(rp, rv);
+          else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = gelu_f(v[e]);
-        if (full) { OutIO<TC>::st4(cp, v); OutIO<TC>::st4(c2, u); }
+            for (int e = 0; e < VN; ++e) rv[e] = (n + e < g.N) ? rp[e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] = d1 * v[e] + d0 * rv[e];
+        }
+        if (EPI == UVC_EPI_DGELU) {
+          const T* ap = reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n;
+          float av[VN];
+          if (nfull && (g.ldaux % VN) == 0) load_vec<T, VN>(ap, av);
+          else {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) av[e] = (n + e < g.N) ? ElemIO<T>::load(ap + e) : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] *= Gelu<T>::g(av[e]);
+        }
+        TC* cp = C + mo * g.ldc + n;
+        if (nfull) OutVec<TC>::st(cp, v);
         else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) { ElemIO<TC>::store(cp + e, v[e]); ElemIO<TC>::store(c2 + e, u[e]); }
+          for (int e = 0; e < VN; ++e) if (n + e < g.N) ElemIO<TC>::store(cp + e, v[e]);
         }
-      } else {
-        if (full) OutIO<TC>::st4(cp, v);
-        else {
+        if (EPI == UVC_EPI_BIAS_GELU) {
+          TC* c2 = reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n;
+          float u[VN];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) ElemIO<TC>::store(cp + e, v[e]);
+          for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
+          if (nfull) OutVec<TC>::st(c2, u);
+          else {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) if (n + e < g.N) ElemIO<TC>::store(c2 + e, u[e]);
+          }
         }
       }
     }
+    __syncthreads();
   }
 }
 
 template <typename TA, typename T, typename TC>
 static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
-  const int grid = ceil_div(a.M, NT_BM) * ceil_div(a.N, NT_BN);
+  const int grid = ceil_div(ceil_div(a.M, NT_BM), 8) * 8 * ceil_div(a.N, NT_BN);   // M tiles padded to the 8 XCDs
 #define NT_CASE(E) case E: k_gemm_nt<TA, T, TC, E><<<grid, 256, 0, st>>>(a); break;
   switch (epi) {
     NT_CASE(UVC_EPI_NONE) NT_CASE(UVC_EPI_BIAS) NT_CASE(UVC_EPI_BIAS_GELU) NT_CASE(UVC_EPI_BIAS_RESID)
@@ -307,8 +371,22 @@ template <> struct TrFrag<float> {
 };
 
 struct TnArgs {
-  const void* A; const void* B; float* part;
+  const void* A; const void* B; float* part; float* bpart;   // bpart: [splits][N1] column sums of A (bias gradient) or null
   int M, N1, N2, lda, ldb, rows_per_split;
+};
+
+template <typename T> struct ChunkSum;    // add the CH elements of a staged chunk into float accumulators
+template <> struct ChunkSum<bf16_t> {
+  static __device__ __forceinline__ void add(const u32x4& r, float* s) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[2 * e] += __uint_as_float(r[e] << 16); s[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u); }
+  }
+};
+template <> struct ChunkSum<float> {
+  static __device__ __forceinline__ void add(const u32x4& r, float* s) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += __uint_as_float(r[e]);
+  }
 };
 
 template <typename TA, typename T>
@@ -345,11 +423,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(TnArgs g) {
       rb[i] = (m < mend && n < g.N2) ? ChunkLoad<T, T>::ld(B + (size_t)m * g.ldb + n) : z;
     }
   };
+  float csum[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) csum[e] = 0.f;
+  const bool do_cs = g.bpart != nullptr && blockIdx.y == 0;
   auto lstore = [&]() {
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
       const int id = tid + 256 * i, row = id / C1, c = id % C1;
       *reinterpret_cast<u32x4*>(sA + row * LD1 + c * 16) = ra[i];
+      if (do_cs) ChunkSum<T>::add(ra[i], csum);      // this thread always owns chunk column tid % C1
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
@@ -390,6 +473,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(TnArgs g) {
       }
     }
   }
+  if (do_cs) {     // column sums of the A slice: reduce the 256/C1 threads that share a chunk column (fixed order)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sA);                 // [256/C1][TN_B1]
+    const int c = tid % C1, grp = tid / C1;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) red[grp * TN_B1 + c * CH + e] = csum[e];
+    __syncthreads();
+    if (tid < TN_B1 && n10 + tid < g.N1) {
+      float t = 0.f;
+      for (int q = 0; q < 256 / C1; ++q) t += red[q * TN_B1 + tid];
+      g.bpart[(size_t)blockIdx.z * g.N1 + n10 + tid] = t;
+    }
+  }
   // partial[z][n1][n2]: lane owns n1 = .. + (lane&15), n2 = .. + (lane>>4)*4 + {0..3}
   float* P = g.part + (size_t)blockIdx.z * g.N1 * g.N2;
 #pragma unroll
@@ -409,24 +505,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(TnArgs g) {
 }
 
 __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ part, float* __restrict__ C, int n, int ldc,
-                                                   int N2, int splits, float alpha, const float* alpha_ptr, float beta) {
+                                                   int N2, int splits, float alpha, const float* alpha_ptr, float beta,
+                                                   const float* __restrict__ bpart, float* __restrict__ bias_out, int N1) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += part[(size_t)z * n + i];
+  if (i >= n + (bpart ? N1 : 0)) return;
   if (alpha_ptr) alpha *= *alpha_ptr;
-  float* c = C + (size_t)(i / N2) * ldc + (i % N2);
-  *c = (beta != 0.f ? beta * *c : 0.f) + alpha * s;
+  float s = 0.f;
+  if (i < n) {
+    for (int z = 0; z < splits; ++z) s += part[(size_t)z * n + i];
+    float* c = C + (size_t)(i / N2) * ldc + (i % N2);
+    *c = (beta != 0.f ? beta * *c : 0.f) + alpha * s;
+  } else {
+    const int j = i - n;
+    for (int z = 0; z < splits; ++z) s += bpart[(size_t)z * N1 + j];
+    bias_out[j] = (beta != 0.f ? beta * bias_out[j] : 0.f) + alpha * s;
+  }
 }
 
 extern "C" int uvc_gemm_tn_workspace_bytes(int M, int N1, int N2, int64_t* bytes, int* splits_out) {
   if (!bytes) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn_workspace_bytes: null");
   const int tiles = ceil_div(N1, TN_B1) * ceil_div(N2, TN_B2);
-  int splits = ceil_div(1024, tiles);                       // ~4 blocks per CU
+  int splits = ceil_div(768, tiles);                        // ~3 blocks per CU
   const int max_splits = ceil_div(M, TN_BM);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  *bytes = (int64_t)splits * N1 * N2 * 4;
+  *bytes = (int64_t)splits * ((int64_t)N1 * N2 + N1) * 4;   // partial tiles + partial column sums
   if (splits_out) *splits_out = splits;
   return UVC_OK;
 }
@@ -442,6 +545,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   if (p->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: workspace too small");
   TnArgs a;
   a.A = p->A; a.B = p->B; a.part = (float*)p->workspace; a.M = p->M; a.N1 = p->N1; a.N2 = p->N2; a.lda = p->lda; a.ldb = p->ldb;
+  a.bpart = p->colsum_out ? a.part + (size_t)splits * p->N1 * p->N2 : nullptr;
   int rps = ceil_div(p->M, splits);
   rps = ceil_div(rps, TN_BM) * TN_BM;
   splits = ceil_div(p->M, rps);
@@ -457,7 +561,8 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   } else return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: dtype must be UVC_F32 or UVC_BF16");
   UVC_CHECK_LAUNCH();
   const int n = p->N1 * p->N2;
-  k_tn_reduce<<<ceil_div(n, 256), 256, 0, st>>>(a.part, p->C, n, p->ldc, p->N2, splits, p->alpha, p->alpha_ptr, p->beta);
+  k_tn_reduce<<<ceil_div(n + (a.bpart ? p->N1 : 0), 256), 256, 0, st>>>(a.part, p->C, n, p->ldc, p->N2, splits, p->alpha, p->alpha_ptr, p->beta,
+                                                                         a.bpart, p->colsum_out, p->N1);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

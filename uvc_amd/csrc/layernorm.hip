@@ -135,6 +135,173 @@ __global__ __launch_bounds__(256) void k_ln_bwd_reduce(uvc_ln_args a, int nblock
   }
 }
 
+
+// ---- vectorised path (D % 64 == 0): 16 lanes per row x 16-byte accesses, 4 rows per wave in flight ----
+template <typename T> struct Ld4;
+template <> struct Ld4<float> {
+  static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Ld4<bf16_t> {
+  static __device__ __forceinline__ f32x4 ld(const bf16_t* p) {
+    const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, f32x4 v) {
+    u32x2 r; r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p) = r;
+  }
+};
+__device__ __forceinline__ float sum16(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+constexpr int LNV_FWD_ROWS = 64;     // rows per block (16 per wave, 4 at a time)
+template <typename TY, int NV4>
+__global__ __launch_bounds__(256) void k_ln_fwd_v(uvc_ln_args a) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane & 15, rg = lane >> 4;
+  f32x4 gam[NV4], bet[NV4];
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) { gam[i] = Ld4<float>::ld(a.gamma + (sub + 16 * i) * 4); bet[i] = Ld4<float>::ld(a.beta + (sub + 16 * i) * 4); }
+  const float invD = 1.0f / (float)a.D;
+  const int rbase = blockIdx.x * LNV_FWD_ROWS + w * 16;
+#pragma unroll 2
+  for (int it = 0; it < 4; ++it) {
+    const int r = rbase + it * 4 + rg;
+    const bool ok = r < a.rows;
+    const float* x = a.x + (ok ? row_off(r, a.rows_per_group, a.group_stride, a.D) : 0);
+    f32x4 v[NV4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      v[i] = ok ? Ld4<float>::ld(x + (sub + 16 * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = sum16(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(sum16(q) * invD + a.eps);
+    if (ok) {
+      TY* y = reinterpret_cast<TY*>(a.y) + (size_t)r * a.D;
+#pragma unroll
+      for (int i = 0; i < NV4; ++i) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gam[i][e] + bet[i][e];
+        Ld4<TY>::st(y + (sub + 16 * i) * 4, o);
+      }
+      if (sub == 0) { a.mean[r] = mean; a.rstd[r] = rstd; }
+    }
+  }
+}
+
+template <typename TDY, int NV4>
+__global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
+  __shared__ float red[4][2 * 64 * NV4 + 2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane & 15, rg = lane >> 4;
+  f32x4 gam[NV4], dgam[NV4], dbet[NV4];
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    gam[i] = Ld4<float>::ld(a.gamma + (sub + 16 * i) * 4);
+    dgam[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbet[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float a1 = a.a1 ? *a.a1 : 1.f, a2 = a.a2 ? *a.a2 : 1.f;
+  float dotA = 0.f, dotB = 0.f;
+  const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
+  const int r1 = min(a.rows, r0 + LN_ROWS_PER_BLOCK);
+  const float invD = 1.0f / (float)a.D;
+  for (int rb = r0 + w * 4; rb < r1; rb += 16) {
+    const int r = rb + rg;
+    const bool ok = r < r1;
+    const size_t off = ok ? row_off(r, a.rows_per_group, a.group_stride, a.D) : 0;
+    const float* x = a.x + off;
+    const TDY* dy = reinterpret_cast<const TDY*>(a.dy) + (size_t)(ok ? r : 0) * a.D;
+    const float mean = ok ? a.mean[r] : 0.f, rstd = ok ? a.rstd[r] : 0.f;
+    f32x4 xv[NV4], gy[NV4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 d = ok ? Ld4<TDY>::ld(dy + (sub + 16 * i) * 4) : z;
+      xv[i] = ok ? Ld4<float>::ld(x + (sub + 16 * i) * 4) : z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[i][e] - mean) * rstd;
+        gy[i][e] = d[e] * gam[i][e];
+        dgam[i][e] += d[e] * xh;
+        dbet[i][e] += d[e];
+        c1 += gy[i][e];
+        c2 += gy[i][e] * xh;
+      }
+    }
+    c1 = sum16(c1) * invD;
+    c2 = sum16(c2) * invD;
+    if (ok) {
+      float* dx = a.dx + off;
+#pragma unroll
+      for (int i = 0; i < NV4; ++i) {
+        const int c = (sub + 16 * i) * 4;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[i][e] - c1 - ((xv[i][e] - mean) * rstd) * c2);
+        if (a.add1) { const f32x4 t = Ld4<float>::ld(a.add1 + off + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += a1 * t[e]; }
+        if (a.add2) { const f32x4 t = Ld4<float>::ld(a.add2 + off + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] += a2 * t[e]; dotB += t[e] * xv[i][e]; } }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dotA += o[e] * xv[i][e];
+        Ld4<float>::st(dx + c, o);
+      }
+    }
+  }
+  // reduce the 4 row groups of the wave, then the 4 waves (fixed order)
+#pragma unroll
+  for (int i = 0; i < NV4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g = dgam[i][e], b = dbet[i][e];
+      g += __shfl_xor(g, 16, 64); g += __shfl_xor(g, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (rg == 0) { red[w][(sub + 16 * i) * 4 + e] = g; red[w][64 * NV4 + (sub + 16 * i) * 4 + e] = b; }
+    }
+  dotA = wave_sum(dotA); dotB = wave_sum(dotB);
+  if (lane == 0) { red[w][2 * 64 * NV4] = dotA; red[w][2 * 64 * NV4 + 1] = dotB; }
+  __syncthreads();
+  float* P = a.partial + (size_t)blockIdx.x * (2 * a.D + 2);
+  for (int c = threadIdx.x; c < 2 * 64 * NV4 + 2; c += 256) P[c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+}
+
+// two-stage reduction of the per-block partials: [nblocks, W] -> [RED_S, W] -> [W]
+constexpr int RED_S = 16;
+__global__ __launch_bounds__(256) void k_ln_bwd_reduce1(const float* __restrict__ partial, int nblocks, int W, float* __restrict__ p2) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6, s = blockIdx.y;
+  const int b0 = (int)((long)nblocks * s / RED_S), b1 = (int)((long)nblocks * (s + 1) / RED_S);
+  float acc = 0.f;
+  if (c < W)
+    for (int b = b0 + sl; b < b1; b += 4) acc += partial[(size_t)b * W + c];
+  red[sl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sl == 0 && c < W) { const int t = threadIdx.x; p2[(size_t)s * W + c] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]; }
+}
+__global__ __launch_bounds__(256) void k_ln_bwd_reduce2(uvc_ln_args a, const float* __restrict__ p2) {
+  const int W = 2 * a.D + 2;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= W) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int s = 0; s < RED_S; ++s) tot += p2[(size_t)s * W + c];
+  if (c < a.D) a.dgamma[c] = (a.beta_acc != 0.f ? a.beta_acc * a.dgamma[c] : 0.f) + tot;
+  else if (c < 2 * a.D) a.dbeta[c - a.D] = (a.beta_acc != 0.f ? a.beta_acc * a.dbeta[c - a.D] : 0.f) + tot;
+  else if (a.dots) a.dots[c - 2 * a.D] = tot;
+}
+
 int check(const uvc_ln_args* p) {
   if (!p || !p->x || !p->gamma || !p->mean || !p->rstd) return uvc_set_error_msg(UVC_ERR_ARG, "layernorm: null pointer");
   if (p->rows <= 0 || p->D <= 0 || p->D > 1024) return uvc_set_error_msg(UVC_ERR_ARG, "layernorm: need 0 < D <= 1024");
@@ -143,6 +310,19 @@ int check(const uvc_ln_args* p) {
 }
 
 template <typename T> int launch_fwd(const uvc_ln_args& a, hipStream_t st) {
+  if (a.D % 64 == 0 && (a.group_stride % 4) == 0) {
+    const int grid = ceil_div(a.rows, LNV_FWD_ROWS);
+    switch (a.D / 64) {
+      case 2: k_ln_fwd_v<T, 2><<<grid, 256, 0, st>>>(a); break;
+      case 3: k_ln_fwd_v<T, 3><<<grid, 256, 0, st>>>(a); break;
+      case 6: k_ln_fwd_v<T, 6><<<grid, 256, 0, st>>>(a); break;
+      case 12: k_ln_fwd_v<T, 12><<<grid, 256, 0, st>>>(a); break;
+      default: goto generic;
+    }
+    UVC_CHECK_LAUNCH();
+    return UVC_OK;
+  }
+generic:
   const int grid = ceil_div(a.rows, 4);
   const int nv = ceil_div(a.D, 64);
   if (nv <= 2) k_ln_fwd<T, 2><<<grid, 256, 0, st>>>(a);
@@ -156,20 +336,41 @@ template <typename T> int launch_fwd(const uvc_ln_args& a, hipStream_t st) {
 template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
   const int grid = ceil_div(a.rows, LN_ROWS_PER_BLOCK);
   const int nv = ceil_div(a.D, 64);
-  if (nv <= 2) k_ln_bwd<T, 2><<<grid, 256, 0, st>>>(a);
-  else if (nv <= 3) k_ln_bwd<T, 3><<<grid, 256, 0, st>>>(a);
-  else if (nv <= 6) k_ln_bwd<T, 6><<<grid, 256, 0, st>>>(a);
-  else if (nv <= 12) k_ln_bwd<T, 12><<<grid, 256, 0, st>>>(a);
-  else k_ln_bwd<T, 16><<<grid, 256, 0, st>>>(a);
+  bool vec = a.D % 64 == 0 && (a.group_stride % 4) == 0;
+  if (vec) {
+    switch (a.D / 64) {
+      case 2: k_ln_bwd_v<T, 2><<<grid, 256, 0, st>>>(a); break;
+      case 3: k_ln_bwd_v<T, 3><<<grid, 256, 0, st>>>(a); break;
+      case 6: k_ln_bwd_v<T, 6><<<grid, 256, 0, st>>>(a); break;
+      case 12: k_ln_bwd_v<T, 12><<<grid, 256, 0, st>>>(a); break;
+      default: vec = false;
+    }
+  }
+  if (!vec) {
+    if (nv <= 2) k_ln_bwd<T, 2><<<grid, 256, 0, st>>>(a);
+    else if (nv <= 3) k_ln_bwd<T, 3><<<grid, 256, 0, st>>>(a);
+    else if (nv <= 6) k_ln_bwd<T, 6><<<grid, 256, 0, st>>>(a);
+    else if (nv <= 12) k_ln_bwd<T, 12><<<grid, 256, 0, st>>>(a);
+    else k_ln_bwd<T, 16><<<grid, 256, 0, st>>>(a);
+  }
   UVC_CHECK_LAUNCH();
-  k_ln_bwd_reduce<<<ceil_div(2 * a.D + 2, 64), 256, 0, st>>>(a, grid);
+  const int W = 2 * a.D + 2;
+  if (grid >= 4 * RED_S) {
+    float* p2 = a.partial + (size_t)grid * W;            // scratch tail (uvc_layernorm_bwd_blocks reserves it)
+    k_ln_bwd_reduce1<<<dim3(ceil_div(W, 64), RED_S), 256, 0, st>>>(a.partial, grid, W, p2);
+    UVC_CHECK_LAUNCH();
+    k_ln_bwd_reduce2<<<ceil_div(W, 256), 256, 0, st>>>(a, p2);
+  } else {
+    k_ln_bwd_reduce<<<ceil_div(W, 64), 256, 0, st>>>(a, grid);
+  }
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }
 
 }  // namespace
 
-extern "C" int uvc_layernorm_bwd_blocks(int32_t rows) { return ceil_div(rows, LN_ROWS_PER_BLOCK); }
+// number of [2D+2]-float rows the backward scratch must hold: per-block partials + the second reduction stage
+extern "C" int uvc_layernorm_bwd_blocks(int32_t rows) { return ceil_div(rows, LN_ROWS_PER_BLOCK) + RED_S; }
 
 extern "C" int uvc_layernorm_fwd(const uvc_ln_args* p, void* stream) {
   if (int e = check(p)) return e;

@@ -118,9 +118,12 @@ int nt(const Ctx& c, const void* A, int a_f32, const void* B, void* C, int c_f32
   a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32; a.c_is_f32 = c_f32 || c.d.dtype == UVC_F32; a.epilogue = epi;
   return uvc_gemm_nt(&a, c.st);
 }
-int tn(const Ctx& c, const void* A, int a_f32, const void* B, float* C, int M, int N1, int N2, const float* alpha_ptr = nullptr, int lda = 0, int ldb = 0) {
+// weight gradient + (same pass over A) bias gradient
+int tn(const Ctx& c, const void* A, int a_f32, const void* B, float* C, float* bias_grad, int M, int N1, int N2, const float* alpha_ptr = nullptr,
+       int lda = 0, int ldb = 0) {
   uvc_gemm_tn_args a;
   memset(&a, 0, sizeof(a));
+  a.colsum_out = bias_grad;
   a.A = A; a.B = B; a.C = C; a.workspace = c.w.tn_ws; a.workspace_bytes = c.w.tn_ws_bytes; a.alpha_ptr = alpha_ptr; a.alpha = 1.0f;
   a.beta = c.io->accumulate; a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda ? lda : N1; a.ldb = ldb ? ldb : N2; a.ldc = N2;
   a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32;
@@ -307,13 +310,11 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   // heads: dhc = dlogits . W ; dW = dlogits^T . hc ; db = colsum(dlogits)
   TRY(nt(c, io->d_logits, 1, sh(c, so.head_wt), w.dhc, 0, d.B, d.D, d.NC, UVC_EPI_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
          d.ntok * d.D));
-  TRY(tn(c, io->d_logits, 1, w.hc, G + o.head_w, d.B, d.NC, d.D, nullptr, 0, d.ntok * d.D));
-  TRY(csum(c, io->d_logits, 1, G + o.head_b, d.B, d.NC));
+  TRY(tn(c, io->d_logits, 1, w.hc, G + o.head_w, G + o.head_b, d.B, d.NC, d.D, nullptr, 0, d.ntok * d.D));
   if (d.ntok == 2) {
     TRY(nt(c, io->d_logits_dist, 1, sh(c, so.headd_wt), (char*)w.dhc + (size_t)d.D * d.tsz, 0, d.B, d.D, d.NC, UVC_EPI_NONE, nullptr, nullptr, nullptr,
            nullptr, nullptr, nullptr, nullptr, 0, d.ntok * d.D));
-    TRY(tn(c, io->d_logits_dist, 1, (const char*)w.hc + (size_t)d.D * d.tsz, G + o.headd_w, d.B, d.NC, d.D, nullptr, 0, d.ntok * d.D));
-    TRY(csum(c, io->d_logits_dist, 1, G + o.headd_b, d.B, d.NC));
+    TRY(tn(c, io->d_logits_dist, 1, (const char*)w.hc + (size_t)d.D * d.tsz, G + o.headd_w, G + o.headd_b, d.B, d.NC, d.D, nullptr, 0, d.ntok * d.D));
   }
   // final norm backward -> gA = dL/dx_L (zero except the token rows)
   hipError_t he = hipMemsetAsync(w.gA, 0, (size_t)d.M * d.D * 4, hs);
@@ -330,20 +331,16 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     const float* g1 = io->gate_d ? io->gate_d + 2 * l + 1 : nullptr;   // d1
     // MLP: out = d1*(x1 + fc2(u)) + d0*x
     TRY(nt(c, w.gA, 1, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
-    TRY(tn(c, w.gA, 1, b.u, G + q[10], d.M, d.D, d.F, g1));
-    TRY(csum(c, w.gA, 1, G + q[11], d.M, d.D, g1));
+    TRY(tn(c, w.gA, 1, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1));
     TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
-    TRY(tn(c, w.dA, 0, b.h2, G + q[8], d.M, d.F, d.D));
-    TRY(csum(c, w.dA, 0, G + q[9], d.M, d.F));
+    TRY(tn(c, w.dA, 0, b.h2, G + q[8], G + q[9], d.M, d.F, d.D));
     TRY(ln_bwd(c, w.dH, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr, d.M, 1, d.D));   // gB = dL/dx1
     // attention
     TRY(nt(c, w.gB, 1, sh(c, so.blk_wt[l][1]), w.dH, 0, d.M, d.D, d.D, UVC_EPI_NONE));                                      // dO
-    TRY(tn(c, w.gB, 1, b.o, G + q[4], d.M, d.D, d.D));
-    TRY(csum(c, w.gB, 1, G + q[5], d.M, d.D));
+    TRY(tn(c, w.gB, 1, b.o, G + q[4], G + q[5], d.M, d.D, d.D));
     TRY(attn(c, b, true));
     TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));
-    TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], d.M, 3 * d.D, d.D));
-    TRY(csum(c, w.dqkv, 0, G + q[3], d.M, 3 * d.D));
+    TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], G + q[3], d.M, 3 * d.D, d.D));
     // gA <- dL/dx_l = LN1'(dH) + gB + d0*gA ; dots: <new gA, x_l>, <old gA, x_l>
     TRY(ln_bwd(c, w.dH, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0, w.dotsraw + 2 * l, d.M, 1, d.D));
   }
@@ -354,7 +351,6 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   // token assembly + patch embedding
   TRY(uvc_assemble_tokens_bwd(w.gA, w.pe, io->patch_mask, w.dpe, G + o.pos_embed, G + o.cls_token, d.ntok == 2 ? G + o.dist_token : nullptr,
                               io->d_patch_mask, d.B, d.np, d.D, d.ntok, d.dtype, 0, io->accumulate, stream));
-  TRY(tn(c, w.dpe, 0, w.patches, G + o.patch_w, d.B * d.np, d.D, d.K0));
-  TRY(csum(c, w.dpe, 0, G + o.patch_b, d.B * d.np, d.D));
+  TRY(tn(c, w.dpe, 0, w.patches, G + o.patch_w, G + o.patch_b, d.B * d.np, d.D, d.K0));
   return UVC_OK;
 }

@@ -61,13 +61,13 @@ def gemm_tn_workspace_bytes(M, N1, N2) -> int:
 
 
 def gemm_tn(A, B, C_, workspace, *, dtype, alpha=1.0, alpha_ptr=None, beta=0.0, M=None, N1=None, N2=None, lda=None,
-            ldb=None):
-    """C[N1,N2] = beta*C + alpha * A[M,N1]^T . B[M,N2]."""
-    _chk(A, B, C_, workspace, alpha_ptr)
+            ldb=None, colsum_out=None):
+    """C[N1,N2] = beta*C + alpha * A[M,N1]^T . B[M,N2]  (+ optional colsum_out[N1] = beta*old + alpha*colsum(A))."""
+    _chk(A, B, C_, workspace, alpha_ptr, colsum_out)
     a = L.uvc_gemm_tn_args()
     a.A, a.B, a.C, a.workspace = L.ptr(A), L.ptr(B), L.ptr(C_), L.ptr(workspace)
     a.workspace_bytes = workspace.numel() * workspace.element_size()
-    a.alpha_ptr, a.alpha, a.beta = L.ptr(alpha_ptr), alpha, beta
+    a.alpha_ptr, a.alpha, a.beta, a.colsum_out = L.ptr(alpha_ptr), alpha, beta, L.ptr(colsum_out)
     a.M = M if M is not None else A.shape[0]
     a.N1 = N1 if N1 is not None else A.shape[1]
     a.N2 = N2 if N2 is not None else B.shape[1]

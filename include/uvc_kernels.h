@@ -148,7 +148,20 @@ int uvc_assemble_tokens_bwd(const float* dtok, const float* pe, const float* row
                             int32_t dpe_is_f32, float beta_acc, void* stream);
 /* column sums: out[n] = beta*out[n] + alpha * sum_m X[m,n];  X is T or float32.  partial: [uvc_colsum_blocks(M), N]. */
 int uvc_colsum(const void* X, int32_t M, int32_t N, int32_t ldx, int32_t dtype, int32_t x_is_f32, float* partial, float* out,
-               float alpha, const float* alpha_ptr, float beta, void* stream);
+               float alpha, const float* alpha_ptr, float beta, const float* row_weight /* optional [M] */, void* stream);
+/* patch gating (model_distilled.py:434-456, :36-63).
+ * mode 1: mask[b,i] = sigmoid(patch_gating[i]) (or the hard >= .5 threshold with token 0 kept); backward sums over the batch.
+ * mode 2: scores = Linear(D->1)(patch embedding); mask = straight-through Gumbel top-k of log_softmax(scores)
+ *         with k = int(ratio*P), tau, Exp(1) draws e[B,P]; token 0 forced to 1.  ysoft/psoft [B,P] are kept for backward. */
+int uvc_patch_gate_sigmoid(const float* pg, float* mask, int32_t B, int32_t P, int32_t hard, void* stream);
+int uvc_patch_gate_sigmoid_bwd(const float* pg, const float* dmask, float* dpg, int32_t B, int32_t P, float beta_acc, void* stream);
+int uvc_patch_scores(const float* pe, const float* w, const float* bias, float* scores, int32_t rows, int32_t D, void* stream);
+int uvc_patch_topk_mask(const float* scores, const float* e, float* mask, float* ysoft, float* psoft, int32_t B, int32_t P, int32_t k,
+                        float tau, void* stream);
+int uvc_patch_topk_mask_bwd(const float* dmask, const float* ysoft, const float* psoft, float* dscores, int32_t B, int32_t P, float tau,
+                            void* stream);
+/* X[row,:] += row_weight[row] * w[:]   (X of type T, or float32 when x_is_f32) */
+int uvc_add_outer(void* X, const float* row_weight, const float* w, int32_t rows, int32_t D, int32_t dtype, int32_t x_is_f32, void* stream);
 int uvc_colsum_blocks(int32_t M);
 /* float32 -> bf16 copy and transposed copy of a [R,C] matrix (weight shadows for the GEMMs). */
 int uvc_cast_transpose(const float* W, int32_t R, int32_t C, void* w_bf16, void* wt, int32_t dtype, void* stream);

@@ -51,6 +51,7 @@ typedef struct uvc_vit_shadow_offsets {
 
 int uvc_vit_layout(const uvc_vit_cfg* cfg, uvc_vit_offsets* off, uvc_vit_shadow_offsets* soff);
 int64_t uvc_vit_workspace_bytes(const uvc_vit_cfg* cfg, int32_t batch, int32_t training);
+int uvc_vit_ws_offsets(const uvc_vit_cfg* cfg, int32_t batch, int32_t training, int64_t* pe_off, int64_t* dpe_off);
 
 /* refresh the T-typed shadows (W and W^T) from the float32 master weights */
 int uvc_vit_update_shadows(const uvc_vit_cfg* cfg, const float* params, void* shadow, void* stream);
@@ -74,10 +75,12 @@ typedef struct uvc_vit_io {
   int32_t gate_mode;        /* 0 warm-up / none, 1 soft Gumbel, 2 softL0: selects d(gate logits) formula */
   float gate_eps;           /* softL0 eps */
   float accumulate;         /* backward: 0 = overwrite gradients, 1 = add (gradient accumulation) */
-  /* backward stages [stage_begin, stage_end): 0 = heads + final norm, 1..L = blocks L-1..0,
-   * L+1 = gate logits + token assembly + patch embedding.  0,0 = everything.  Lets the host cut the
-   * backward at gradient-bucket boundaries and start the RCCL all-reduce of a finished bucket on a
-   * second stream while the rest of the backward runs. */
+  /* stages [stage_begin, stage_end); 0,0 = everything.
+   * backward: 0 = heads + final norm, 1..L = blocks L-1..0, L+1 = gate logits + token assembly,
+   *           L+2 = patch-embedding weight gradient.  Lets the host cut the backward at gradient-bucket
+   *           boundaries and start the RCCL all-reduce of a finished bucket on a second stream while the
+   *           rest of the backward runs (and add the patch-scorer term to dpe before stage L+2).
+   * forward:  0 = patch embedding, 1 = everything after it (the patch-gating mask is computed in between). */
   int32_t stage_begin, stage_end;
 } uvc_vit_io;
 

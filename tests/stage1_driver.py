@@ -56,11 +56,17 @@ class Stage1Run:
         prune_w_mask(mm, tr.optimizer)
 
     def inject_draws(self, model_draws, e1, e2):
-        """The student consumes its L block-gate draws as one [L,2] tensor (one launch)."""
+        """The student consumes its L block-gate draws as one [L,2] tensor (one launch); the patch-gating
+        draw [B,P] (mode 2) comes first in the reference's order."""
         L = self.cfg.depth
-        if model_draws:
-            stacked = torch.stack([d.reshape(2) for d in model_draws[-L:]]).cuda()
-            self.model.exp_source = lambda shape, t=stacked: t
+        md = list(model_draws)
+        by_shape = {}
+        if self.r["enable_patch_gating"] == 2 and md:
+            pd = md.pop(0).cuda()
+            by_shape[tuple(pd.shape)] = pd
+        if md:
+            by_shape[(L, 2)] = torch.stack([d.reshape(2) for d in md[-L:]]).cuda()
+        self.model.exp_source = lambda shape, t=by_shape: t[tuple(shape)]
         q = [t.cuda() for t in (e1, e2) if t is not None]
         self.minimax.exp_source = lambda shape, q=q: q.pop(0)
 

@@ -35,7 +35,7 @@ def _worker(rank, world, port, depth, nb, out):
             cover[o:o + n] += 1
     assert bool((cover == 1).all()), "bucket plan must tile the flat buffer"
     ends = [p[0] for p in plan]
-    assert ends == sorted(ends) and ends[-1] == depth + 2
+    assert ends == sorted(ends) and ends[-1] == depth + 3
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(off.n_total + n_extra, generator=g)
     flat[off.n_total] = 3.25                      # the dual scalar: identical on every rank

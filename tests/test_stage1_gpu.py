@@ -13,7 +13,7 @@ from stage1_driver import Stage1Run
 pytestmark = pytest.mark.gpu
 
 CORE = ["micro_warmup", "micro_train", "micro_pruned", "micro_clip", "micro_bounds", "micro_softl0", "micro_deit",
-        "tiny8_train", "tiny8_pruned"]
+        "micro_patch1", "micro_patch2", "tiny8_train", "tiny8_pruned"]
 
 
 def close(a, b, rtol, atol, what):

@@ -108,7 +108,13 @@ _SIGNATURES = {
     "uvc_patchify": [VP, VP, I32, I32, I32, I32, I32, VP],
     "uvc_assemble_tokens": [VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, VP],
     "uvc_assemble_tokens_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, I32, I32, F32, VP],
-    "uvc_colsum": [VP, I32, I32, I32, I32, I32, VP, VP, F32, VP, F32, VP],
+    "uvc_colsum": [VP, I32, I32, I32, I32, I32, VP, VP, F32, VP, F32, VP, VP],
+    "uvc_patch_gate_sigmoid": [VP, VP, I32, I32, I32, VP],
+    "uvc_patch_gate_sigmoid_bwd": [VP, VP, VP, I32, I32, F32, VP],
+    "uvc_patch_scores": [VP, VP, VP, VP, I32, I32, VP],
+    "uvc_patch_topk_mask": [VP, VP, VP, VP, VP, I32, I32, I32, F32, VP],
+    "uvc_patch_topk_mask_bwd": [VP, VP, VP, VP, I32, I32, F32, VP],
+    "uvc_add_outer": [VP, VP, VP, I32, I32, I32, I32, VP],
     "uvc_colsum_blocks": [I32],
     "uvc_cast_transpose": [VP, I32, I32, VP, VP, I32, VP],
     "uvc_gate_distrib": [VP, VP, VP, I32, I32, F32, VP],
@@ -117,7 +123,8 @@ _SIGNATURES = {
 
 
 # include/uvc_vit.h (bound in uvc_amd/model_distilled.py next to its ctypes structures)
-VIT_SYMBOLS = ["uvc_vit_layout", "uvc_vit_workspace_bytes", "uvc_vit_update_shadows", "uvc_vit_forward", "uvc_vit_backward"]
+VIT_SYMBOLS = ["uvc_vit_layout", "uvc_vit_workspace_bytes", "uvc_vit_ws_offsets", "uvc_vit_update_shadows", "uvc_vit_forward",
+               "uvc_vit_backward"]
 
 
 def exported_symbols():

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_assemble_bwd_dmask(const float* __restr
 // ---------------------------------------------------------------------------- column sums
 constexpr int CS_ROWS = 256;
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ X, int M, int N, int ldx, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ X, int M, int N, int ldx, float* __restrict__ partial, const float* __restrict__ rw) {
   __shared__ float red[4][64 * VEC];
   const int c0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * VEC, sl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
@@ -101,14 +101,15 @@ __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ X, int M, 
   if (c0 < N) {
     for (int r = r0 + sl; r < r1; r += 4) {
       const T* p = X + (size_t)r * ldx + c0;
+      const float wr = rw ? rw[r] : 1.0f;
       if (VEC == 4) {
-        if (sizeof(T) == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p); s[0] += v[0]; s[1 % VEC] += v[1]; s[2 % VEC] += v[2]; s[3 % VEC] += v[3]; }
+        if (sizeof(T) == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p); s[0] += wr * v[0]; s[1 % VEC] += wr * v[1]; s[2 % VEC] += wr * v[2]; s[3 % VEC] += wr * v[3]; }
         else {
           const u32x2 q = *reinterpret_cast<const u32x2*>(p);
-          s[0] += __uint_as_float(q[0] << 16); s[1 % VEC] += __uint_as_float(q[0] & 0xffff0000u);
-          s[2 % VEC] += __uint_as_float(q[1] << 16); s[3 % VEC] += __uint_as_float(q[1] & 0xffff0000u);
+          s[0] += wr * __uint_as_float(q[0] << 16); s[1 % VEC] += wr * __uint_as_float(q[0] & 0xffff0000u);
+          s[2 % VEC] += wr * __uint_as_float(q[1] << 16); s[3 % VEC] += wr * __uint_as_float(q[1] & 0xffff0000u);
         }
-      } else s[0] += ElemIO<T>::load(p);
+      } else s[0] += wr * ElemIO<T>::load(p);
     }
   }
 #pragma unroll
@@ -196,6 +197,101 @@ __global__ void k_gate_grad(const float* g, const float* d, const float* dots, f
   dg[2 * l + 1] = (beta != 0.f ? beta * dg[2 * l + 1] : 0.f) + g1;
 }
 
+
+// ---------------------------------------------------------------------------- patch gating
+// mode 1 (model_distilled.py:434-444): mask[b,i] = sigmoid(pg[i]) (soft) or [sigmoid >= .5] with token 0 kept (hard)
+__global__ __launch_bounds__(256) void k_patch_sigmoid(const float* __restrict__ pg, float* __restrict__ mask, int B, int P, int hard) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * P) return;
+  const int t = i % P;
+  const float sg = 1.0f / (1.0f + __expf(-pg[t]));
+  mask[i] = hard ? ((sg >= 0.5f || t == 0) ? 1.0f : 0.0f) : sg;
+}
+__global__ __launch_bounds__(256) void k_patch_sigmoid_bwd(const float* __restrict__ pg, const float* __restrict__ dmask,
+                                                           float* __restrict__ dpg, int B, int P, float beta) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= P) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dmask[(size_t)b * P + t];
+  const float sg = 1.0f / (1.0f + __expf(-pg[t]));
+  dpg[t] = (beta != 0.f ? beta * dpg[t] : 0.f) + s * sg * (1.0f - sg);
+}
+// mode 2 scorer: scores[row] = <pe[row,:], w> + bias   (self.gumbel = Linear(D,1), :450)
+__global__ __launch_bounds__(256) void k_patch_scores(const float* __restrict__ pe, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ scores, int rows, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* p = pe + (size_t)row * D;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += p[d] * w[d];
+  s = wave_sum(s);
+  if (lane == 0) scores[row] = s + bias[0];
+}
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__device__ __forceinline__ float block_max256(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+// custom gumbel_softmax(log_softmax(scores), k, tau, hard=True) + token 0 forced to 1 (:36-63,446-456).
+// One block per image, P <= 256.  Outputs the straight-through mask, y_soft and softmax(scores) for backward.
+__global__ __launch_bounds__(256) void k_patch_topk(const float* __restrict__ scores, const float* __restrict__ e, float* __restrict__ mask,
+                                                    float* __restrict__ ysoft, float* __restrict__ psoft, int P, int k, float tau) {
+  __shared__ float sh[4];
+  __shared__ float yv[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const bool ok = t < P;
+  const float s = ok ? scores[(size_t)b * P + t] : -INFINITY;
+  const float m1 = block_max256(s, sh);
+  const float z1 = block_sum256(ok ? __expf(s - m1) : 0.f, sh);
+  const float logp = s - m1 - __logf(z1);
+  const float u = ok ? (logp + (-__logf(e[(size_t)b * P + t]))) / tau : -INFINITY;
+  const float m2 = block_max256(u, sh);
+  const float ex = ok ? __expf(u - m2) : 0.f;
+  const float z2 = block_sum256(ex, sh);
+  const float y = ex / z2;
+  yv[t] = ok ? y : -1.0f;
+  __syncthreads();
+  if (ok) {
+    int rank = 0;                                   // descending order, ties -> lower index first
+    for (int j = 0; j < P; ++j) { const float o = yv[j]; rank += (o > y) || (o == y && j < t); }
+    const float hard = rank < k ? 1.0f : 0.0f;
+    mask[(size_t)b * P + t] = t == 0 ? 1.0f : (hard - y) + y;
+    ysoft[(size_t)b * P + t] = y;
+    psoft[(size_t)b * P + t] = __expf(logp);
+  }
+}
+// backward of the above w.r.t. the scores (straight-through: dmask -> dy, token 0 has no gradient)
+__global__ __launch_bounds__(256) void k_patch_topk_bwd(const float* __restrict__ dmask, const float* __restrict__ ysoft,
+                                                        const float* __restrict__ psoft, float* __restrict__ dscores, int P, float tau) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const bool ok = t < P;
+  const float y = ok ? ysoft[(size_t)b * P + t] : 0.f;
+  const float dy = (ok && t != 0) ? dmask[(size_t)b * P + t] : 0.f;
+  const float ydy = block_sum256(y * dy, sh);
+  const float dlogp = ok ? y * (dy - ydy) / tau : 0.f;
+  const float sdl = block_sum256(dlogp, sh);
+  if (ok) dscores[(size_t)b * P + t] = dlogp - psoft[(size_t)b * P + t] * sdl;
+}
+// X[row, :] += rw[row] * w[:]   (scorer's contribution to d(patch embedding))
+template <typename T>
+__global__ __launch_bounds__(256) void k_add_outer(T* __restrict__ X, const float* __restrict__ rw, const float* __restrict__ w, int rows, int D) {
+  const int64_t total = (int64_t)rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / D), d = (int)(i % D);
+    ElemIO<T>::store(X + i, ElemIO<T>::load(X + i) + rw[r] * w[d]);
+  }
+}
+
 inline int grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -238,7 +334,7 @@ extern "C" int uvc_assemble_tokens_bwd(const float* dtok, const float* pe, const
 extern "C" int uvc_colsum_blocks(int32_t M) { return ceil_div(M, CS_ROWS); }
 
 extern "C" int uvc_colsum(const void* X, int32_t M, int32_t N, int32_t ldx, int32_t dtype, int32_t x_is_f32, float* partial, float* out,
-                          float alpha, const float* alpha_ptr, float beta, void* stream) {
+                          float alpha, const float* alpha_ptr, float beta, const float* row_weight, void* stream) {
   if (!X || !partial || !out || M <= 0 || N <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_colsum: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int nb = ceil_div(M, CS_ROWS);
@@ -246,15 +342,56 @@ extern "C" int uvc_colsum(const void* X, int32_t M, int32_t N, int32_t ldx, int3
   const bool vec = (N % 4 == 0) && (ldx % 4 == 0);
   if (vec) {
     dim3 grid(ceil_div(N, 256), nb);
-    if (f32) k_colsum<float, 4><<<grid, 256, 0, st>>>((const float*)X, M, N, ldx, partial);
-    else k_colsum<bf16_t, 4><<<grid, 256, 0, st>>>((const bf16_t*)X, M, N, ldx, partial);
+    if (f32) k_colsum<float, 4><<<grid, 256, 0, st>>>((const float*)X, M, N, ldx, partial, row_weight);
+    else k_colsum<bf16_t, 4><<<grid, 256, 0, st>>>((const bf16_t*)X, M, N, ldx, partial, row_weight);
   } else {
     dim3 grid(ceil_div(N, 64), nb);
-    if (f32) k_colsum<float, 1><<<grid, 256, 0, st>>>((const float*)X, M, N, ldx, partial);
-    else k_colsum<bf16_t, 1><<<grid, 256, 0, st>>>((const bf16_t*)X, M, N, ldx, partial);
+    if (f32) k_colsum<float, 1><<<grid, 256, 0, st>>>((const float*)X, M, N, ldx, partial, row_weight);
+    else k_colsum<bf16_t, 1><<<grid, 256, 0, st>>>((const bf16_t*)X, M, N, ldx, partial, row_weight);
   }
   UVC_CHECK_LAUNCH();
   k_colsum_reduce<<<ceil_div(N, 64), 256, 0, st>>>(partial, nb, N, out, alpha, alpha_ptr, beta);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_patch_gate_sigmoid(const float* pg, float* mask, int32_t B, int32_t P, int32_t hard, void* stream) {
+  if (!pg || !mask || B <= 0 || P <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_patch_gate_sigmoid: bad argument");
+  k_patch_sigmoid<<<ceil_div(B * P, 256), 256, 0, (hipStream_t)stream>>>(pg, mask, B, P, hard);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+extern "C" int uvc_patch_gate_sigmoid_bwd(const float* pg, const float* dmask, float* dpg, int32_t B, int32_t P, float beta_acc, void* stream) {
+  if (!pg || !dmask || !dpg || B <= 0 || P <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_patch_gate_sigmoid_bwd: bad argument");
+  k_patch_sigmoid_bwd<<<ceil_div(P, 256), 256, 0, (hipStream_t)stream>>>(pg, dmask, dpg, B, P, beta_acc);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+extern "C" int uvc_patch_scores(const float* pe, const float* w, const float* bias, float* scores, int32_t rows, int32_t D, void* stream) {
+  if (!pe || !w || !bias || !scores || rows <= 0 || D <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_patch_scores: bad argument");
+  k_patch_scores<<<ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(pe, w, bias, scores, rows, D);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+extern "C" int uvc_patch_topk_mask(const float* scores, const float* e, float* mask, float* ysoft, float* psoft, int32_t B, int32_t P, int32_t k,
+                                   float tau, void* stream) {
+  if (!scores || !e || !mask || !ysoft || !psoft || B <= 0 || P <= 0 || P > 256 || k < 0 || tau <= 0.f)
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_patch_topk_mask: bad argument (P <= 256, tau > 0)");
+  k_patch_topk<<<B, 256, 0, (hipStream_t)stream>>>(scores, e, mask, ysoft, psoft, P, k, tau);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+extern "C" int uvc_patch_topk_mask_bwd(const float* dmask, const float* ysoft, const float* psoft, float* dscores, int32_t B, int32_t P, float tau,
+                                       void* stream) {
+  if (!dmask || !ysoft || !psoft || !dscores || B <= 0 || P <= 0 || P > 256 || tau <= 0.f) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_patch_topk_mask_bwd: bad argument");
+  k_patch_topk_bwd<<<B, 256, 0, (hipStream_t)stream>>>(dmask, ysoft, psoft, dscores, P, tau);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+extern "C" int uvc_add_outer(void* X, const float* row_weight, const float* w, int32_t rows, int32_t D, int32_t dtype, int32_t x_is_f32, void* stream) {
+  if (!X || !row_weight || !w || rows <= 0 || D <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_add_outer: bad argument");
+  if (dtype == UVC_F32 || x_is_f32) k_add_outer<float><<<grid_for((int64_t)rows * D), 256, 0, (hipStream_t)stream>>>((float*)X, row_weight, w, rows, D);
+  else k_add_outer<bf16_t><<<grid_for((int64_t)rows * D), 256, 0, (hipStream_t)stream>>>((bf16_t*)X, row_weight, w, rows, D);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

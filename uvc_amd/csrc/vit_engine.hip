@@ -130,7 +130,7 @@ int tn(const Ctx& c, const void* A, int a_f32, const void* B, float* C, float* b
   return uvc_gemm_tn(&a, c.st);
 }
 int csum(const Ctx& c, const void* X, int x_f32, float* out, int M, int N, const float* alpha_ptr = nullptr, int ldx = 0) {
-  return uvc_colsum(X, M, N, ldx ? ldx : N, c.d.dtype, x_f32 || c.d.dtype == UVC_F32, c.w.cs_partial, out, 1.0f, alpha_ptr, c.io->accumulate, c.st);
+  return uvc_colsum(X, M, N, ldx ? ldx : N, c.d.dtype, x_f32 || c.d.dtype == UVC_F32, c.w.cs_partial, out, 1.0f, alpha_ptr, c.io->accumulate, nullptr, c.st);
 }
 int ln_fwd(const Ctx& c, const float* x, int64_t pw, int64_t pb, void* y, float* mean, float* rstd, int rows, int rpg, int64_t gs) {
   uvc_ln_args a;
@@ -220,6 +220,19 @@ extern "C" int64_t uvc_vit_workspace_bytes(const uvc_vit_cfg* cfg, int32_t batch
   return carve(dims_of(*cfg, batch), training, nullptr, w);
 }
 
+// byte offsets inside the training workspace of pe [B*P, D] float32 and dpe [B*P, D] T (patch-gating hooks)
+extern "C" int uvc_vit_ws_offsets(const uvc_vit_cfg* cfg, int32_t batch, int32_t training, int64_t* pe_off, int64_t* dpe_off) {
+  TRY(check_cfg(cfg));
+  if (batch <= 0 || !pe_off || !dpe_off) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_ws_offsets: bad argument");
+  Work w;
+  memset(&w, 0, sizeof(w));
+  char* base = (char*)256;            // any non-null base: only differences are used
+  carve(dims_of(*cfg, batch), training, base, w);
+  *pe_off = (char*)w.pe - base;
+  *dpe_off = training ? (char*)w.dpe - base : -1;
+  return UVC_OK;
+}
+
 extern "C" int uvc_vit_update_shadows(const uvc_vit_cfg* cfg, const float* params, void* shadow, void* stream) {
   TRY(check_cfg(cfg));
   if (!params || !shadow) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_update_shadows: null pointer");
@@ -252,9 +265,15 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
   const uvc_vit_offsets& o = c.off;
   Work& w = c.w;
   const int rows_p = d.B * d.np;
-  // patch embedding (PatchEmbed.forward :145-153) + token assembly (:434-471)
-  TRY(uvc_patchify(io->x, w.patches, d.B, d.C, d.S, d.P, d.dtype, stream));
-  TRY(nt(c, w.patches, 0, wmat(c, o.patch_w, c.soff.patch_w), w.pe, 1, rows_p, d.D, d.K0, UVC_EPI_BIAS, P + o.patch_b));
+  // forward stages: 0 = patch embedding (PatchEmbed.forward :145-153), 1 = token assembly (:434-471) + blocks + heads.
+  // The cut lets the host compute the patch-gating mask from the patch embedding in between.
+  const int fsb = io->stage_begin, fse = (io->stage_begin == 0 && io->stage_end == 0) ? 2 : io->stage_end;
+  if (fsb < 0 || fse > 2 || fsb >= fse) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_forward: bad stage range");
+  if (fsb == 0) {
+    TRY(uvc_patchify(io->x, w.patches, d.B, d.C, d.S, d.P, d.dtype, stream));
+    TRY(nt(c, w.patches, 0, wmat(c, o.patch_w, c.soff.patch_w), w.pe, 1, rows_p, d.D, d.K0, UVC_EPI_BIAS, P + o.patch_b));
+  }
+  if (fse < 2) return UVC_OK;
   float* x0 = w.blk[0].x;
   TRY(uvc_assemble_tokens(w.pe, P + o.cls_token, d.ntok == 2 ? P + o.dist_token : nullptr, P + o.pos_embed, io->patch_mask, x0, d.B, d.np,
                           d.D, d.ntok, stream));
@@ -304,8 +323,8 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   Work& w = c.w;
   hipStream_t hs = (hipStream_t)stream;
   const int rh = d.B * d.ntok;
-  const int sb = io->stage_begin, se = (io->stage_begin == 0 && io->stage_end == 0) ? d.L + 2 : io->stage_end;
-  if (sb < 0 || se > d.L + 2 || sb >= se) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_backward: bad stage range");
+  const int sb = io->stage_begin, se = (io->stage_begin == 0 && io->stage_end == 0) ? d.L + 3 : io->stage_end;
+  if (sb < 0 || se > d.L + 3 || sb >= se) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_backward: bad stage range");
   if (sb == 0) {
   // heads: dhc = dlogits . W ; dW = dlogits^T . hc ; db = colsum(dlogits)
   TRY(nt(c, io->d_logits, 1, sh(c, so.head_wt), w.dhc, 0, d.B, d.D, d.NC, UVC_EPI_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
@@ -344,13 +363,16 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     // gA <- dL/dx_l = LN1'(dH) + gB + d0*gA ; dots: <new gA, x_l>, <old gA, x_l>
     TRY(ln_bwd(c, w.dH, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0, w.dotsraw + 2 * l, d.M, 1, d.D));
   }
-  if (se < d.L + 2) return UVC_OK;
-  // gate logits (block_skip_gating) gradient
-  if (io->gate_d && io->gate_mode != 0)
-    TRY(uvc_gate_grad(P + o.gate, io->gate_d, w.dotsraw, G + o.gate, d.L, io->gate_mode, io->gate_eps, io->accumulate, stream));
-  // token assembly + patch embedding
-  TRY(uvc_assemble_tokens_bwd(w.gA, w.pe, io->patch_mask, w.dpe, G + o.pos_embed, G + o.cls_token, d.ntok == 2 ? G + o.dist_token : nullptr,
-                              io->d_patch_mask, d.B, d.np, d.D, d.ntok, d.dtype, 0, io->accumulate, stream));
+  if (sb <= d.L + 1 && se > d.L + 1) {
+    // gate logits (block_skip_gating) gradient
+    if (io->gate_d && io->gate_mode != 0)
+      TRY(uvc_gate_grad(P + o.gate, io->gate_d, w.dotsraw, G + o.gate, d.L, io->gate_mode, io->gate_eps, io->accumulate, stream));
+    // token assembly
+    TRY(uvc_assemble_tokens_bwd(w.gA, w.pe, io->patch_mask, w.dpe, G + o.pos_embed, G + o.cls_token, d.ntok == 2 ? G + o.dist_token : nullptr,
+                                io->d_patch_mask, d.B, d.np, d.D, d.ntok, d.dtype, 0, io->accumulate, stream));
+  }
+  if (se < d.L + 3) return UVC_OK;
+  // patch embedding (weight gradient only: the image needs no gradient)
   TRY(tn(c, w.dpe, 0, w.patches, G + o.patch_w, G + o.patch_b, d.B * d.np, d.D, d.K0));
   return UVC_OK;
 }

@@ -65,7 +65,7 @@ class FlatGradReducer:
 
 def bucket_plan(off, depth: int, n_extra: int, num_buckets: int = 4):
     """Backward stage boundaries and the flat-buffer ranges that are final after each of them.
-    Stages: 0 = heads + final norm, 1..L = blocks L-1..0, L+1 = embedding (uvc_vit.h).  The flat
+    Stages: 0 = heads + final norm, 1..L = blocks L-1..0, L+1/L+2 = embedding (uvc_vit.h).  The flat
     layout is in forward order, so a bucket is a contiguous [block k .. previous bucket) range."""
     num_buckets = max(1, min(num_buckets, depth))
     per = -(-depth // num_buckets)
@@ -82,7 +82,7 @@ def bucket_plan(off, depth: int, n_extra: int, num_buckets: int = 4):
         hi = lo
         l = lo_blk
     # tail: blocks [0, l) + embedding + the small conditionally-active tensors (+ the dual scalar slot)
-    plan.append((depth + 2, [(0, hi), (off.n_main, off.n_total - off.n_main + n_extra)]))
+    plan.append((depth + 3, [(0, hi), (off.n_main, off.n_total - off.n_main + n_extra)]))
     return plan
 
 

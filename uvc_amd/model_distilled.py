@@ -118,22 +118,20 @@ class Block(nn.Module):
 
 
 class _VitFunction(torch.autograd.Function):
-    """One autograd node for the whole model.  Gradients of the parameters are written straight into
-    the flat gradient buffer (the ``.grad`` views); only the patch-mask gradient flows through autograd."""
+    """One autograd node for the whole model.  Gradients of ALL parameters are written straight into the
+    flat gradient buffer (the ``.grad`` views) by the HIP backward; nothing flows back through autograd."""
 
     @staticmethod
-    def forward(ctx, model, x, anchor, patch_mask):
-        logits, logits_dist = model._run_forward(x, patch_mask, training=True)
+    def forward(ctx, model, x, anchor, tau, ratio):
+        logits, logits_dist = model._run_forward(x, tau, ratio, training=True)
         ctx.model = model
-        ctx.has_mask = patch_mask is not None
         ctx.two = logits_dist is not None
         return (logits, logits_dist) if ctx.two else logits
 
     @staticmethod
     def backward(ctx, *grads):
-        model = ctx.model
-        dmask = model._run_backward(grads[0], grads[1] if ctx.two else None, ctx.has_mask)
-        return None, None, None, dmask
+        ctx.model._run_backward(grads[0], grads[1] if ctx.two else None)
+        return None, None, None, None, None
 
 
 class DistilledVisionTransformer(nn.Module):
@@ -327,7 +325,25 @@ class DistilledVisionTransformer(nn.Module):
         io.accumulate = 1.0 if self.grad_accumulate else 0.0
         return io
 
-    def _run_forward(self, x, patch_mask, training):
+    def _ws_view(self, B, training, which):
+        """float32 view of pe [B*P, D] / T view of dpe inside the workspace (patch-gating hooks)."""
+        lib = _bind()
+        if not hasattr(lib, "_wsoff_bound"):
+            lib.uvc_vit_ws_offsets.argtypes = [C.POINTER(uvc_vit_cfg), C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+            lib.uvc_vit_ws_offsets.restype = C.c_int
+            lib._wsoff_bound = True
+        pe_off, dpe_off = C.c_int64(), C.c_int64()
+        L.check(lib.uvc_vit_ws_offsets(C.byref(self._cfg), B, int(training), C.byref(pe_off), C.byref(dpe_off)), "uvc_vit_ws_offsets")
+        ws = self._workspace(B, training)
+        cfg = self._cfg
+        rows = B * (cfg.img_size // cfg.patch_size) ** 2
+        if which == "pe":
+            return ws[pe_off.value:pe_off.value + rows * cfg.embed_dim * 4].view(torch.float32).view(rows, cfg.embed_dim)
+        tdt = torch.float32 if self.precision == "fp32" else torch.bfloat16
+        nb = rows * cfg.embed_dim * (4 if self.precision == "fp32" else 2)
+        return ws[dpe_off.value:dpe_off.value + nb].view(tdt).view(rows, cfg.embed_dim)
+
+    def _run_forward(self, x, tau, ratio, training):
         L.require_cuda(x)
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.contiguous().float()
@@ -350,12 +366,11 @@ class DistilledVisionTransformer(nn.Module):
         if self.enable_block_gating:                                   # model_distilled.py:479-494
             gate_d = torch.empty(cfg.depth, 2, device=dev)
             if self.enable_warmup:
-                mode, e = 0, None
+                mode = 0
             elif self.use_gumbel == 1:
-                mode, e = (3 if self.gumbel_hard else 1), self.exp_source((cfg.depth, 2))
+                mode = 3 if self.gumbel_hard else 1
             else:
-                mode, e = 2, None
-            ops.gate_distrib(self.block_skip_gating.data, e, gate_d, cfg.depth, mode, float(self.eps))
+                mode = 2
         else:                                                          # :496-500 hard skip by logit order
             if self._run_block_host is None or not self.frozen_weights:
                 g = self.block_skip_gating.detach().cpu()
@@ -364,19 +379,64 @@ class DistilledVisionTransformer(nn.Module):
             if training and not all(run_block):
                 raise NotImplementedError("hard block skipping inside a training forward is the Stage-2 path")
         io.x, io.logits, io.logits_dist = L.ptr(x), L.ptr(logits), L.ptr(logits_dist)
-        io.gate_d = L.ptr(gate_d)
         io.run_block = run_block if run_block is not None else None
-        io.patch_mask = L.ptr(patch_mask)
+        # ---- patch gating (model_distilled.py:434-456): the mask needs the patch embedding, so the forward is cut there
+        P = (cfg.img_size // cfg.patch_size) ** 2
+        mode1 = self.enable_patch_gating == 1
+        mode2 = tau > 0
+        if mode1 and mode2:
+            raise NotImplementedError("patch gating modes 1 and 2 together (never produced by the reference driver)")
+        patch = None
+        if mode1 or mode2:
+            io.stage_begin, io.stage_end = 0, 1
+            L.check(lib.uvc_vit_forward(C.byref(cfg), C.byref(io), stream), "uvc_vit_forward")
+            mask = torch.empty(B, P, device=dev)
+            if mode1:
+                ops.patch_gate_sigmoid(self.patch_gating.data, mask, B, P, self.patch_hard)
+                patch = dict(mode=1, mask=mask)
+            else:
+                pe = self._ws_view(B, training, "pe")
+                scores, ys, ps = (torch.empty(B, P, device=dev) for _ in range(3))
+                ops.patch_scores(pe, self.gumbel.weight.data, self.gumbel.bias.data, scores, B * P, cfg.embed_dim)
+                ops.patch_topk_mask(scores, self.exp_source((B, P)), mask, ys, ps, B, P, int(ratio * P), float(tau))
+                patch = dict(mode=2, mask=mask, ysoft=ys, psoft=ps, tau=float(tau))
+            io.patch_mask = L.ptr(mask)
+            io.stage_begin, io.stage_end = 1, 2
+        if gate_d is not None:     # drawn after the patch-gating noise, in the reference's RNG order (:446-485)
+            e = self.exp_source((cfg.depth, 2)) if mode in (1, 3) else None
+            ops.gate_distrib(self.block_skip_gating.data, e, gate_d, cfg.depth, mode, float(self.eps))
+        io.gate_d = L.ptr(gate_d)
         L.check(lib.uvc_vit_forward(C.byref(cfg), C.byref(io), stream), "uvc_vit_forward")
-        self._last = dict(x=x, gate_d=gate_d, patch_mask=patch_mask, B=B) if training else None
+        self._last = dict(x=x, gate_d=gate_d, patch=patch, B=B) if training else None
         self.last_distrib = gate_d
+        self.last_patch_mask = patch["mask"] if patch else None
         return logits, logits_dist
 
-    def _run_backward(self, d_logits, d_logits_dist, want_dmask):
+    def _patch_backward(self, st, dmask):
+        """Gradients of the patch-gating parameters from d(mask) (model_distilled.py:434-456)."""
+        cfg = self._cfg
+        B, pt = st["B"], st["patch"]
+        P = (cfg.img_size // cfg.patch_size) ** 2
+        beta = 1.0 if self.grad_accumulate else 0.0
+        if pt["mode"] == 1:
+            ops.patch_gate_sigmoid_bwd(self.patch_gating.data, dmask, self.patch_gating.grad, B, P, beta)
+            return
+        dev = self._flat.device
+        ds = torch.empty(B, P, device=dev)
+        ops.patch_topk_mask_bwd(dmask, pt["ysoft"], pt["psoft"], ds, B, P, pt["tau"])
+        pe = self._ws_view(B, True, "pe")
+        dt = ops.UVC_F32 if self.precision == "fp32" else ops.UVC_BF16
+        part = torch.empty(ops.colsum_blocks(B * P) * cfg.embed_dim, device=dev)
+        ops.colsum(pe, part, self.gumbel.weight.grad.view(-1), dt, row_weight=ds.view(-1), beta=beta)       # dW = sum ds * pe
+        ops.colsum(ds.view(-1, 1), part, self.gumbel.bias.grad.view(-1), dt, beta=beta)                      # db = sum ds
+        ops.add_outer(self._ws_view(B, True, "dpe"), ds.view(-1), self.gumbel.weight.data.view(-1), B * P, cfg.embed_dim, dt)
+
+    def _run_backward(self, d_logits, d_logits_dist):
         st = self._last
         if st is None:
             raise RuntimeError("backward without a training forward")
-        self.grad_views()
+        patch = st["patch"]
+        self.grad_views(patch_mode2=bool(patch and patch["mode"] == 2))
         io = self._io(st["B"], True)
         d_logits = d_logits.contiguous()
         io.d_logits = L.ptr(d_logits)
@@ -384,26 +444,31 @@ class DistilledVisionTransformer(nn.Module):
             d_logits_dist = d_logits_dist.contiguous()
             io.d_logits_dist = L.ptr(d_logits_dist)
         io.gate_d = L.ptr(st["gate_d"])
-        io.patch_mask = L.ptr(st["patch_mask"])
         dmask = None
-        if want_dmask:
-            dmask = torch.empty_like(st["patch_mask"])
+        if patch:
+            io.patch_mask = L.ptr(patch["mask"])
+            dmask = torch.empty_like(patch["mask"])
             io.d_patch_mask = L.ptr(dmask)
-        ddp = self._ddp
-        if ddp is None or ddp.world == 1:
-            L.check(_bind().uvc_vit_backward(C.byref(self._cfg), C.byref(io), L.cur_stream()), "uvc_vit_backward")
-            return dmask
+        ddp = self._ddp if (self._ddp is not None and self._ddp.world > 1) else None
+        depth = self._cfg.depth
+        cuts = set(ddp.stage_ends) if ddp else {depth + 3}
+        if patch:
+            cuts.add(depth + 2)            # after token assembly: d(mask) is known, dpe not yet consumed
         begin = 0
-        for i, end in enumerate(ddp.stage_ends):                       # cut at gradient-bucket boundaries
+        for end in sorted(cuts):
             io.stage_begin, io.stage_end = begin, end
             L.check(_bind().uvc_vit_backward(C.byref(self._cfg), C.byref(io), L.cur_stream()), "uvc_vit_backward")
-            if i == len(ddp.stage_ends) - 1:
-                ddp.pack_dual()
-            ddp.reducer.launch(i)                                       # RCCL on the side stream, overlaps the next stages
+            if patch and end == depth + 2:
+                self._patch_backward(st, dmask)
+            if ddp and end in ddp.stage_ends:
+                i = ddp.stage_ends.index(end)
+                if i == len(ddp.stage_ends) - 1:
+                    ddp.pack_dual()
+                ddp.reducer.launch(i)      # RCCL on the side stream, overlaps the remaining stages
             begin = end
-        ddp.reducer.finish()
-        ddp.unpack_dual()
-        return dmask
+        if ddp:
+            ddp.reducer.finish()
+            ddp.unpack_dual()
 
     # -- reference API ----------------------------------------------------------------------------------
     def macs(self, B):
@@ -415,21 +480,14 @@ class DistilledVisionTransformer(nn.Module):
         blk = [B * 3 * D * N * D, N * B * H * N * 64, N * B * H * N * 64, B * N * D * D, F * B * N * D, D * B * N * F]
         return embed, [list(blk) for _ in range(c.depth)]
 
-    def _patch_mask(self, B, tau, ratio):
-        if self.enable_patch_gating == 1 or tau > 0:
-            raise NotImplementedError("patch gating (modes 1/2) is not wired into the HIP engine yet")
-        return None
-
     def forward(self, x, tau=-1, number=0.9):
         if self.enable_jumping:
             raise NotImplementedError("enable_jumping is off on the UVC hot path")
-        B = x.shape[0]
-        macs = self.macs(B)
-        patch_mask = self._patch_mask(B, tau, number)
+        macs = self.macs(x.shape[0])
         if self.training and torch.is_grad_enabled():
-            out = _VitFunction.apply(self, x, self.cls_token, patch_mask)
+            out = _VitFunction.apply(self, x, self.cls_token, tau, number)
             return (out if self.num_tokens == 2 else (out, out)), macs       # x_dist = x without the dist token (:523-524)
-        o, od = self._run_forward(x, patch_mask, training=False)
+        o, od = self._run_forward(x, tau, number, training=False)
         if od is None:
             od = o
         if self.training:

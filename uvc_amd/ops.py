@@ -181,12 +181,45 @@ def colsum_blocks(M) -> int:
     return int(L.lib().uvc_colsum_blocks(M))
 
 
-def colsum(X, partial, out, dtype, *, M=None, N=None, ldx=None, alpha=1.0, alpha_ptr=None, beta=0.0):
-    _chk(X, partial, out, alpha_ptr)
+def colsum(X, partial, out, dtype, *, M=None, N=None, ldx=None, alpha=1.0, alpha_ptr=None, beta=0.0, row_weight=None):
+    _chk(X, partial, out, alpha_ptr, row_weight)
     M = M if M is not None else X.shape[0]
     N = N if N is not None else X.shape[1]
     L.check(L.lib().uvc_colsum(L.ptr(X), M, N, ldx if ldx is not None else N, dtype, _is_f32(X), L.ptr(partial), L.ptr(out),
-                               alpha, L.ptr(alpha_ptr), beta, L.cur_stream()), "uvc_colsum")
+                               alpha, L.ptr(alpha_ptr), beta, L.ptr(row_weight), L.cur_stream()), "uvc_colsum")
+
+
+def patch_gate_sigmoid(pg, mask, B, P, hard):
+    _chk(pg, mask)
+    L.check(L.lib().uvc_patch_gate_sigmoid(L.ptr(pg), L.ptr(mask), B, P, int(bool(hard)), L.cur_stream()), "uvc_patch_gate_sigmoid")
+
+
+def patch_gate_sigmoid_bwd(pg, dmask, dpg, B, P, beta_acc=0.0):
+    _chk(pg, dmask, dpg)
+    L.check(L.lib().uvc_patch_gate_sigmoid_bwd(L.ptr(pg), L.ptr(dmask), L.ptr(dpg), B, P, beta_acc, L.cur_stream()),
+            "uvc_patch_gate_sigmoid_bwd")
+
+
+def patch_scores(pe, w, bias, scores, rows, D):
+    _chk(pe, w, bias, scores)
+    L.check(L.lib().uvc_patch_scores(L.ptr(pe), L.ptr(w), L.ptr(bias), L.ptr(scores), rows, D, L.cur_stream()), "uvc_patch_scores")
+
+
+def patch_topk_mask(scores, e, mask, ysoft, psoft, B, P, k, tau):
+    _chk(scores, e, mask, ysoft, psoft)
+    L.check(L.lib().uvc_patch_topk_mask(L.ptr(scores), L.ptr(e), L.ptr(mask), L.ptr(ysoft), L.ptr(psoft), B, P, k, tau,
+                                        L.cur_stream()), "uvc_patch_topk_mask")
+
+
+def patch_topk_mask_bwd(dmask, ysoft, psoft, dscores, B, P, tau):
+    _chk(dmask, ysoft, psoft, dscores)
+    L.check(L.lib().uvc_patch_topk_mask_bwd(L.ptr(dmask), L.ptr(ysoft), L.ptr(psoft), L.ptr(dscores), B, P, tau, L.cur_stream()),
+            "uvc_patch_topk_mask_bwd")
+
+
+def add_outer(X, row_weight, w, rows, D, dtype):
+    _chk(X, row_weight, w)
+    L.check(L.lib().uvc_add_outer(L.ptr(X), L.ptr(row_weight), L.ptr(w), rows, D, dtype, _is_f32(X), L.cur_stream()), "uvc_add_outer")
 
 
 def cast_transpose(W, R, Cc, w_cast, wt, dtype):

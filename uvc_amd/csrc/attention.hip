@@ -73,15 +73,55 @@ template <typename T> struct Geom {
   static constexpr int TPS = Mma<T>::KSTEP / 16;             // 16-row tiles consumed per "pair" step (2 bf16, 1 f32)
 };
 
-// stage `rows` rows of 64 T (row stride ld_g elements) into LDS rows of ROWB bytes; rows >= nvalid zero
+// stage `rows` rows of 64 T (row stride ld_g elements) into LDS rows of ROWB bytes; rows >= nvalid zero.
+// All global loads of a batch are issued before the first LDS write so their latencies overlap
+// (a load->store loop exposes one HBM round trip per iteration: 7 trips per matrix at N = 197).
 template <typename T>
 __device__ __forceinline__ void stage_rows(char* lds, const T* g, size_t ld_g, int nvalid, int nrows_pad) {
   constexpr int CPR = HD / Mma<T>::CH;                        // chunks per row
+  constexpr int BATCH = 8;
   const u32x4 z = {0u, 0u, 0u, 0u};
-  for (int id = threadIdx.x; id < nrows_pad * CPR; id += blockDim.x) {
-    const int row = id / CPR, c = id % CPR;
-    const u32x4 v = row < nvalid ? *reinterpret_cast<const u32x4*>(g + (size_t)row * ld_g + c * Mma<T>::CH) : z;
-    *reinterpret_cast<u32x4*>(lds + row * Geom<T>::ROWB + c * 16) = v;
+  const int total = nrows_pad * CPR;
+  for (int base = 0; base < total; base += BATCH * (int)blockDim.x) {
+    u32x4 v[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int id = base + i * (int)blockDim.x + (int)threadIdx.x;
+      const int row = id / CPR, c = id % CPR;
+      v[i] = (id < total && row < nvalid) ? *reinterpret_cast<const u32x4*>(g + (size_t)row * ld_g + c * Mma<T>::CH) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int id = base + i * (int)blockDim.x + (int)threadIdx.x;
+      if (id < total) *reinterpret_cast<u32x4*>(lds + (id / CPR) * Geom<T>::ROWB + (id % CPR) * 16) = v[i];
+    }
+  }
+}
+// two matrices at once (K and V / Q and dO): twice the bytes in flight per thread
+template <typename T>
+__device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, size_t ld0, char* lds1, const T* g1, size_t ld1, int nvalid, int nrows_pad) {
+  constexpr int CPR = HD / Mma<T>::CH;
+  constexpr int BATCH = 8;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  const int total = nrows_pad * CPR;
+  for (int base = 0; base < total; base += BATCH * (int)blockDim.x) {
+    u32x4 v0[BATCH], v1[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int id = base + i * (int)blockDim.x + (int)threadIdx.x;
+      const int row = id / CPR, c = id % CPR;
+      const bool ok = id < total && row < nvalid;
+      v0[i] = ok ? *reinterpret_cast<const u32x4*>(g0 + (size_t)row * ld0 + c * Mma<T>::CH) : z;
+      v1[i] = ok ? *reinterpret_cast<const u32x4*>(g1 + (size_t)row * ld1 + c * Mma<T>::CH) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int id = base + i * (int)blockDim.x + (int)threadIdx.x;
+      if (id < total) {
+        *reinterpret_cast<u32x4*>(lds0 + (id / CPR) * Geom<T>::ROWB + (id % CPR) * 16) = v0[i];
+        *reinterpret_cast<u32x4*>(lds1 + (id / CPR) * Geom<T>::ROWB + (id % CPR) * 16) = v1[i];
+      }
+    }
   }
 }
 
@@ -151,8 +191,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
   const T* kb = qb + a.H * HD;
   const T* vb = qb + 2 * a.H * HD;
-  stage_rows<T>(sK, kb, ldq, a.N, NP);
-  stage_rows<T>(sV, vb, ldq, a.N, NP);
+  stage_rows2<T>(sK, kb, ldq, sV, vb, ldq, a.N, NP);
   __syncthreads();
   T* ob = reinterpret_cast<T*>(a.o) + (size_t)b * a.N * a.H * HD + h * HD;
   const int nqt = (a.N + 15) / 16;
@@ -167,21 +206,23 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < G::KS; ++ks) c = MM::mma(row_frag_lds<T>(sK, t * 16 + li, ks * 4 + g), qf[ks], c);
+      if (t * 16 + 16 > a.N) {                       // only the last tile(s) hold padded keys (wave-uniform branch)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = t * 16 + g * 4 + e;
-        c[e] = key < a.N ? c[e] * a.scale : -INFINITY;
-        mx = fmaxf(mx, c[e]);
+        for (int e = 0; e < 4; ++e) if (t * 16 + g * 4 + e >= a.N) c[e] = -INFINITY;
       }
+      mx = fmaxf(mx, fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
       st[t] = c;
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // p = exp(scale*(s - max)) = exp2(s*c2 - max*c2): one FMA + one v_exp_f32 per score (scale > 0)
+    const float c2 = a.scale * 1.44269504088896340736f;
+    const float mb = mx * c2;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < NT16; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float p = __expf(st[t][e] - mx); st[t][e] = p; sum += p; }
+      for (int e = 0; e < 4; ++e) { const float p = __builtin_amdgcn_exp2f(st[t][e] * c2 - mb); st[t][e] = p; sum += p; }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     f32x4 ot[4];
@@ -203,7 +244,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
         for (int e = 0; e < 4; ++e) v[e] *= inv;
         Store4<T>::st(ob + (size_t)q * a.H * HD + dt * 16 + g * 4, v);
       }
-      if (g == 0 && a.lse) a.lse[((size_t)b * a.H + h) * a.N + q] = mx + __logf(sum);
+      if (g == 0 && a.lse) a.lse[((size_t)b * a.H + h) * a.N + q] = mx * a.scale + __logf(sum);
     }
   }
 }
@@ -227,8 +268,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
   const T* ob = reinterpret_cast<const T*>(a.o) + (size_t)b * a.N * ldo + h * HD;
   const T* dob = reinterpret_cast<const T*>(a.dout) + (size_t)b * a.N * ldo + h * HD;
   T* dqb = reinterpret_cast<T*>(a.dqkv) + (size_t)b * a.N * ldq + h * HD;
-  stage_rows<T>(sK, kb, ldq, a.N, NP);
-  stage_rows<T>(sV, vb, ldq, a.N, NP);
+  stage_rows2<T>(sK, kb, ldq, sV, vb, ldq, a.N, NP);
   __syncthreads();
   const int nqt = (a.N + 15) / 16;
   for (int qt = w; qt < nqt; qt += 4) {
@@ -243,7 +283,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
     }
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
-    const float lse = q < a.N ? a.lse[((size_t)b * a.H + h) * a.N + q] : 0.f;
+    const float c2 = a.scale * 1.44269504088896340736f;
+    const float lse2 = (q < a.N ? a.lse[((size_t)b * a.H + h) * a.N + q] : 0.f) * 1.44269504088896340736f;
     if (q < a.N && g == 0) a.delta[((size_t)b * a.H + h) * a.N + q] = dl;
     f32x4 dq[4];
 #pragma unroll
@@ -262,9 +303,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int key = t * 16 + g * 4 + e;
-          const float p = key < a.N ? __expf(c[e] * a.scale - lse) : 0.f;
-          ds[u][e] = p * (dp[e] - dl) * a.scale;
+          float p = __builtin_amdgcn_exp2f(c[e] * c2 - lse2);
+          if (t * 16 + 16 > a.N && t * 16 + g * 4 + e >= a.N) p = 0.f;
+          ds[u][e] = p * ((dp[e] - dl) * a.scale);
         }
       }
       const typename MM::Frag dsf = MM::pack(ds[0], ds[G::TPS - 1]);
@@ -299,12 +340,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
   const T* dob = reinterpret_cast<const T*>(a.dout) + (size_t)b * a.N * ldo + h * HD;
   T* dkb = reinterpret_cast<T*>(a.dqkv) + (size_t)b * a.N * ldq + (a.H + h) * HD;
   T* dvb = dkb + a.H * HD;
-  stage_rows<T>(sQ, qb, ldq, a.N, NP);
-  stage_rows<T>(sDO, dob, ldo, a.N, NP);
-  for (int i = threadIdx.x; i < NP; i += blockDim.x) {
-    sLse[i] = i < a.N ? a.lse[((size_t)b * a.H + h) * a.N + i] : 0.f;
+  stage_rows2<T>(sQ, qb, ldq, sDO, dob, ldo, a.N, NP);
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) {      // lse pre-multiplied by log2(e); +inf on padded queries -> p = 0
+    sLse[i] = i < a.N ? a.lse[((size_t)b * a.H + h) * a.N + i] * 1.44269504088896340736f : INFINITY;
     sDel[i] = i < a.N ? a.delta[((size_t)b * a.H + h) * a.N + i] : 0.f;
   }
+  const float c2 = a.scale * 1.44269504088896340736f;
   __syncthreads();
   const int nkt = (a.N + 15) / 16;
   for (int kt = w; kt < nkt; kt += 4) {
@@ -330,12 +371,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
           c = MM::mma(row_frag_lds<T>(sQ, t * 16 + li, ks * 4 + g), kf[ks], c);
           dp = MM::mma(row_frag_lds<T>(sDO, t * 16 + li, ks * 4 + g), vf[ks], dp);
         }
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + t * 16 + g * 4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + t * 16 + g * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int q = t * 16 + g * 4 + e;
-          const float p = q < a.N ? __expf(c[e] * a.scale - sLse[q]) : 0.f;
+          const float p = __builtin_amdgcn_exp2f(c[e] * c2 - l4[e]);
           pp[u][e] = p;
-          ds[u][e] = p * (dp[e] - sDel[q]) * a.scale;
+          ds[u][e] = p * ((dp[e] - d4[e]) * a.scale);
         }
       }
       const typename MM::Frag pf = MM::pack(pp[0], pp[G::TPS - 1]);

@@ -29,15 +29,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define LDS_PTR(T) __attribute__((address_space(3))) T*
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN preserved (quiet)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// float32 -> bfloat16, round-to-nearest-even: the casts lower to v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> struct ElemIO;

@@ -44,6 +44,7 @@ typedef struct uvc_gemm_nt_args {
   float alpha;
   int32_t M, N, K, lda, ldb, ldc, ldr, ldaux;
   int32_t dtype, a_is_f32, c_is_f32, epilogue;
+  int32_t force_generic;  /* tests/tuning: 1 = skip the weights-stationary streaming kernel */
 } uvc_gemm_nt_args;
 int uvc_gemm_nt(const uvc_gemm_nt_args* args, void* stream);
 

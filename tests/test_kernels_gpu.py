@@ -78,6 +78,37 @@ def test_gemm_nt_f32_source_and_epilogues(dtype):
     torch.testing.assert_close(Cd.double(), 0.6 * (Aeff.double() @ Bt.double().t()) * x.grad, **tol(dtype))
 
 
+@pytest.mark.parametrize("K,N", [(192, 192), (192, 576), (192, 768), (128, 128), (128, 512)])
+def test_gemm_nt_streaming_kernel_matches_generic(K, N):
+    """The weights-stationary streaming kernel (M >= 4096, K in {128,192}, N % 64 == 0) must agree with the
+    generic tiled kernel bit-for-bit up to fp32 summation order, on every epilogue, incl. a ragged last M tile."""
+    from uvc_amd import ops
+    M = 4096 + 37
+    A32, W = rnd(M, K, seed=81), rnd(N, K, seed=82, scale=0.05).to(torch.bfloat16)
+    A = A32.to(torch.bfloat16)
+    bias, R, R2 = rnd(N, seed=83), rnd(M, N, seed=84), rnd(M, N, seed=85)
+    aux = rnd(M, N, seed=86).to(torch.bfloat16)
+    gate = torch.tensor([0.25, 0.75], device=dev())
+    alpha = torch.tensor([0.6], device=dev())
+    ref = A.double() @ W.double().t()
+    cases = [
+        (A, torch.bfloat16, dict(epilogue=ops.EPI_BIAS, bias=bias)),
+        (A, torch.float32, dict(epilogue=ops.EPI_BIAS_RESID, bias=bias, R=R)),
+        (A, torch.float32, dict(epilogue=ops.EPI_BIAS_RESID_GATE, bias=bias, R=R, R2=R2, gate=gate)),
+        (A32, torch.bfloat16, dict(epilogue=ops.EPI_DGELU, aux=aux, alpha_ptr=alpha)),
+        (A32, torch.bfloat16, dict(epilogue=ops.EPI_NONE)),
+    ]
+    for Ain, cdt, kw in cases:
+        C1, C2 = torch.empty(M, N, device=dev(), dtype=cdt), torch.empty(M, N, device=dev(), dtype=cdt)
+        ops.gemm_nt(Ain, W, C1, dtype=BF16, **kw)
+        ops.gemm_nt(Ain, W, C2, dtype=BF16, force_generic=True, **kw)
+        torch.testing.assert_close(C1.float(), C2.float(), rtol=1e-2 if cdt == torch.bfloat16 else 1e-5, atol=1e-2 if cdt == torch.bfloat16 else 1e-4)
+    Ca, Cu = torch.empty(M, N, device=dev(), dtype=torch.bfloat16), torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(A, W, Ca, dtype=BF16, epilogue=ops.EPI_BIAS_GELU, bias=bias, C2=Cu)
+    torch.testing.assert_close(Ca.double(), ref + bias.double(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(Cu.double(), F.gelu(ref + bias.double()), rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("M,N1,N2", [(1576, 576, 192), (403, 192, 768), (64, 1000, 192), (5000, 128, 128), (40, 8, 16)])
 def test_gemm_tn(dtype, M, N1, N2):

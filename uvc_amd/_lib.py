@@ -43,7 +43,7 @@ class uvc_gemm_nt_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("A", "B", "C", "C2", "bias", "R", "R2", "aux", "gate", "alpha_ptr")] + \
                [("alpha", C.c_float)] + \
                [(n, C.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldr", "ldaux", "dtype", "a_is_f32",
-                                         "c_is_f32", "epilogue")]
+                                         "c_is_f32", "epilogue", "force_generic")]
 
 
 class uvc_gemm_tn_args(C.Structure):

@@ -286,6 +286,205 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
   }
 }
 
+// ================================================================================================
+//                     NT, weights-stationary / activation-streaming (bf16, K <= 192)
+// ================================================================================================
+// The DeiT GEMMs are skinny: M = B*197 rows (1e5) against K, N of a few hundred, i.e. HBM-bound
+// streaming of A and C with a weight matrix that fits in registers.  Each wave keeps the MFMA B
+// fragments of its 64 output columns in VGPRs for its whole life (KT*4 fragments), the workgroup
+// (3 waves = 192 columns) walks M persistently in 64-row tiles, A is staged once per tile through a
+// double-buffered LDS image (register prefetch of tile i+1 under the MFMAs of tile i) and shared by
+// the three waves, and C leaves through a wave-private LDS transpose as whole 128/256-byte rows.
+// LDS traffic per MFMA is half of the generic kernel's (no B reads) and A is read exactly once per
+// 192-column group; groups of one tile sequence are placed on one XCD so they share its L2.
+constexpr int WS_BM = 64, WS_NW = 3;
+
+template <typename TA, typename TC, int EPI, int KT>
+__global__ __launch_bounds__(192, 2) void k_gemm_ws(NtArgs g, int ngroups, int nslots) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  constexpr int ROWB = KT * 64 + 16;             // bytes per staged A row (KT*32 bf16 + pad)
+  constexpr int CPR = KT * 4;                    // 16-byte chunks per row
+  constexpr int NLD = (WS_BM * CPR + 64 * WS_NW - 1) / (64 * WS_NW);
+  constexpr int VN = OutVec<TC>::VN, LPR = 64 / VN, RPI = 64 / LPR;
+  __shared__ __attribute__((aligned(16))) char sA[2][WS_BM * ROWB];
+  __shared__ __attribute__((aligned(16))) float sStage[WS_NW][16 * EP_LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gq = lane >> 4, li = lane & 15;
+  const int L = blockIdx.x;
+  const int grp = (L >> 3) % ngroups, slot = (L / (8 * ngroups)) * 8 + (L & 7);
+  const int n0 = grp * 64 * WS_NW + w * 64;
+  const bool active = n0 < g.N;                  // N % 64 == 0: a wave is either fully inside or idle
+  const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A);
+  const T* __restrict__ W = reinterpret_cast<const T*>(g.B);
+  TC* __restrict__ C = reinterpret_cast<TC*>(g.C);
+  const int ntiles = (g.M + WS_BM - 1) / WS_BM;
+
+  typename MM::Frag bf[4][KT];
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ks = 0; ks < KT; ++ks)
+        bf[j][ks] = __builtin_bit_cast(typename MM::Frag, *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + j * 16 + li) * g.ldb + (ks * 4 + gq) * 8));
+  }
+  float alpha = g.alpha;
+  if (g.alpha_ptr) alpha *= *g.alpha_ptr;
+  float d0 = 0.f, d1 = 1.f;
+  if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
+  const int cc = (lane % LPR) * VN;
+  const int n = n0 + cc;
+  float bias_v[VN];
+#pragma unroll
+  for (int e = 0; e < VN; ++e) bias_v[e] = 0.f;
+  if (active && (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE)) {
+#pragma unroll
+    for (int e = 0; e < VN; ++e) bias_v[e] = g.bias[n + e];
+  }
+
+  u32x4 ra[NLD];
+  auto gload = [&](int tile) {
+    const int m0 = tile * WS_BM;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int id = tid + 64 * WS_NW * i, row = id / CPR, c = id % CPR;
+      const int m = m0 + row;
+      ra[i] = (row < WS_BM && m < g.M) ? ChunkLoad<TA, T>::ld(A + (size_t)m * g.lda + c * 8) : z;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int id = tid + 64 * WS_NW * i, row = id / CPR, c = id % CPR;
+      if (row < WS_BM) *reinterpret_cast<u32x4*>(sA[buf] + row * ROWB + c * 16) = ra[i];
+    }
+  };
+
+  // epilogue operands (residual rows / GELU pre-activation) are prefetched one 16-row sub-tile ahead into
+  // registers, so their HBM latency hides under the epilogue math of the previous sub-tile and the MFMAs
+  // of the current one.  The accumulator transpose buffer is private to a wave: DS operations of one wave
+  // execute in order, so only a compiler-level wave barrier separates its writes from its reads.
+  constexpr int IT = 16 / RPI;
+  struct Epi { f32x4 r[IT]; f32x4 r2[IT]; u32x4 ax[IT]; };
+  auto eload = [&](Epi& E, int tile_, int sub_) {
+    if (!active) return;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int m = tile_ * WS_BM + sub_ * 16 + it * RPI + lane / LPR;
+      const bool ok = m < g.M && tile_ < ntiles;
+      const size_t mo = (size_t)(ok ? m : 0);
+      if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) E.r[it] = *reinterpret_cast<const f32x4*>(g.R + mo * g.ldr + n);
+      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[it] = *reinterpret_cast<const f32x4*>(g.R2 + mo * g.ldr + n);
+      if (EPI == UVC_EPI_DGELU) E.ax[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n);
+    }
+  };
+  auto subtile = [&](int buf_, int m0_, int sub_, const Epi& E) {
+    if (!active) return;
+    float* stg = sStage[w];
+    {
+      typename MM::Frag fa[KT];
+#pragma unroll
+      for (int ks = 0; ks < KT; ++ks) fa[ks] = lds_frag<T>(sA[buf_] + (sub_ * 16 + li) * ROWB + (ks * 4 + gq) * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) c = MM::mma(bf[j][ks], fa[ks], c);
+        *reinterpret_cast<f32x4*>(stg + li * EP_LD + j * 16 + gq * 4) = c;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int r = it * RPI + lane / LPR;
+      const int m = m0_ + sub_ * 16 + r;
+      float v[VN];
+      load_vec<float, VN>(stg + r * EP_LD + cc, v);
+      if (m < g.M) {
+        const size_t mo = (size_t)m;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] = v[e] * alpha + bias_v[e];
+        if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += E.r[it][e];
+        }
+        if (EPI == UVC_EPI_BIAS_RESID_GATE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = d1 * v[e] + d0 * E.r2[it][e];
+        }
+        if (EPI == UVC_EPI_DGELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] *= Gelu<T>::g(__uint_as_float(E.ax[it][e] << 16));
+            v[2 * e + 1] *= Gelu<T>::g(__uint_as_float(E.ax[it][e] & 0xffff0000u));
+          }
+        }
+        OutVec<TC>::st(C + mo * g.ldc + n, v);
+        if (EPI == UVC_EPI_BIAS_GELU) {
+          float u[VN];
+#pragma unroll
+          for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
+          OutVec<TC>::st(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  int tile = slot;
+  if (tile >= ntiles) return;
+  Epi E0, E1;
+  gload(tile);
+  eload(E0, tile, 0);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (; tile < ntiles; tile += nslots) {
+    const int next = tile + nslots;
+    if (next < ntiles) gload(next);
+    const int m0 = tile * WS_BM;
+    eload(E1, tile, 1);
+    subtile(buf, m0, 0, E0);
+    eload(E0, tile, 2);
+    subtile(buf, m0, 1, E1);
+    eload(E1, tile, 3);
+    subtile(buf, m0, 2, E0);
+    eload(E0, next, 0);
+    subtile(buf, m0, 3, E1);
+    if (next < ntiles) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// eligibility of the streaming kernel: bf16 compute, K in {128, 192}, N a multiple of 64, vector-aligned leading dims
+static bool ws_ok(const NtArgs& a, int vn) {
+  return (a.K == 192 || a.K == 128) && a.N % 64 == 0 && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % vn == 0 && a.ldr % vn == 0 &&
+         a.ldaux % vn == 0 && a.M >= 4096;
+}
+template <typename TA, typename TC, int KT>
+static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
+  const int ngroups = ceil_div(a.N, 64 * WS_NW);
+  const int ntiles = ceil_div(a.M, WS_BM);
+  int nslots = (512 / ngroups) & ~7;                       // ~2 workgroups per CU in total, slots a multiple of the 8 XCDs
+  if (nslots < 8) nslots = 8;
+  if (nslots > ((ntiles + 7) & ~7)) nslots = (ntiles + 7) & ~7;
+  const int grid = nslots * ngroups;
+#define WS_CASE(E) case E: k_gemm_ws<TA, TC, E, KT><<<grid, 64 * WS_NW, 0, st>>>(a, ngroups, nslots); break;
+  switch (epi) {
+    WS_CASE(UVC_EPI_NONE) WS_CASE(UVC_EPI_BIAS) WS_CASE(UVC_EPI_BIAS_GELU) WS_CASE(UVC_EPI_BIAS_RESID)
+    WS_CASE(UVC_EPI_BIAS_RESID_GATE) WS_CASE(UVC_EPI_DGELU)
+    default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
+  }
+#undef WS_CASE
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+template <typename TA, typename TC>
+static int launch_ws(const NtArgs& a, int epi, hipStream_t st) {
+  return a.K == 192 ? launch_ws_epi<TA, TC, 6>(a, epi, st) : launch_ws_epi<TA, TC, 4>(a, epi, st);
+}
+
 template <typename TA, typename T, typename TC>
 static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
   const int grid = ceil_div(ceil_div(a.M, NT_BM), 8) * 8 * ceil_div(a.N, NT_BN);   // M tiles padded to the 8 XCDs
@@ -323,10 +522,13 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
     return launch_nt_epi<float, float, float>(a, e, st);
   }
   if (p->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dtype must be UVC_F32 or UVC_BF16");
+  const bool ws = !p->force_generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
   if (p->a_is_f32) {
     if ((p->lda % 8) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: lda");
+    if (ws) return p->c_is_f32 ? launch_ws<float, float>(a, e, st) : launch_ws<float, bf16_t>(a, e, st);
     return p->c_is_f32 ? launch_nt_epi<float, bf16_t, float>(a, e, st) : launch_nt_epi<float, bf16_t, bf16_t>(a, e, st);
   }
+  if (ws) return p->c_is_f32 ? launch_ws<bf16_t, float>(a, e, st) : launch_ws<bf16_t, bf16_t>(a, e, st);
   return p->c_is_f32 ? launch_nt_epi<bf16_t, bf16_t, float>(a, e, st) : launch_nt_epi<bf16_t, bf16_t, bf16_t>(a, e, st);
 }
 

@@ -34,7 +34,7 @@ def _is_f32(t) -> int:
 
 
 def gemm_nt(A, B, C_, *, dtype, epilogue=EPI_NONE, bias=None, R=None, R2=None, aux=None, gate=None, C2=None, alpha=1.0,
-            alpha_ptr=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
+            alpha_ptr=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, force_generic=False):
     """C[M,N] = epi(A[M,K] . B[N,K]^T)."""
     _chk(A, B, C_, bias, R, R2, aux, gate, C2, alpha_ptr)
     a = L.uvc_gemm_nt_args()
@@ -50,6 +50,7 @@ def gemm_nt(A, B, C_, *, dtype, epilogue=EPI_NONE, bias=None, R=None, R2=None, a
     a.ldr = a.ldc
     a.ldaux = a.ldc
     a.dtype, a.a_is_f32, a.c_is_f32, a.epilogue = dtype, _is_f32(A), _is_f32(C_), epilogue
+    a.force_generic = int(force_generic)
     L.check(L.lib().uvc_gemm_nt(C.byref(a), L.cur_stream()), "uvc_gemm_nt")
 
 

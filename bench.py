@@ -84,12 +84,18 @@ def kernel_roofline(tr, args, iters=30):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * D * F
     esz = 2 if args.precision == "bf16" else 4
-    bytes_alg = (M * D + F * D + 2 * M * F) * esz
+    bytes_alg = (M * D + F * D + 2 * M * F) * esz          # A once + W once + the two outputs (a, GELU(a)) once
+    gbs = bytes_alg / (ms * 1e-3) / 1e9
     tf = flops / (ms * 1e-3) / 1e12
-    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
-    return {"bound": "mfma", "kernel": "k_gemm_nt<bf16,bias+GELU> (mlp.fc1)", "achieved": round(tf, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None, "launch_ms": round(ms, 4),
-            "algorithmic_GBps": round(bytes_alg / (ms * 1e-3) / 1e9, 1)}
+    mfma_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/
+    # r1_pmc_hbm_traffic_kbench.csv); only valid for the profiled configuration
+    traffic = 351281180 if (args.precision == "bf16" and args.batch == 512 and args.model_type == "deit_tiny_patch16_224") else None
+    # intensity 2*M*D*F / bytes = 85 flop/B << the ~400 flop/B ridge: this kernel's roofline is HBM
+    return {"bound": "hbm", "kernel": "k_gemm_ws<bf16,bf16,EPI_BIAS_GELU,6> (mlp.fc1 + bias + GELU, M=%d K=%d N=%d)" % (M, D, F),
+            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "traffic": traffic, "algorithmic_bytes": bytes_alg, "launch_ms": round(ms, 4),
+            "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / mfma_peak, 4)}
 
 
 def cpu_baseline(args):

@@ -706,6 +706,107 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(TnArgs g) {
   }
 }
 
+// ---- big-tile variant (bf16): one workgroup of 8 waves owns a B1 x B2 output tile (192x256, 256x192 or
+// 192x192), so for the DeiT shapes A (or B) is read exactly once and the other operand <= 4 times through
+// L2, instead of 12x / 2x with the 128x64 tile.  The bias gradient (column sums of A) comes from one extra
+// MFMA column against an all-ones fragment in the waves of the first column of tiles.
+template <typename TA, int B1, int B2, int W1, int W2>
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_big(TnArgs g) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  constexpr int LD1 = B1 * 2 + 32, LD2 = B2 * 2 + 32;
+  constexpr int C1 = B1 / 8, C2 = B2 / 8;
+  constexpr int NLA = TN_BM * C1 / 512, NLB = TN_BM * C2 / 512;
+  constexpr int TI = B1 / W1 / 16, TJ = B2 / W2 / 16;
+  static_assert(W1 * W2 == 8 && (TN_BM * C1) % 512 == 0 && (TN_BM * C2) % 512 == 0, "tile config");
+  __shared__ __attribute__((aligned(16))) char sA[TN_BM * LD1];
+  __shared__ __attribute__((aligned(16))) char sB[TN_BM * LD2];
+  const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(g.B);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int w1 = w / W2, w2 = w % W2;
+  const int n10 = blockIdx.x * B1, n20 = blockIdx.y * B2;
+  const int mbeg = blockIdx.z * g.rows_per_split;
+  const int mend = min(g.M, mbeg + g.rows_per_split);
+  const bool do_cs = g.bpart != nullptr && blockIdx.y == 0 && w2 == 0;
+
+  u32x4 ra[NLA], rb[NLB];
+  auto gload = [&](int m0) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      const int id = tid + 512 * i, row = id / C1, c = id % C1;
+      const int m = m0 + row;
+      ra[i] = (m < mend) ? ChunkLoad<TA, T>::ld(A + (size_t)m * g.lda + n10 + c * 8) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int id = tid + 512 * i, row = id / C2, c = id % C2;
+      const int m = m0 + row;
+      rb[i] = (m < mend) ? ChunkLoad<T, T>::ld(B + (size_t)m * g.ldb + n20 + c * 8) : z;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) { const int id = tid + 512 * i; *reinterpret_cast<u32x4*>(sA + (id / C1) * LD1 + (id % C1) * 16) = ra[i]; }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) { const int id = tid + 512 * i; *reinterpret_cast<u32x4*>(sB + (id / C2) * LD2 + (id % C2) * 16) = rb[i]; }
+  };
+
+  f32x4 acc[TI][TJ], cs[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const typename MM::Frag ones = __builtin_bit_cast(typename MM::Frag, ones_u);
+
+  if (mbeg < mend) {
+    gload(mbeg);
+    lstore();
+    __syncthreads();
+    for (int m0 = mbeg; m0 < mend; m0 += TN_BM) {
+      const bool more = m0 + TN_BM < mend;
+      if (more) gload(m0 + TN_BM);
+#pragma unroll
+      for (int ks = 0; ks < TN_BM / 32; ++ks) {
+        typename MM::Frag fa[TI], fb[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) fa[i] = TrFrag<T>::ld(sA, LD1, ks * 32, w1 * (B1 / W1) + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) fb[j] = TrFrag<T>::ld(sB, LD2, ks * 32, w2 * (B2 / W2) + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = MM::mma(fb[j], fa[i], acc[i][j]);
+          if (do_cs) cs[i] = MM::mma(ones, fa[i], cs[i]);
+        }
+      }
+      if (more) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+      }
+    }
+  }
+  if (do_cs && (lane >> 4) == 0) {      // every row of cs[i] holds the column sums of n1 = .. + (lane & 15)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) g.bpart[(size_t)blockIdx.z * g.N1 + n10 + w1 * (B1 / W1) + i * 16 + (lane & 15)] = cs[i][0];
+  }
+  float* P = g.part + (size_t)blockIdx.z * g.N1 * g.N2;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int n1 = n10 + w1 * (B1 / W1) + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int n2 = n20 + w2 * (B2 / W2) + j * 16 + (lane >> 4) * 4;
+      *reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ part, float* __restrict__ C, int n, int ldc,
                                                    int N2, int splits, float alpha, const float* alpha_ptr, float beta,
                                                    const float* __restrict__ bpart, float* __restrict__ bias_out, int N1) {
@@ -724,13 +825,27 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ par
   }
 }
 
-extern "C" int uvc_gemm_tn_workspace_bytes(int M, int N1, int N2, int64_t* bytes, int* splits_out) {
-  if (!bytes) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn_workspace_bytes: null");
-  const int tiles = ceil_div(N1, TN_B1) * ceil_div(N2, TN_B2);
-  int splits = ceil_div(768, tiles);                        // ~3 blocks per CU
+// 0 = generic 128x64 tiles; 1 = 192x256, 2 = 256x192, 3 = 192x192 (bf16 big tiles)
+static int tn_config(int N1, int N2) {
+  if (N1 % 192 == 0 && N2 % 256 == 0) return 1;
+  if (N1 % 256 == 0 && N2 % 192 == 0) return 2;
+  if (N1 % 192 == 0 && N2 % 192 == 0 && (N1 / 192) * (N2 / 192) >= 2) return 3;   // a single 192x192 tile would need 256 splits
+  return 0;
+}
+static int tn_splits(int M, int N1, int N2, int cfg) {
+  int tiles, target;
+  if (cfg == 0) { tiles = ceil_div(N1, TN_B1) * ceil_div(N2, TN_B2); target = 768; }
+  else { const int b1 = cfg == 2 ? 256 : 192, b2 = cfg == 1 ? 256 : 192; tiles = (N1 / b1) * (N2 / b2); target = 256; }   // one 8-wave group per CU
+  int splits = ceil_div(target, tiles);
   const int max_splits = ceil_div(M, TN_BM);
   if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  return splits < 1 ? 1 : splits;
+}
+
+extern "C" int uvc_gemm_tn_workspace_bytes(int M, int N1, int N2, int64_t* bytes, int* splits_out) {
+  if (!bytes) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn_workspace_bytes: null");
+  const int s0 = tn_splits(M, N1, N2, 0), s1 = tn_splits(M, N1, N2, tn_config(N1, N2));
+  const int splits = s0 > s1 ? s0 : s1;                      // large enough for either kernel
   *bytes = (int64_t)splits * ((int64_t)N1 * N2 + N1) * 4;   // partial tiles + partial column sums
   if (splits_out) *splits_out = splits;
   return UVC_OK;
@@ -745,21 +860,35 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   int64_t need; int splits;
   uvc_gemm_tn_workspace_bytes(p->M, p->N1, p->N2, &need, &splits);
   if (p->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: workspace too small");
+  const int cfg = (p->dtype == UVC_BF16 && p->lda % 8 == 0 && p->ldb % 8 == 0) ? tn_config(p->N1, p->N2) : 0;
+  splits = tn_splits(p->M, p->N1, p->N2, cfg);
   TnArgs a;
   a.A = p->A; a.B = p->B; a.part = (float*)p->workspace; a.M = p->M; a.N1 = p->N1; a.N2 = p->N2; a.lda = p->lda; a.ldb = p->ldb;
-  a.bpart = p->colsum_out ? a.part + (size_t)splits * p->N1 * p->N2 : nullptr;
   int rps = ceil_div(p->M, splits);
   rps = ceil_div(rps, TN_BM) * TN_BM;
   splits = ceil_div(p->M, rps);
   a.rows_per_split = rps;
+  a.bpart = p->colsum_out ? a.part + (size_t)splits * p->N1 * p->N2 : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(ceil_div(p->N1, TN_B1), ceil_div(p->N2, TN_B2), splits);
   if (p->dtype == UVC_F32) {
     if (!p->a_is_f32) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: float32 mode needs float32 A");
+    dim3 grid(ceil_div(p->N1, TN_B1), ceil_div(p->N2, TN_B2), splits);
     k_gemm_tn<float, float><<<grid, 256, 0, st>>>(a);
   } else if (p->dtype == UVC_BF16) {
-    if (p->a_is_f32) k_gemm_tn<float, bf16_t><<<grid, 256, 0, st>>>(a);
-    else k_gemm_tn<bf16_t, bf16_t><<<grid, 256, 0, st>>>(a);
+    if (cfg == 0) {
+      dim3 grid(ceil_div(p->N1, TN_B1), ceil_div(p->N2, TN_B2), splits);
+      if (p->a_is_f32) k_gemm_tn<float, bf16_t><<<grid, 256, 0, st>>>(a);
+      else k_gemm_tn<bf16_t, bf16_t><<<grid, 256, 0, st>>>(a);
+    } else {
+      const int b1 = cfg == 2 ? 256 : 192, b2 = cfg == 1 ? 256 : 192;
+      dim3 grid(p->N1 / b1, p->N2 / b2, splits);
+#define TN_BIG(TA_) \
+      if (cfg == 1) k_gemm_tn_big<TA_, 192, 256, 2, 4><<<grid, 512, 0, st>>>(a); \
+      else if (cfg == 2) k_gemm_tn_big<TA_, 256, 192, 4, 2><<<grid, 512, 0, st>>>(a); \
+      else k_gemm_tn_big<TA_, 192, 192, 2, 4><<<grid, 512, 0, st>>>(a);
+      if (p->a_is_f32) { TN_BIG(float) } else { TN_BIG(bf16_t) }
+#undef TN_BIG
+    }
   } else return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: dtype must be UVC_F32 or UVC_BF16");
   UVC_CHECK_LAUNCH();
   const int n = p->N1 * p->N2;

@@ -166,6 +166,10 @@ int uvc_add_outer(void* X, const float* row_weight, const float* w, int32_t rows
 int uvc_colsum_blocks(int32_t M);
 /* float32 -> bf16 copy and transposed copy of a [R,C] matrix (weight shadows for the GEMMs). */
 int uvc_cast_transpose(const float* W, int32_t R, int32_t C, void* w_bf16, void* wt, int32_t dtype, void* stream);
+/* the same for up to 64 matrices in one launch: srcs[i] = element offset into params, ws[i]/wts[i] = element
+ * offsets (units of T) into shadow for the cast / transposed copy, -1 = skip.  Host arrays. */
+int uvc_cast_transpose_multi(const float* params, void* shadow, int32_t n, const int64_t* srcs, const int32_t* Rs, const int32_t* Cs,
+                             const int64_t* ws, const int64_t* wts, int32_t dtype, void* stream);
 /* block-gate distributions (model_distilled.py:480-488): d[L,2] from g[L,2] and Exp(1) draws. */
 int uvc_gate_distrib(const float* g, const float* e, float* d, int32_t L, int32_t mode, float eps, void* stream);
 /* gradient of the gate logits from the dot products the LayerNorm-backward kernels leave behind

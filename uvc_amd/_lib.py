@@ -117,6 +117,7 @@ _SIGNATURES = {
     "uvc_add_outer": [VP, VP, VP, I32, I32, I32, I32, VP],
     "uvc_colsum_blocks": [I32],
     "uvc_cast_transpose": [VP, I32, I32, VP, VP, I32, VP],
+    "uvc_cast_transpose_multi": [VP, VP, I32, VP, VP, VP, VP, VP, I32, VP],
     "uvc_gate_distrib": [VP, VP, VP, I32, I32, F32, VP],
     "uvc_gate_grad": [VP, VP, VP, VP, I32, I32, F32, F32, VP],
 }

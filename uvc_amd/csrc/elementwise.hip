@@ -60,18 +60,36 @@ __global__ __launch_bounds__(256) void k_assemble_bwd_dpe(const float* __restric
   }
 }
 
-// dpos[t,d] = sum_b dtok[b,t,d]; the class / dist token gradients are rows 0 / 1 of the same sum
+// dpos[t,d] = sum_b dtok[b,t,d]; the class / dist token gradients are rows 0 / 1 of the same sum.
+// 256 threads = 32 column quads x 8 batch slices, 16-byte loads, fixed-order LDS reduction over the slices.
 __global__ __launch_bounds__(256) void k_assemble_bwd_dpos(const float* __restrict__ dtok, float* __restrict__ dpos,
                                                            float* __restrict__ dcls, float* __restrict__ ddist, int B, int N,
                                                            int D, int ntok, float beta) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * D) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += dtok[(size_t)b * N * D + i];
-  dpos[i] = (beta != 0.f ? beta * dpos[i] : 0.f) + s;
-  const int t = i / D, d = i % D;
-  if (t == 0) dcls[d] = (beta != 0.f ? beta * dcls[d] : 0.f) + s;
-  if (t == 1 && ntok == 2 && ddist) ddist[d] = (beta != 0.f ? beta * ddist[d] : 0.f) + s;
+  __shared__ f32x4 red[8][32];
+  const int tx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int ND = N * D, col = (blockIdx.x * 32 + tx) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (col < ND) {
+#pragma unroll 4
+    for (int b = sl; b < B; b += 8) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dtok + (size_t)b * ND + col);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+  }
+  red[sl][tx] = s;
+  __syncthreads();
+  if (sl == 0 && col < ND) {
+    f32x4 t = red[0][tx];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) { const f32x4 v = red[q][tx]; t[0] += v[0]; t[1] += v[1]; t[2] += v[2]; t[3] += v[3]; }
+    const int tok = col / D, d = col % D;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dpos[col + e] = (beta != 0.f ? beta * dpos[col + e] : 0.f) + t[e];
+      if (tok == 0) dcls[d + e] = (beta != 0.f ? beta * dcls[d + e] : 0.f) + t[e];
+      if (tok == 1 && ntok == 2 && ddist) ddist[d + e] = (beta != 0.f ? beta * ddist[d + e] : 0.f) + t[e];
+    }
+  }
 }
 
 // dmask[b,i] = <dtok[b, ntok+i, :], pe[b, i, :]>  (one wave per row)
@@ -322,7 +340,7 @@ extern "C" int uvc_assemble_tokens_bwd(const float* dtok, const float* pe, const
   if (dtype == UVC_F32 || dpe_is_f32) k_assemble_bwd_dpe<float><<<grid_for((int64_t)B * P * D / 4), 256, 0, st>>>(dtok, row_mask, (float*)dpe, B, P, D, ntok);
   else k_assemble_bwd_dpe<bf16_t><<<grid_for((int64_t)B * P * D / 4), 256, 0, st>>>(dtok, row_mask, (bf16_t*)dpe, B, P, D, ntok);
   UVC_CHECK_LAUNCH();
-  k_assemble_bwd_dpos<<<ceil_div((P + ntok) * D, 256), 256, 0, st>>>(dtok, dpos, dcls, ddist, B, P + ntok, D, ntok, beta_acc);
+  k_assemble_bwd_dpos<<<ceil_div((P + ntok) * D, 128), 256, 0, st>>>(dtok, dpos, dcls, ddist, B, P + ntok, D, ntok, beta_acc);
   UVC_CHECK_LAUNCH();
   if (dmask) {
     k_assemble_bwd_dmask<<<ceil_div(B * P, 4), 256, 0, st>>>(dtok, pe, dmask, B, P, D, ntok);
@@ -401,6 +419,51 @@ extern "C" int uvc_cast_transpose(const float* W, int32_t R, int32_t C, void* w_
   dim3 grid(ceil_div(C, 32), ceil_div(R, 32));
   if (dtype == UVC_F32) k_cast_transpose<float><<<grid, 256, 0, (hipStream_t)stream>>>(W, R, C, (float*)w_cast, (float*)wt);
   else k_cast_transpose<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(W, R, C, (bf16_t*)w_cast, (bf16_t*)wt);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+// all weight shadows of a model in ONE launch: table of up to 64 matrices passed by value
+struct CtTable { int n; int tile0[65]; int R[64]; int C[64]; long long src[64]; long long w[64]; long long wt[64]; };
+template <typename T>
+__global__ __launch_bounds__(256) void k_cast_transpose_multi(const float* __restrict__ base, T* __restrict__ sh, CtTable t) {
+  __shared__ float tile[32][33];
+  int m = 0;
+  while (m + 1 < t.n && (int)blockIdx.x >= t.tile0[m + 1]) ++m;
+  const int R = t.R[m], C = t.C[m];
+  const int lt = blockIdx.x - t.tile0[m], tc = (C + 31) / 32;
+  const int r0 = (lt / tc) * 32, c0 = (lt % tc) * 32;
+  const float* W = base + t.src[m];
+  T* w = t.w[m] >= 0 ? sh + t.w[m] : nullptr;
+  T* wt = t.wt[m] >= 0 ? sh + t.wt[m] : nullptr;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    const float v = (r < R && c < C) ? W[(size_t)r * C + c] : 0.f;
+    tile[i][tx] = v;
+    if (w && r < R && c < C) ElemIO<T>::store(w + (size_t)r * C + c, v);
+  }
+  __syncthreads();
+  if (wt)
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (r < R && c < C) ElemIO<T>::store(wt + (size_t)c * R + r, tile[tx][i]);
+    }
+}
+// srcs/ws/wts are element offsets (params / shadow buffer, -1 = skip); n <= 64
+extern "C" int uvc_cast_transpose_multi(const float* params, void* shadow, int32_t n, const int64_t* srcs, const int32_t* Rs, const int32_t* Cs,
+                                        const int64_t* ws, const int64_t* wts, int32_t dtype, void* stream) {
+  if (!params || !shadow || n <= 0 || n > 64 || !srcs || !Rs || !Cs || !ws || !wts) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_cast_transpose_multi: bad argument");
+  CtTable t;
+  t.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    t.tile0[i] = tiles; t.R[i] = Rs[i]; t.C[i] = Cs[i]; t.src[i] = srcs[i]; t.w[i] = ws[i]; t.wt[i] = wts[i];
+    tiles += ceil_div(Rs[i], 32) * ceil_div(Cs[i], 32);
+  }
+  t.tile0[n] = tiles;
+  if (dtype == UVC_F32) k_cast_transpose_multi<float><<<tiles, 256, 0, (hipStream_t)stream>>>(params, (float*)shadow, t);
+  else k_cast_transpose_multi<bf16_t><<<tiles, 256, 0, (hipStream_t)stream>>>(params, (bf16_t*)shadow, t);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -269,8 +269,45 @@ __global__ __launch_bounds__(256) void k_resource(uvc_state st, uvc_dims d, uvc_
   if (threadIdx.x == 0) out[0] = resource_eval(st, d, hp, e, hard != 0, nullptr, nullptr, nullptr, false);
 }
 
-__global__ __launch_bounds__(256) void k_dual_step(uvc_state st, uvc_dims d, uvc_hyper hp, const float* e1,
-                                                   const float* e2, int enable_warmup, int global_step) {
+__global__ __launch_bounds__(256) void k_dual_step(uvc_state gst, uvc_dims d, uvc_hyper hp, const float* ge1,
+                                                   const float* ge2, int enable_warmup, int global_step) {
+  // The scalar update is a few hundred dependent float ops run by one lane: every global access would be a
+  // full memory round trip, so the whole state is staged in LDS first and written back at the end.
+  __shared__ float l_s[UVC_MAX_L * 2], l_r[UVC_MAX_L * UVC_MAX_H], l_y[UVC_MAX_L * 2], l_p[UVC_MAX_L * UVC_MAX_H], l_z[1];
+  __shared__ float l_gate[UVC_MAX_L * 2], l_ggrad[UVC_MAX_L * 2], l_gmom[UVC_MAX_L * 2], l_gsum[UVC_MAX_L * 2];
+  __shared__ float l_macs[UVC_MAX_L * 6], l_e1[UVC_MAX_L * 2], l_e2[UVC_MAX_L * 2], l_out[4];
+  __shared__ int32_t l_rankh[UVC_MAX_L * UVC_MAX_H], l_cnt[2];
+  const bool gating = gst.gate != nullptr && hp.enable_block_gating;
+  {
+    const int L = d.L, H = d.H, t = threadIdx.x;
+    for (int i = t; i < L * 2; i += blockDim.x) {
+      l_s[i] = gst.s[i]; l_y[i] = gst.y[i];
+      if (gating) { l_gate[i] = gst.gate[i]; l_gmom[i] = gst.gate_momentum ? gst.gate_momentum[i] : 0.f; l_gsum[i] = gst.gate_gsum ? gst.gate_gsum[i] : 0.f;
+                    l_ggrad[i] = gst.gate_grad ? gst.gate_grad[i] : 0.f; }
+      l_e1[i] = ge1 ? ge1[i] : 1.f; l_e2[i] = ge2 ? ge2[i] : 1.f;
+    }
+    for (int i = t; i < L * H; i += blockDim.x) { l_r[i] = gst.r[i]; l_p[i] = gst.p[i]; l_rankh[i] = gst.rankh[i]; }
+    for (int i = t; i < L * 6; i += blockDim.x) l_macs[i] = gst.total_macs[i];
+    if (t == 0) { l_z[0] = gst.z[0]; l_cnt[0] = gst.gate_counters ? gst.gate_counters[0] : 0; l_cnt[1] = gst.gate_counters ? gst.gate_counters[1] : 0; }
+    if (t < 4) l_out[t] = gst.out[t];
+  }
+  __syncthreads();
+  uvc_state st = gst;
+  st.s = l_s; st.r = l_r; st.y = l_y; st.p = l_p; st.z = l_z; st.total_macs = l_macs; st.rankh = l_rankh; st.out = l_out;
+  st.gate = gating ? l_gate : nullptr; st.gate_grad = l_ggrad; st.gate_momentum = l_gmom; st.gate_gsum = l_gsum; st.gate_counters = l_cnt;
+  const float* e1 = l_e1;
+  const float* e2 = l_e2;
+  auto write_back = [&]() {
+    __syncthreads();
+    const int L = d.L, H = d.H, t = threadIdx.x;
+    for (int i = t; i < L * 2; i += blockDim.x) {
+      gst.s[i] = l_s[i]; gst.y[i] = l_y[i];
+      if (gating && !enable_warmup) { gst.gate[i] = l_gate[i]; gst.gate_momentum[i] = l_gmom[i]; gst.gate_gsum[i] = l_gsum[i]; }
+    }
+    for (int i = t; i < L * H; i += blockDim.x) { gst.r[i] = l_r[i]; gst.p[i] = l_p[i]; }
+    if (t == 0) { gst.z[0] = l_z[0]; if (gating && !enable_warmup) { gst.gate_counters[0] = l_cnt[0]; gst.gate_counters[1] = l_cnt[1]; } }
+    if (t < 4) gst.out[t] = l_out[t];
+  };
   __shared__ double red[4];
   __shared__ float redf[1];
   __shared__ float nx_s[UVC_MAX_L * 2], nx_r[UVC_MAX_L * UVC_MAX_H];
@@ -376,7 +413,7 @@ __global__ __launch_bounds__(256) void k_dual_step(uvc_state st, uvc_dims d, uvc
     __threadfence_block();
   }
   __syncthreads();
-  if (!go_on) return;
+  if (!go_on) { write_back(); return; }
   // ---- phase 3: least-k sums at the UPDATED s, r (uvc_utils.py:231-254)
   for (int l = 0; l < L; ++l) {
     GroupStat a = group_stat(st.scores2 + l * H, st.rankh + l * H, H, (int)ceilf(st.s[l * 2 + 0]), red, redf);
@@ -397,6 +434,7 @@ __global__ __launch_bounds__(256) void k_dual_step(uvc_state st, uvc_dims d, uvc
     for (int i = 0; i < L * H; ++i) st.p[i] = fmaxf(st.p[i] + hp.plr * ks_r[i], 0.0f);
     st.z[0] = fmaxf(st.z[0] + hp.zlr * (R2 - hp.budget), 0.0f);
   }
+  write_back();
 }
 
 // ---------------------------------------------------------------------------- C-ABI

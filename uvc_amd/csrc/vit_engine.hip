@@ -239,10 +239,19 @@ extern "C" int uvc_vit_update_shadows(const uvc_vit_cfg* cfg, const float* param
   const Dims d = dims_of(*cfg, 1);
   uvc_vit_offsets off; uvc_vit_shadow_offsets so;
   TRY(uvc_vit_layout(cfg, &off, &so));
-  char* S = (char*)shadow;
   const bool f32 = d.dtype == UVC_F32;           // float32 mode: only the transposed copies are needed
+  int64_t srcs[64], ws[64], wts[64];
+  int32_t Rs[64], Cs[64];
+  int n = 0;
+  auto flush = [&]() -> int {
+    if (n == 0) return UVC_OK;
+    const int e = uvc_cast_transpose_multi(params, shadow, n, srcs, Rs, Cs, ws, wts, d.dtype, stream);
+    n = 0;
+    return e;
+  };
   auto one = [&](int64_t p, int R, int C, int64_t sw, int64_t swt) -> int {
-    return uvc_cast_transpose(params + p, R, C, (f32 || sw < 0) ? nullptr : S + sw * d.tsz, swt < 0 ? nullptr : S + swt * d.tsz, d.dtype, stream);
+    srcs[n] = p; Rs[n] = R; Cs[n] = C; ws[n] = f32 ? -1 : sw; wts[n] = swt; ++n;
+    return n == 64 ? flush() : UVC_OK;
   };
   if (!f32) TRY(one(off.patch_w, d.D, d.K0, so.patch_w, -1));
   const int RC[4][2] = {{3 * d.D, d.D}, {d.D, d.D}, {d.F, d.D}, {d.D, d.F}};
@@ -251,7 +260,7 @@ extern "C" int uvc_vit_update_shadows(const uvc_vit_cfg* cfg, const float* param
     for (int j = 0; j < 4; ++j) TRY(one(off.blk[l][pi[j]], RC[j][0], RC[j][1], so.blk_w[l][j], so.blk_wt[l][j]));
   TRY(one(off.head_w, d.NC, d.D, so.head_w, so.head_wt));
   if (d.ntok == 2) TRY(one(off.headd_w, d.NC, d.D, so.headd_w, so.headd_wt));
-  return UVC_OK;
+  return flush();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -94,7 +94,7 @@ def build_model(m, r, student=True):
     return DistilledVisionTransformer(enable_dist=m["enable_dist"], **kw)   # :957-961
 
 
-def margins_ok(minimax, tag):
+def margins_ok(minimax, tag, min_margin=3e-6):
     """Every topk boundary used by prox/mask/loss: (1) the reference's own float32 scores and the
     oracle's float64-accumulated scores must select the SAME index sets, and (2) the boundary
     must be separated by more than float32 reduction noise, so that this holds on any machine."""
@@ -117,7 +117,7 @@ def margins_ok(minimax, tag):
                     srt = torch.sort(sc.double())[0]
                     gap = (srt[kk] - srt[kk - 1]).item() / max(srt[kk].item(), 1e-30)
                     worst = min(worst, gap)
-    assert worst > 3e-6, f"{tag}: selection margin {worst:.2e} too close to float32 reduction noise; change the seed"
+    assert worst > min_margin, f"{tag}: selection margin {worst:.2e} too close to float32 reduction noise; change the seed"
     return worst
 
 
@@ -181,7 +181,8 @@ def run_scenario(name):
     else:
         minimax.model.enable_warmup = 0
         minimax.model.block_skip_gating.requires_grad = True
-    margins = [margins_ok(minimax, name + ":start")]
+    mm_ = r.get("min_margin", 3e-6)
+    margins = [margins_ok(minimax, name + ":start", mm_)]
     uvc_utils.prune_w_mask(minimax, optimizer)
     out["mask0_count"] = np.float64(float(count_mask(model)))
     global_step = 0
@@ -202,11 +203,11 @@ def run_scenario(name):
             scheduler.step()
             global_step += 1
             minimax.update_gating()
-            margins.append(margins_ok(minimax, f"{name}:pre-prox{step}"))
+            margins.append(margins_ok(minimax, f"{name}:pre-prox{step}", mm_))
             cur, s_np, r_np, g_np, gating_grad_list = uvc_opt_mod.uvc_optimizer(
                 optimizer, minimax, s_opt, r_opt, gating_opt, dual_opt, args, {}, [], flops_list,
                 r["z_grad_clip"], global_step, r["gating_interval"], gating_grad_list)
-            margins.append(margins_ok(minimax, f"{name}:post{step}"))
+            margins.append(margins_ok(minimax, f"{name}:post{step}", mm_))
             optimizer.zero_grad()
             draws = rec.draws[n0:]
             pre = f"step{step}."

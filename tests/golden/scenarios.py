@@ -34,6 +34,13 @@ SCENARIOS = {
     "tiny8_train": dict(model="deit_tiny", batch=8, steps=2, warmup=0, state="zero", seed=730),
     "tiny8_pruned": dict(model="deit_tiny", batch=8, steps=2, warmup=0, state="pruned", seed=731,
                          gating_interval=2, warmup_steps=1),
+    # BASELINE configs 3 / 4 at a CPU-sized batch: DeiT-Small budget .58; DeiT-Base with the distillation token
+    "small2_pruned": dict(model="deit_small", batch=2, steps=1, warmup=0, state="pruned", seed=735, budget=0.58,
+                          gating_interval=2, warmup_steps=1),
+    # 3072 fc2 columns per layer: the densest score spectrum of the fixtures, so the margin floor is lower here;
+    # make_golden.py still asserts that the reference's float32 and the float64 scores pick identical sets
+    "base2_deit": dict(model="deit_base_dist", batch=2, steps=1, warmup=0, state="pruned", seed=734,
+                       gating_interval=2, warmup_steps=1, min_margin=4e-7),
 }
 
 MODELS = {
@@ -43,6 +50,10 @@ MODELS = {
                        mlp_ratio=4.0, enable_dist=1, weight_gain=3.0),
     "deit_tiny": dict(img_size=224, patch_size=16, num_classes=1000, embed_dim=192, depth=12,
                       num_heads=3, mlp_ratio=4.0, enable_dist=0, weight_gain=2.0),
+    "deit_small": dict(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12,
+                       num_heads=6, mlp_ratio=4.0, enable_dist=0, weight_gain=1.5),
+    "deit_base_dist": dict(img_size=224, patch_size=16, num_classes=1000, embed_dim=768, depth=12,
+                           num_heads=12, mlp_ratio=4.0, enable_dist=1, weight_gain=1.0),
 }
 
 # README command (run_uvc_train.sh:4-38) hyper-parameters

@@ -109,6 +109,27 @@ def test_gemm_nt_streaming_kernel_matches_generic(K, N):
     torch.testing.assert_close(Cu.double(), F.gelu(ref + bias.double()), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("K", [768, 576])
+def test_gemm_nt_ksplit_streaming_kernel_matches_generic(K):
+    """The K-split weights-stationary kernel (N == 192, K in {576, 768}, M >= 4096) against the generic kernel."""
+    from uvc_amd import ops
+    M, N = 4096 + 21, 192
+    A, W = rnd(M, K, seed=91).to(torch.bfloat16), rnd(N, K, seed=92, scale=0.03).to(torch.bfloat16)
+    bias, R, R2 = rnd(N, seed=93), rnd(M, N, seed=94), rnd(M, N, seed=95)
+    gate = torch.tensor([0.25, 0.75], device=dev())
+    ref = A.double() @ W.double().t()
+    for cdt, kw in ((torch.float32, dict(epilogue=ops.EPI_BIAS_RESID_GATE, bias=bias, R=R, R2=R2, gate=gate)),
+                    (torch.float32, dict(epilogue=ops.EPI_BIAS_RESID, bias=bias, R=R)),
+                    (torch.float32, dict(epilogue=ops.EPI_NONE)), (torch.float32, dict(epilogue=ops.EPI_BIAS, bias=bias))):
+        C1, C2 = torch.empty(M, N, device=dev(), dtype=cdt), torch.empty(M, N, device=dev(), dtype=cdt)
+        ops.gemm_nt(A, W, C1, dtype=BF16, **kw)
+        ops.gemm_nt(A, W, C2, dtype=BF16, force_generic=True, **kw)
+        torch.testing.assert_close(C1.float(), C2.float(), rtol=1e-2 if cdt == torch.bfloat16 else 1e-5, atol=1e-2 if cdt == torch.bfloat16 else 2e-4)
+    C1 = torch.empty(M, N, device=dev())
+    ops.gemm_nt(A, W, C1, dtype=BF16, epilogue=ops.EPI_BIAS_RESID, bias=bias, R=R)
+    torch.testing.assert_close(C1.double(), ref + bias.double() + R.double(), rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("M,N1,N2", [(1576, 576, 192), (403, 192, 768), (3001, 768, 192), (64, 1000, 192), (5000, 128, 128), (40, 8, 16)])
 def test_gemm_tn(dtype, M, N1, N2):

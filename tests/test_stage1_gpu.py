@@ -13,7 +13,7 @@ from stage1_driver import Stage1Run
 pytestmark = pytest.mark.gpu
 
 CORE = ["micro_warmup", "micro_train", "micro_pruned", "micro_clip", "micro_bounds", "micro_softl0", "micro_deit",
-        "micro_patch1", "micro_patch2", "tiny8_train", "tiny8_pruned"]
+        "micro_patch1", "micro_patch2", "tiny8_train", "tiny8_pruned", "small2_pruned", "base2_deit"]
 
 
 def close(a, b, rtol, atol, what):
@@ -98,7 +98,7 @@ def test_stage1_fp32_matches_reference_golden(name):
     run_scenario(name, "fp32", 1e-3)
 
 
-@pytest.mark.parametrize("name", ["micro_train", "micro_pruned", "tiny8_train", "tiny8_pruned"])
+@pytest.mark.parametrize("name", ["micro_train", "micro_pruned", "tiny8_train", "tiny8_pruned", "small2_pruned"])
 def test_stage1_bf16_matches_reference_golden(name):
     """bf16 operands (8 mantissa bits) with float32 accumulation and float32 master weights: loss and
     logits within 2e-2; the UVC state and the mask index sets do not depend on the activations' precision

@@ -26,7 +26,8 @@ enum {
   UVC_EPI_BIAS_GELU = 2,       /* C = a = acc + bias ; C2 = GELU_erf(a)         (Mlp fc1+act, :116-118) */
   UVC_EPI_BIAS_RESID = 3,      /* C = acc + bias + R[m,n]                       (x + proj(...), :240)   */
   UVC_EPI_BIAS_RESID_GATE = 4, /* C = g1*(acc + bias + R[m,n]) + g0*R2[m,n]     (:244 then :493)        */
-  UVC_EPI_DGELU = 5            /* C = alpha*acc * GELU'(aux[m,n])               (backward of :118)      */
+  UVC_EPI_DGELU = 5,           /* C = alpha*acc * GELU'(aux[m,n])               (backward of :118)      */
+  UVC_EPI_BIAS_GELU_OUT = 6    /* C = GELU_erf(acc + bias)   (inference: pre-activation not kept)        */
 };
 
 /* C[M,N] = epilogue( A[M,K] . B[N,K]^T ); A, B row-major with K contiguous. */

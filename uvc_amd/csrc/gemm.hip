@@ -226,9 +226,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
         const size_t mo = (size_t)m;
 #pragma unroll
         for (int e = 0; e < VN; ++e) v[e] *= alpha;
-        if (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
+        if (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
 #pragma unroll
           for (int e = 0; e < VN; ++e) if (n + e < g.N) v[e] += g.bias[n + e];
+        }
+        if (EPI == UVC_EPI_BIAS_GELU_OUT) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] = Gelu<T>::f(v[e]);
         }
         if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
           const float* rp = g.R + mo * g.ldr + n;
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(192, 2) void k_gemm_ws(NtArgs g, int ngroups, int n
   float bias_v[VN];
 #pragma unroll
   for (int e = 0; e < VN; ++e) bias_v[e] = 0.f;
-  if (active && (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE)) {
+  if (active && (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE)) {
 #pragma unroll
     for (int e = 0; e < VN; ++e) bias_v[e] = g.bias[n + e];
   }
@@ -419,6 +423,10 @@ __global__ __launch_bounds__(192, 2) void k_gemm_ws(NtArgs g, int ngroups, int n
             v[2 * e + 1] *= Gelu<T>::g(__uint_as_float(E.ax[it][e] & 0xffff0000u));
           }
         }
+        if (EPI == UVC_EPI_BIAS_GELU_OUT) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] = Gelu<T>::f(v[e]);
+        }
         OutVec<TC>::st(C + mo * g.ldc + n, v);
         if (EPI == UVC_EPI_BIAS_GELU) {
           float u[VN];
@@ -473,7 +481,7 @@ static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
 #define WS_CASE(E) case E: k_gemm_ws<TA, TC, E, KT><<<grid, 64 * WS_NW, 0, st>>>(a, ngroups, nslots); break;
   switch (epi) {
     WS_CASE(UVC_EPI_NONE) WS_CASE(UVC_EPI_BIAS) WS_CASE(UVC_EPI_BIAS_GELU) WS_CASE(UVC_EPI_BIAS_RESID)
-    WS_CASE(UVC_EPI_BIAS_RESID_GATE) WS_CASE(UVC_EPI_DGELU)
+    WS_CASE(UVC_EPI_BIAS_RESID_GATE) WS_CASE(UVC_EPI_DGELU) WS_CASE(UVC_EPI_BIAS_GELU_OUT)
     default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
   }
 #undef WS_CASE
@@ -681,7 +689,7 @@ static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
 #define NT_CASE(E) case E: k_gemm_nt<TA, T, TC, E><<<grid, 256, 0, st>>>(a); break;
   switch (epi) {
     NT_CASE(UVC_EPI_NONE) NT_CASE(UVC_EPI_BIAS) NT_CASE(UVC_EPI_BIAS_GELU) NT_CASE(UVC_EPI_BIAS_RESID)
-    NT_CASE(UVC_EPI_BIAS_RESID_GATE) NT_CASE(UVC_EPI_DGELU)
+    NT_CASE(UVC_EPI_BIAS_RESID_GATE) NT_CASE(UVC_EPI_DGELU) NT_CASE(UVC_EPI_BIAS_GELU_OUT)
     default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
   }
 #undef NT_CASE
@@ -695,7 +703,7 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   const int ch = (p->dtype == UVC_F32) ? 4 : 8;
   if (p->K % ch || p->lda % ch || p->ldb % ch) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: K, lda, ldb must be multiples of a 16-byte chunk");
   const int e = p->epilogue;
-  if ((e == UVC_EPI_BIAS || e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && !p->bias)
+  if ((e == UVC_EPI_BIAS || e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_GELU_OUT || e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && !p->bias)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue needs bias");
   if ((e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && (!p->R || !p->c_is_f32))
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: residual epilogue needs R and a float32 C");

@@ -300,7 +300,10 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     TRY(attn(c, b, false));
     TRY(nt(c, b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), b.x1, 1, d.M, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xin));
     TRY(ln_fwd(c, b.x1, q[6], q[7], b.h2, b.mean2, b.rstd2, d.M, 1, d.D));
-    TRY(nt(c, b.h2, 0, wmat(c, q[8], c.soff.blk_w[l][2]), b.a, 0, d.M, d.F, d.D, UVC_EPI_BIAS_GELU, P + q[9], nullptr, nullptr, nullptr, nullptr, b.u));
+    if (io->training)
+      TRY(nt(c, b.h2, 0, wmat(c, q[8], c.soff.blk_w[l][2]), b.a, 0, d.M, d.F, d.D, UVC_EPI_BIAS_GELU, P + q[9], nullptr, nullptr, nullptr, nullptr, b.u));
+    else   // inference (teacher / eval): the pre-activation is not needed, write GELU(a) only
+      TRY(nt(c, b.h2, 0, wmat(c, q[8], c.soff.blk_w[l][2]), b.u, 0, d.M, d.F, d.D, UVC_EPI_BIAS_GELU_OUT, P + q[9]));
     if (io->gate_d)
       TRY(nt(c, b.u, 0, wmat(c, q[10], c.soff.blk_w[l][3]), xout, 1, d.M, d.D, d.F, UVC_EPI_BIAS_RESID_GATE, P + q[11], b.x1, xin, nullptr, io->gate_d + 2 * l));
     else

@@ -57,6 +57,34 @@ class DistillationLoss(torch.nn.Module):
         self.distillation_type = distillation_type
         self.alpha = alpha
         self.tau = tau
+        self._side = None
+        self._pref = None
+
+    def prefetch(self, inputs):
+        """Optional: start the teacher forward for ``inputs`` on a side HIP stream so that it overlaps the
+        student forward (both are strings of latency-bound kernels that do not fill the chip alone).
+        ``forward`` picks the result up if it is called with the same tensor; numerics are unchanged."""
+        if self.distillation_type == 'none' or self.teacher_model is None:
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=inputs.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side), torch.no_grad():
+            out, _ = self.teacher_model(inputs)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._pref = (inputs.data_ptr(), inputs._version, out, ev)
+
+    def _teacher(self, inputs):
+        p, self._pref = self._pref, None
+        if p is not None and p[0] == inputs.data_ptr() and p[1] == inputs._version:
+            torch.cuda.current_stream().wait_event(p[3])
+            p[2].record_stream(torch.cuda.current_stream())
+            return p[2]
+        with torch.no_grad():
+            out, _ = self.teacher_model(inputs)                       # losses.py:47-49
+        return out
 
     def forward(self, inputs, outputs, labels):
         outputs_kd = None
@@ -68,6 +96,5 @@ class DistillationLoss(torch.nn.Module):
         if outputs_kd is None:
             raise ValueError("When knowledge distillation is enabled, the model is expected to return a "
                              "Tuple[Tensor, Tensor] with the output of the class_token and the dist_token")
-        with torch.no_grad():
-            teacher_outputs, _ = self.teacher_model(inputs)           # losses.py:47-49
+        teacher_outputs = self._teacher(inputs)
         return _LossFunction.apply(outputs, outputs_kd, labels, teacher_outputs.contiguous(), float(self.alpha), float(self.tau), 1)

@@ -9,8 +9,8 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_NONE, UVC_BF16,
-                   UVC_F32)
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_OUT, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_NONE,
+                   UVC_BF16, UVC_F32)
 
 __all__ = ["EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RESID", "EPI_BIAS_RESID_GATE", "EPI_DGELU", "UVC_F32",
            "UVC_BF16"]

@@ -125,6 +125,8 @@ class Stage1Trainer:
     # -- one step (joint_train.py:395-450), x / y already mixed
     def step(self, x, y, tau=None, zero_grad=True):
         a = self.args
+        if getattr(a, "overlap_teacher", 1):
+            self.criterion.prefetch(x)              # teacher forward on a side stream, under the student forward
         outputs, _ = self.model(x, self.get_tau() if tau is None else tau, a.patch_ratio)
         loss = self.criterion(x, outputs, y)
         loss.backward()

@@ -82,6 +82,10 @@ typedef struct uvc_vit_io {
    *           rest of the backward runs (and add the patch-scorer term to dpe before stage L+2).
    * forward:  0 = patch embedding, 1 = everything after it (the patch-gating mask is computed in between). */
   int32_t stage_begin, stage_end;
+  /* backward, optional: a second hipStream_t.  The weight-gradient GEMMs (which hang off the dgrad chain) are
+   * enqueued there and overlap the chain on `stream`; events order operand reads against buffer reuse, and
+   * `stream` waits for the side stream before the call's last stage returns. */
+  void* side_stream;
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

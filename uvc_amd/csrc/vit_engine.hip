@@ -102,7 +102,39 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
 }
 
 // ---- small helpers around the kernel entry points -----------------------------------------------
-struct Ctx { const uvc_vit_cfg* cfg; Dims d; uvc_vit_offsets off; uvc_vit_shadow_offsets soff; const uvc_vit_io* io; void* st; Work w; };
+struct Ctx {
+  const uvc_vit_cfg* cfg; Dims d; uvc_vit_offsets off; uvc_vit_shadow_offsets soff; const uvc_vit_io* io; void* st; Work w;
+  void* side;            // optional second stream for the weight-gradient GEMMs (backward)
+  bool done_set[5];      // ev_done[k] recorded in this call
+};
+
+// Events for the two-stream backward.  Created once per process (host objects, no device memory).
+hipEvent_t g_ev_raw = nullptr, g_ev_join = nullptr, g_ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+int ensure_events() {
+  if (g_ev_raw) return UVC_OK;
+  hipError_t e = hipEventCreateWithFlags(&g_ev_raw, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming);
+  for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&g_ev_done[i], hipEventDisableTiming);
+  if (e != hipSuccess) { g_ev_raw = nullptr; return uvc_set_error(e, __FILE__, __LINE__); }
+  return UVC_OK;
+}
+// buffers the side-stream wgrads read and the main stream later overwrites
+enum { BUF_GA = 0, BUF_DA = 1, BUF_GB = 2, BUF_DQKV = 3, BUF_OTHER = 4 };
+// main stream is about to overwrite buffer k: wait for the side-stream reader launched earlier in this call
+int guard_overwrite(Ctx& c, int k) {
+  if (c.side && c.done_set[k]) {
+    hipError_t e = hipStreamWaitEvent((hipStream_t)c.st, g_ev_done[k], 0);
+    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+  }
+  return UVC_OK;
+}
+int join_side(Ctx& c) {
+  if (!c.side) return UVC_OK;
+  hipError_t e = hipEventRecord(g_ev_join, (hipStream_t)c.side);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)c.st, g_ev_join, 0);
+  if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+  return UVC_OK;
+}
 
 const void* sh(const Ctx& c, int64_t off) { return (const char*)c.io->shadow + off * c.d.tsz; }
 // GEMM B operand [out,in]: float32 mode reads the master weights directly
@@ -118,16 +150,30 @@ int nt(const Ctx& c, const void* A, int a_f32, const void* B, void* C, int c_f32
   a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32; a.c_is_f32 = c_f32 || c.d.dtype == UVC_F32; a.epilogue = epi;
   return uvc_gemm_nt(&a, c.st);
 }
-// weight gradient + (same pass over A) bias gradient
-int tn(const Ctx& c, const void* A, int a_f32, const void* B, float* C, float* bias_grad, int M, int N1, int N2, const float* alpha_ptr = nullptr,
-       int lda = 0, int ldb = 0) {
+// weight gradient + (same pass over A) bias gradient.  With a side stream the launch goes there: it waits for
+// everything the main stream has enqueued so far (its operands) and records ev_done[buf] for the overwrite guard.
+int tn(Ctx& c, const void* A, int a_f32, const void* B, float* C, float* bias_grad, int M, int N1, int N2, const float* alpha_ptr = nullptr,
+       int lda = 0, int ldb = 0, int buf = BUF_OTHER) {
+  void* stream = c.st;
+  if (c.side) {
+    hipError_t e = hipEventRecord(g_ev_raw, (hipStream_t)c.st);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)c.side, g_ev_raw, 0);
+    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+    stream = c.side;
+  }
   uvc_gemm_tn_args a;
   memset(&a, 0, sizeof(a));
   a.colsum_out = bias_grad;
   a.A = A; a.B = B; a.C = C; a.workspace = c.w.tn_ws; a.workspace_bytes = c.w.tn_ws_bytes; a.alpha_ptr = alpha_ptr; a.alpha = 1.0f;
   a.beta = c.io->accumulate; a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda ? lda : N1; a.ldb = ldb ? ldb : N2; a.ldc = N2;
   a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32;
-  return uvc_gemm_tn(&a, c.st);
+  if (int e = uvc_gemm_tn(&a, stream)) return e;
+  if (c.side) {
+    hipError_t e = hipEventRecord(g_ev_done[buf], (hipStream_t)c.side);
+    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+    c.done_set[buf] = true;
+  }
+  return UVC_OK;
 }
 int csum(const Ctx& c, const void* X, int x_f32, float* out, int M, int N, const float* alpha_ptr = nullptr, int ldx = 0) {
   return uvc_colsum(X, M, N, ldx ? ldx : N, c.d.dtype, x_f32 || c.d.dtype == UVC_F32, c.w.cs_partial, out, 1.0f, alpha_ptr, c.io->accumulate, nullptr, c.st);
@@ -164,6 +210,9 @@ int setup(Ctx& c, const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream, bo
   if (cfg->dtype == UVC_BF16 && !io->shadow) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: bf16 mode needs the shadow buffer");
   if (!io->shadow) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: shadow buffer (W^T copies) missing");
   c.cfg = cfg; c.io = io; c.st = stream; c.d = dims_of(*cfg, io->batch);
+  c.side = bwd ? io->side_stream : nullptr;
+  for (int i = 0; i < 5; ++i) c.done_set[i] = false;
+  if (c.side) TRY(ensure_events());
   TRY(uvc_vit_layout(cfg, &c.off, &c.soff));
   const int64_t need = carve(c.d, bwd ? 1 : io->training, (char*)io->workspace, c.w);
   if (io->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: workspace too small");
@@ -361,18 +410,22 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     const float* g0 = io->gate_d ? io->gate_d + 2 * l : nullptr;       // d0
     const float* g1 = io->gate_d ? io->gate_d + 2 * l + 1 : nullptr;   // d1
     // MLP: out = d1*(x1 + fc2(u)) + d0*x
+    TRY(guard_overwrite(c, BUF_DA));
     TRY(nt(c, w.gA, 1, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
-    TRY(tn(c, w.gA, 1, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1));
+    TRY(tn(c, w.gA, 1, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1, 0, 0, BUF_GA));
     TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
-    TRY(tn(c, w.dA, 0, b.h2, G + q[8], G + q[9], d.M, d.F, d.D));
+    TRY(tn(c, w.dA, 0, b.h2, G + q[8], G + q[9], d.M, d.F, d.D, nullptr, 0, 0, BUF_DA));
+    TRY(guard_overwrite(c, BUF_GB));
     TRY(ln_bwd(c, w.dH, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr, d.M, 1, d.D));   // gB = dL/dx1
     // attention
     TRY(nt(c, w.gB, 1, sh(c, so.blk_wt[l][1]), w.dH, 0, d.M, d.D, d.D, UVC_EPI_NONE));                                      // dO
-    TRY(tn(c, w.gB, 1, b.o, G + q[4], G + q[5], d.M, d.D, d.D));
+    TRY(tn(c, w.gB, 1, b.o, G + q[4], G + q[5], d.M, d.D, d.D, nullptr, 0, 0, BUF_GB));
+    TRY(guard_overwrite(c, BUF_DQKV));
     TRY(attn(c, b, true));
     TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));
-    TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], G + q[3], d.M, 3 * d.D, d.D));
+    TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], G + q[3], d.M, 3 * d.D, d.D, nullptr, 0, 0, BUF_DQKV));
     // gA <- dL/dx_l = LN1'(dH) + gB + d0*gA ; dots: <new gA, x_l>, <old gA, x_l>
+    TRY(guard_overwrite(c, BUF_GA));
     TRY(ln_bwd(c, w.dH, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0, w.dotsraw + 2 * l, d.M, 1, d.D));
   }
   if (sb <= d.L + 1 && se > d.L + 1) {
@@ -383,8 +436,8 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     TRY(uvc_assemble_tokens_bwd(w.gA, w.pe, io->patch_mask, w.dpe, G + o.pos_embed, G + o.cls_token, d.ntok == 2 ? G + o.dist_token : nullptr,
                                 io->d_patch_mask, d.B, d.np, d.D, d.ntok, d.dtype, 0, io->accumulate, stream));
   }
-  if (se < d.L + 3) return UVC_OK;
+  if (se < d.L + 3) return join_side(c);
   // patch embedding (weight gradient only: the image needs no gradient)
   TRY(tn(c, w.dpe, 0, w.patches, G + o.patch_w, G + o.patch_b, d.B * d.np, d.D, d.K0));
-  return UVC_OK;
+  return join_side(c);
 }

@@ -51,7 +51,7 @@ class uvc_vit_io(C.Structure):
                 ("d_logits", C.c_void_p), ("d_logits_dist", C.c_void_p), ("gate_d", C.c_void_p),
                 ("run_block", C.POINTER(C.c_int32)), ("patch_mask", C.c_void_p), ("d_patch_mask", C.c_void_p),
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
-                ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32)]
+                ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p)]
 
 
 def _bind():
@@ -172,6 +172,8 @@ class DistilledVisionTransformer(nn.Module):
         self.eps = eps
         self.enable_warmup = enable_warmup
         self.frozen_weights = False          # set on the teacher: shadows are refreshed once
+        self.two_stream_backward = True      # weight-gradient GEMMs on a side stream, overlapping the dgrad chain
+        self._wgrad_stream = None
         self.grad_accumulate = False         # True: backward adds into .grad (gradient_accumulation_steps > 1)
         # --- registration order follows the reference so state_dict keys line up
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
@@ -444,6 +446,10 @@ class DistilledVisionTransformer(nn.Module):
             d_logits_dist = d_logits_dist.contiguous()
             io.d_logits_dist = L.ptr(d_logits_dist)
         io.gate_d = L.ptr(st["gate_d"])
+        if self.two_stream_backward:
+            if self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream(device=self._flat.device)
+            io.side_stream = self._wgrad_stream.cuda_stream
         dmask = None
         if patch:
             io.patch_mask = L.ptr(patch["mask"])

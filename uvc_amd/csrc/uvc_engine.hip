@@ -176,31 +176,20 @@ struct GroupStat {   // least-k statistics of one score group
   float ksum;        // sum of the k smallest (float64 accumulate) -- get_least_*_norm
 };
 
-// all threads of the block cooperate; result valid in every thread after return
-__device__ GroupStat group_stat(const float* __restrict__ sc, const int32_t* __restrict__ rk, int n, int k,
-                                double* red, float* redf) {
+// one WAVE computes the least-k statistics of one score group (no block barriers): result valid in every lane
+__device__ GroupStat group_stat(const float* __restrict__ sc, const int32_t* __restrict__ rk, int n, int k) {
+  const int lane = threadIdx.x & 63;
   double part = 0.0;
-  float nxt = 0.0f;
-  bool have = false;
+  float nxt = -1.0f;                               // scores are sums of squares (>= 0): -1 is a safe "not mine"
   const int want = (k + 1 <= n) ? k : n - 1;     // rank of the backward factor
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = lane; i < n; i += 64) {
     const int rr = rk[i];
     if (rr < k) part += (double)sc[i];
-    if (rr == want) { nxt = sc[i]; have = true; }
+    if (rr == want) nxt = sc[i];
   }
-  // block reduction (fixed order)
-  part = wave_sum_f64(part);
-  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[w] = part;
-  if (have) redf[0] = nxt;
-  __syncthreads();
-  double tot = 0.0;
-  for (int i = 0; i < nw; ++i) tot += red[i];
   GroupStat g;
-  g.ksum = (float)tot;
-  g.next = redf[0];
-  __syncthreads();
+  g.ksum = (float)wave_sum_f64(part);              // butterfly: same order on every run
+  g.next = wave_max(nxt);
   return g;
 }
 
@@ -269,7 +258,7 @@ __global__ __launch_bounds__(256) void k_resource(uvc_state st, uvc_dims d, uvc_
   if (threadIdx.x == 0) out[0] = resource_eval(st, d, hp, e, hard != 0, nullptr, nullptr, nullptr, false);
 }
 
-__global__ __launch_bounds__(256) void k_dual_step(uvc_state gst, uvc_dims d, uvc_hyper hp, const float* ge1,
+__global__ __launch_bounds__(1024) void k_dual_step(uvc_state gst, uvc_dims d, uvc_hyper hp, const float* ge1,
                                                    const float* ge2, int enable_warmup, int global_step) {
   // The scalar update is a few hundred dependent float ops run by one lane: every global access would be a
   // full memory round trip, so the whole state is staged in LDS first and written back at the end.
@@ -308,22 +297,20 @@ __global__ __launch_bounds__(256) void k_dual_step(uvc_state gst, uvc_dims d, uv
     if (t == 0) { gst.z[0] = l_z[0]; if (gating && !enable_warmup) { gst.gate_counters[0] = l_cnt[0]; gst.gate_counters[1] = l_cnt[1]; } }
     if (t < 4) gst.out[t] = l_out[t];
   };
-  __shared__ double red[4];
-  __shared__ float redf[1];
   __shared__ float nx_s[UVC_MAX_L * 2], nx_r[UVC_MAX_L * UVC_MAX_H];
   __shared__ float ks_s[UVC_MAX_L * 2], ks_r[UVC_MAX_L * UVC_MAX_H];
   __shared__ float gs2[UVC_MAX_L * 2], gr2[UVC_MAX_L * UVC_MAX_H], gg2[UVC_MAX_L * 2];
   __shared__ int go_on;
   const int L = d.L, H = d.H;
-  // ---- phase 1: backward factors of sloss1 / rloss1 at k = ceil(s), ceil(r) (uvc_utils.py:177-217)
-  for (int l = 0; l < L; ++l) {
-    GroupStat a = group_stat(st.scores2 + l * H, st.rankh + l * H, H, (int)ceilf(st.s[l * 2 + 0]), red, redf);
-    GroupStat b = group_stat(st.scores3 + l * d.F, st.rank3 + l * d.F, d.F, (int)ceilf(st.s[l * 2 + 1]), red, redf);
-    if (threadIdx.x == 0) { nx_s[l * 2 + 0] = a.next; nx_s[l * 2 + 1] = b.next; }
+  // ---- phase 1: backward factors of sloss1 / rloss1 at k = ceil(s), ceil(r) (uvc_utils.py:177-217); one wave per layer
+  const int wv = threadIdx.x >> 6, nwv = blockDim.x >> 6, ln0 = threadIdx.x & 63;
+  for (int l = wv; l < L; l += nwv) {
+    GroupStat a = group_stat(st.scores2 + l * H, st.rankh + l * H, H, (int)ceilf(st.s[l * 2 + 0]));
+    GroupStat b = group_stat(st.scores3 + l * d.F, st.rank3 + l * d.F, d.F, (int)ceilf(st.s[l * 2 + 1]));
+    if (ln0 == 0) { nx_s[l * 2 + 0] = a.next; nx_s[l * 2 + 1] = b.next; }
     for (int h = 0; h < H; ++h) {
-      GroupStat c = group_stat(st.scores1 + l * d.D + h * d.hd, st.rank1 + l * d.D + h * d.hd, d.hd,
-                               (int)ceilf(st.r[l * H + h]), red, redf);
-      if (threadIdx.x == 0) nx_r[l * H + h] = c.next;
+      GroupStat c = group_stat(st.scores1 + l * d.D + h * d.hd, st.rank1 + l * d.D + h * d.hd, d.hd, (int)ceilf(st.r[l * H + h]));
+      if (ln0 == 0) nx_r[l * H + h] = c.next;
     }
   }
   __syncthreads();
@@ -415,14 +402,13 @@ __global__ __launch_bounds__(256) void k_dual_step(uvc_state gst, uvc_dims d, uv
   __syncthreads();
   if (!go_on) { write_back(); return; }
   // ---- phase 3: least-k sums at the UPDATED s, r (uvc_utils.py:231-254)
-  for (int l = 0; l < L; ++l) {
-    GroupStat a = group_stat(st.scores2 + l * H, st.rankh + l * H, H, (int)ceilf(st.s[l * 2 + 0]), red, redf);
-    GroupStat b = group_stat(st.scores3 + l * d.F, st.rank3 + l * d.F, d.F, (int)ceilf(st.s[l * 2 + 1]), red, redf);
-    if (threadIdx.x == 0) { ks_s[l * 2 + 0] = a.ksum; ks_s[l * 2 + 1] = b.ksum; }
+  for (int l = wv; l < L; l += nwv) {
+    GroupStat a = group_stat(st.scores2 + l * H, st.rankh + l * H, H, (int)ceilf(st.s[l * 2 + 0]));
+    GroupStat b = group_stat(st.scores3 + l * d.F, st.rank3 + l * d.F, d.F, (int)ceilf(st.s[l * 2 + 1]));
+    if (ln0 == 0) { ks_s[l * 2 + 0] = a.ksum; ks_s[l * 2 + 1] = b.ksum; }
     for (int h = 0; h < H; ++h) {
-      GroupStat c = group_stat(st.scores1 + l * d.D + h * d.hd, st.rank1 + l * d.D + h * d.hd, d.hd,
-                               (int)ceilf(st.r[l * H + h]), red, redf);
-      if (threadIdx.x == 0) ks_r[l * H + h] = c.ksum;
+      GroupStat c = group_stat(st.scores1 + l * d.D + h * d.hd, st.rank1 + l * d.D + h * d.hd, d.hd, (int)ceilf(st.r[l * H + h]));
+      if (ln0 == 0) ks_r[l * H + h] = c.ksum;
     }
   }
   __syncthreads();
@@ -503,7 +489,8 @@ extern "C" int uvc_dual_step(const uvc_state* st, uvc_dims d, uvc_hyper hp, cons
   if (int e = check_state(st, hp, !enable_warmup)) return e;
   const bool gum = hp.enable_block_gating && st->gate && hp.use_gumbel;
   if (gum && (!e1 || (!enable_warmup && !e2))) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_dual_step: Exp(1) draws missing");
-  k_dual_step<<<1, 256, 0, (hipStream_t)stream>>>(*st, d, hp, e1, e2, enable_warmup, global_step);
+  const int nwaves = d.L < 16 ? d.L : 16;                  // one wave per layer for the least-k scans
+  k_dual_step<<<1, 64 * nwaves, 0, (hipStream_t)stream>>>(*st, d, hp, e1, e2, enable_warmup, global_step);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

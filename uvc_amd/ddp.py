@@ -105,7 +105,7 @@ class DistributedDataParallel(torch.nn.Module):
         plan = bucket_plan(module._off, module._cfg.depth, module.N_EXTRA, 1 if delay_allreduce else num_buckets)
         self.stage_ends = [p[0] for p in plan]
         self.reducer = FlatGradReducer(module._flat_grad, [p[1] for p in plan], process_group)
-        module._ddp = self
+        object.__setattr__(module, "_ddp", self)      # plain attribute: registering it as a sub-module would create a module cycle
 
     def forward(self, *a, **k):
         return self.module(*a, **k)

@@ -301,10 +301,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
 // the three waves, and C leaves through a wave-private LDS transpose as whole 128/256-byte rows.
 // LDS traffic per MFMA is half of the generic kernel's (no B reads) and A is read exactly once per
 // 192-column group; groups of one tile sequence are placed on one XCD so they share its L2.
-constexpr int WS_BM = 64, WS_NW = 3;
+constexpr int WS_BM = 64;
 
-template <typename TA, typename TC, int EPI, int KT>
-__global__ __launch_bounds__(192, 2) void k_gemm_ws(NtArgs g, int ngroups, int nslots) {
+template <typename TA, typename TC, int EPI, int KT, int WS_NW>
+__global__ __launch_bounds__(64 * WS_NW, 2) void k_gemm_ws(NtArgs g, int ngroups, int nslots) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   constexpr int ROWB = KT * 64 + 16;             // bytes per staged A row (KT*32 bf16 + pad)
@@ -470,7 +470,7 @@ static bool ws_ok(const NtArgs& a, int vn) {
   return (a.K == 192 || a.K == 128) && a.N % 64 == 0 && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % vn == 0 && a.ldr % vn == 0 &&
          a.ldaux % vn == 0 && a.M >= 4096;
 }
-template <typename TA, typename TC, int KT>
+template <typename TA, typename TC, int KT, int WS_NW>
 static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
   const int ngroups = ceil_div(a.N, 64 * WS_NW);
   const int ntiles = ceil_div(a.M, WS_BM);
@@ -478,7 +478,7 @@ static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
   if (nslots < 8) nslots = 8;
   if (nslots > ((ntiles + 7) & ~7)) nslots = (ntiles + 7) & ~7;
   const int grid = nslots * ngroups;
-#define WS_CASE(E) case E: k_gemm_ws<TA, TC, E, KT><<<grid, 64 * WS_NW, 0, st>>>(a, ngroups, nslots); break;
+#define WS_CASE(E) case E: k_gemm_ws<TA, TC, E, KT, WS_NW><<<grid, 64 * WS_NW, 0, st>>>(a, ngroups, nslots); break;
   switch (epi) {
     WS_CASE(UVC_EPI_NONE) WS_CASE(UVC_EPI_BIAS) WS_CASE(UVC_EPI_BIAS_GELU) WS_CASE(UVC_EPI_BIAS_RESID)
     WS_CASE(UVC_EPI_BIAS_RESID_GATE) WS_CASE(UVC_EPI_DGELU) WS_CASE(UVC_EPI_BIAS_GELU_OUT)
@@ -490,7 +490,9 @@ static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
 }
 template <typename TA, typename TC>
 static int launch_ws(const NtArgs& a, int epi, hipStream_t st) {
-  return a.K == 192 ? launch_ws_epi<TA, TC, 6>(a, epi, st) : launch_ws_epi<TA, TC, 4>(a, epi, st);
+  // 4 waves (256 columns) per workgroup when N divides: more waves per CU to overlap the GELU epilogues
+  if (a.N % 256 == 0) return a.K == 192 ? launch_ws_epi<TA, TC, 6, 4>(a, epi, st) : launch_ws_epi<TA, TC, 4, 4>(a, epi, st);
+  return a.K == 192 ? launch_ws_epi<TA, TC, 6, 3>(a, epi, st) : launch_ws_epi<TA, TC, 4, 3>(a, epi, st);
 }
 
 // ================================================================================================

@@ -1009,22 +1009,39 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_big(TnArgs g) {
   }
 }
 
+// sum the split-M partial tiles (and partial column sums) in a fixed order.  VEC = 4: 16-byte accesses, 4 slices in flight
+template <int VEC>
 __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ part, float* __restrict__ C, int n, int ldc,
                                                    int N2, int splits, float alpha, const float* alpha_ptr, float beta,
                                                    const float* __restrict__ bpart, float* __restrict__ bias_out, int N1) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * VEC;
   if (i >= n + (bpart ? N1 : 0)) return;
   if (alpha_ptr) alpha *= *alpha_ptr;
-  float s = 0.f;
-  if (i < n) {
-    for (int z = 0; z < splits; ++z) s += part[(size_t)z * n + i];
-    float* c = C + (size_t)(i / N2) * ldc + (i % N2);
-    *c = (beta != 0.f ? beta * *c : 0.f) + alpha * s;
-  } else {
-    const int j = i - n;
-    for (int z = 0; z < splits; ++z) s += bpart[(size_t)z * N1 + j];
-    bias_out[j] = (beta != 0.f ? beta * bias_out[j] : 0.f) + alpha * s;
+  const bool main_part = i < n;
+  const float* src = main_part ? part + i : bpart + (i - n);
+  const size_t stride = main_part ? (size_t)n : (size_t)N1;
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+  int z = 0;
+  for (; z + 4 <= splits; z += 4) {
+    float v[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (VEC == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(src + (size_t)(z + u) * stride); v[u][0] = t[0]; v[u][1 % VEC] = t[1]; v[u][2 % VEC] = t[2]; v[u][3 % VEC] = t[3]; }
+      else v[u][0] = src[(size_t)(z + u) * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[e] += v[u][e];
   }
+  for (; z < splits; ++z)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] += src[(size_t)z * stride + e];
+  float* dst = main_part ? C + (size_t)(i / N2) * ldc + (i % N2) : bias_out + (i - n);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) dst[e] = (beta != 0.f ? beta * dst[e] : 0.f) + alpha * s[e];
 }
 
 // 0 = generic 128x64 tiles; 1 = 192x256, 2 = 256x192, 3 = 192x192 (bf16 big tiles)
@@ -1094,8 +1111,11 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   } else return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: dtype must be UVC_F32 or UVC_BF16");
   UVC_CHECK_LAUNCH();
   const int n = p->N1 * p->N2;
-  k_tn_reduce<<<ceil_div(n + (a.bpart ? p->N1 : 0), 256), 256, 0, st>>>(a.part, p->C, n, p->ldc, p->N2, splits, p->alpha, p->alpha_ptr, p->beta,
-                                                                         a.bpart, p->colsum_out, p->N1);
+  const int tot = n + (a.bpart ? p->N1 : 0);
+  if (n % 4 == 0 && p->N2 % 4 == 0 && p->ldc % 4 == 0 && p->N1 % 4 == 0)
+    k_tn_reduce<4><<<ceil_div(tot / 4, 256), 256, 0, st>>>(a.part, p->C, n, p->ldc, p->N2, splits, p->alpha, p->alpha_ptr, p->beta, a.bpart, p->colsum_out, p->N1);
+  else
+    k_tn_reduce<1><<<ceil_div(tot, 256), 256, 0, st>>>(a.part, p->C, n, p->ldc, p->N2, splits, p->alpha, p->alpha_ptr, p->beta, a.bpart, p->colsum_out, p->N1);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int LN_ROWS_PER_BLOCK = 32;    // backward: rows per block (8 per wave; 3152 blocks at M = 100864 -> no tail round)
+constexpr int LN_ROWS_PER_BLOCK = 128;   // backward: rows per block (32 per wave); smaller blocks only inflate the partial reduction
 
 __device__ __forceinline__ size_t row_off(int r, int rpg, int64_t gs, int D) {
   return (size_t)(r / rpg) * gs + (size_t)(r % rpg) * D;

@@ -37,6 +37,8 @@ def parse():
     p.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE config 2)")
     p.add_argument("--model_type", default="deit_tiny_patch16_224")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--stage", type=int, default=1, choices=[1, 2],
+                   help="1 = the headline Stage-1 UVC-train step; 2 = the Stage-2 masked fine-tune step (SURVEY §8 f-1)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_steps", type=int, default=6)
     return p.parse_args()
@@ -54,6 +56,36 @@ def pruned_state(tr, seed=731):
     r = rs.uniform(0, 30.0, (L, H)).astype(np.float32)
     mm.s.data.copy_(torch.from_numpy(s)); mm.r.data.copy_(torch.from_numpy(r))
     mm.y.data.fill_(1.0); mm.p.data.fill_(1.0); mm.z.data.fill_(2.0)
+
+
+def stage2_checkpoint_state(model, seed=732, skip_blocks=(4, 9)):
+    """A finished-Stage-1-like state for the Stage-2 bench: structured masks at roughly the budget-0.5 operating point
+    (one head of three dropped + a quarter of the remaining proj input columns, half of the MLP hidden units) and
+    two hard-skipped blocks."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    cfg = model._cfg
+    D, F, H = cfg.embed_dim, cfg.hidden, cfg.num_heads
+    hd = D // H
+    dev = model._flat.device
+    with torch.no_grad():
+        for l, blk in enumerate(model.blocks):
+            kp = np.ones(D, np.float32)
+            dead = rs.randint(0, H)
+            kp[dead * hd:(dead + 1) * hd] = 0
+            for h in range(H):
+                if h != dead:
+                    kp[h * hd + rs.choice(hd, size=hd // 4, replace=False)] = 0
+            kh = np.ones(F, np.float32)
+            kh[rs.choice(F, size=F // 2, replace=False)] = 0
+            kp, kh = torch.from_numpy(kp).to(dev), torch.from_numpy(kh).to(dev)
+            blk.attn.proj.mask.copy_(kp[None, :].expand(D, -1))
+            blk.mlp.fc2.mask.copy_(kh[None, :].expand(D, -1))
+            blk.mlp.fc1.mask.copy_(kh[:, None].expand(-1, D))
+        g = torch.tensor([-1.0, 1.0]).repeat(cfg.depth, 1)
+        for b in skip_blocks:
+            g[b] = torch.tensor([1.0, -1.0])
+        model.block_skip_gating.data.copy_(g.to(dev))
 
 
 def kernel_roofline(tr, args, iters=30):
@@ -135,12 +167,19 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
-    from uvc_amd.stage1 import Stage1Trainer, default_args
     torch.manual_seed(730)
-    a = default_args(model_type=args.model_type, precision=args.precision, train_batch_size=args.batch, local_rank=local)
-    tr = Stage1Trainer(a, device=f"cuda:{local}", distributed=world > 1)
-    pruned_state(tr)
-    tr.begin_epoch(a.warmup_epochs + 1)                 # UVC-train phase (post warm-up), SURVEY.md §8d
+    if args.stage == 2:
+        from uvc_amd.post_train import Stage2Trainer, default_args
+        a = default_args(model_type=args.model_type, precision=args.precision, train_batch_size=args.batch, local_rank=local)
+        tr = Stage2Trainer(a, device=f"cuda:{local}", distributed=world > 1, world_size=world)
+        stage2_checkpoint_state(tr.model)
+        tr.begin_epoch(a.warmup_epochs + 1)
+    else:
+        from uvc_amd.stage1 import Stage1Trainer, default_args
+        a = default_args(model_type=args.model_type, precision=args.precision, train_batch_size=args.batch, local_rank=local)
+        tr = Stage1Trainer(a, device=f"cuda:{local}", distributed=world > 1)
+        pruned_state(tr)
+        tr.begin_epoch(a.warmup_epochs + 1)             # UVC-train phase (post warm-up), SURVEY.md §8d
     dev = torch.device("cuda", local)
     g = torch.Generator(device=dev).manual_seed(730 + rank)
     x = torch.randn(args.batch, 3, a.img_size, a.img_size, device=dev, generator=g)
@@ -168,18 +207,26 @@ def main():
     if rank == 0:
         imgs = world * args.batch * args.steps / dt
         gf = GFLOP_PER_IMG.get(args.model_type)
-        line = {"metric": "images/sec UVC Stage-1 step, DeiT-Tiny budget=0.5", "value": round(imgs, 1), "unit": "images/sec",
+        metric = "images/sec UVC Stage-1 step, DeiT-Tiny budget=0.5" if args.stage == 1 else \
+                 "images/sec UVC Stage-2 masked fine-tune step, DeiT-Tiny (SURVEY 8 f-1, not the headline)"
+        line = {"metric": metric, "value": round(imgs, 1), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-                "config": {"workload": f"{args.model_type} Stage-1 UVC-train step, budget 0.5, per-GPU batch {args.batch}, "
-                                       f"224x224x3 synthetic, soft distillation alpha 0.1, block gating on",
+                "config": {"workload": (f"{args.model_type} Stage-1 UVC-train step, budget 0.5, per-GPU batch {args.batch}, "
+                                        f"224x224x3 synthetic, soft distillation alpha 0.1, block gating on") if args.stage == 1 else
+                                       (f"{args.model_type} Stage-2 masked fine-tune step, per-GPU batch {args.batch}, masks at the "
+                                        f"budget-0.5 operating point, 2 of 12 blocks hard-skipped, soft distillation alpha 0.1"),
                            "global_batch": world * args.batch, "parallelism": f"dp{world}"},
                 "step_tflops_per_gpu": round(imgs / world * gf / 1e3, 2) if gf else None,
                 "step_frac_of_bf16_mfma_peak": round(imgs / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,
-                "final_loss": round(loss, 4), "cur_resource": round(float(out["cur"]), 4)}
+                "final_loss": round(loss, 4)}
+        if args.stage == 1:
+            line["cur_resource"] = round(float(out["cur"]), 4)
+        else:   # Stage-2 FLOPs per image: teacher 1x forward, student (fwd + bwd) only over the blocks that run
+            line.pop("step_tflops_per_gpu"); line.pop("step_frac_of_bf16_mfma_peak")
         line["roofline"] = kernel_roofline(tr, args)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.stage == 1:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
     if world > 1:

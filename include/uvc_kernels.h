@@ -130,6 +130,8 @@ typedef struct uvc_adamw_args {
   int64_t n;
   float lr, beta1, beta2, eps, weight_decay, max_norm;
   int32_t step;          /* this segment's 1-based step count (bias correction) */
+  const uint8_t* flags;  /* optional device [n]: bit 0 = weight decay applies to this element (timm add_weight_decay groups,
+                            post_train.py:299), bit 1 = frozen: leave p/m/v untouched (parameter whose .grad is None) */
 } uvc_adamw_args;
 int uvc_adamw_step(const uvc_adamw_args* args, void* stream);
 /* g *= clip coefficient (so later readers see what clip_grad_norm_ left in .grad; uvc_optimizer.py:90 reads it). */
@@ -165,6 +167,9 @@ int uvc_patch_topk_mask_bwd(const float* dmask, const float* ysoft, const float*
 /* X[row,:] += row_weight[row] * w[:]   (X of type T, or float32 when x_is_f32) */
 int uvc_add_outer(void* X, const float* row_weight, const float* w, int32_t rows, int32_t D, int32_t dtype, int32_t x_is_f32, void* stream);
 int uvc_colsum_blocks(int32_t M);
+/* params[i] *= mask[i] over a flat parameter buffer: the Stage-2 `m.weight.data *= m.mask` for every module with a
+ * mask buffer (post_train.py:343-346); mask is 1 where no module mask covers the element (biases, tokens). */
+int uvc_apply_masks(float* params, const float* mask, int64_t n, void* stream);
 /* float32 -> bf16 copy and transposed copy of a [R,C] matrix (weight shadows for the GEMMs). */
 int uvc_cast_transpose(const float* W, int32_t R, int32_t C, void* w_bf16, void* wt, int32_t dtype, void* stream);
 /* the same for up to 64 matrices in one launch: srcs[i] = element offset into params, ws[i]/wts[i] = element

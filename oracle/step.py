@@ -61,7 +61,8 @@ class AdamWState:
     t: Dict[str, int] = field(default_factory=dict)
 
 
-def adamw_step(opt: AdamWState, params: Dict[str, torch.Tensor], grads: Dict[str, Optional[torch.Tensor]], lr: float):
+def adamw_step(opt: AdamWState, params: Dict[str, torch.Tensor], grads: Dict[str, Optional[torch.Tensor]], lr: float,
+               wd_of: Optional[Dict[str, float]] = None):
     """torch.optim.AdamW(lr, betas=(.9,.999), eps=1e-8, weight_decay=.05) (joint_train.py:271,429):
     decoupled decay on every parameter that HAS a gradient; parameters whose grad is None are
     skipped entirely (gumbel.*, attn/mlp_skip_gating, block_skip_gating during warm-up)."""
@@ -75,7 +76,7 @@ def adamw_step(opt: AdamWState, params: Dict[str, torch.Tensor], grads: Dict[str
             opt.t[name] = 0
         opt.t[name] += 1
         t = opt.t[name]
-        p.mul_(1 - lr * opt.wd)
+        p.mul_(1 - lr * (opt.wd if wd_of is None else wd_of[name]))      # wd_of: per-parameter groups (Stage-2)
         opt.m[name].lerp_(g, 1 - opt.b1)
         opt.v[name].mul_(opt.b2).addcmul_(g, g, value=1 - opt.b2)
         bc1 = 1 - opt.b1 ** t

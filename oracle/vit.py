@@ -198,6 +198,7 @@ def forward(params: Dict[str, torch.Tensor], cfg: VitConfig, flags: GateFlags, x
         toks.append(params["dist_token"].expand(B, -1, -1))
     h = torch.cat(toks + [t], dim=1) + params["pos_embed"]            # :462-471
     distribs = []
+    skipped = []
     accum = 0
     for i in range(cfg.depth):
         p = f"blocks.{i}."
@@ -223,6 +224,8 @@ def forward(params: Dict[str, torch.Tensor], cfg: VitConfig, flags: GateFlags, x
             g = params["block_skip_gating"][i]
             if g[1] > g[0]:
                 h = blk(h)
+            else:
+                skipped.append(i)                                      # tmp_macs stays [] (:477,500)
         accum = accum + h
     if flags.enable_jumping:
         h = accum
@@ -235,6 +238,8 @@ def forward(params: Dict[str, torch.Tensor], cfg: VitConfig, flags: GateFlags, x
     if record is not None:
         record["distribs"] = distribs
     macs = mac_table(cfg, B)
+    if skipped:
+        macs = (macs[0], [[] if i in skipped else m for i, m in enumerate(macs[1])])
     if flags.training:
         return (o, od), macs
     return (o + od) / 2, macs

@@ -111,3 +111,53 @@ def initial_state(r: dict, L: int, H: int, hd: int, F: int):
         rr[-1, -1] = 0.0
         y[0, 0] = 0.0
     return s, rr, y, p, z
+
+
+# ----------------------------------------------------------------------------------------------------
+# Stage-2 (post_train.py) scenarios: masked fine-tune steps from a pruned state with hard-skipped blocks.
+STAGE2 = {
+    "stage2_micro": dict(model="micro", batch=4, steps=3, seed=41, skip_blocks=[], epoch_of_step=[0, 1, 1]),
+    "stage2_micro_skip": dict(model="micro", batch=4, steps=3, seed=42, skip_blocks=[1], epoch_of_step=[1, 1, 2]),
+    "stage2_micro_none": dict(model="micro", batch=4, steps=2, seed=43, skip_blocks=[0], epoch_of_step=[2, 2],
+                              distillation_type="none"),
+    "stage2_micro_deit": dict(model="micro_dist", batch=4, steps=2, seed=44, skip_blocks=[], epoch_of_step=[1, 3]),
+    # BASELINE config 1 shape: DeiT-Tiny, batch 8, two blocks skipped
+    "stage2_tiny8": dict(model="deit_tiny", batch=8, steps=2, seed=740, skip_blocks=[3, 7], epoch_of_step=[1, 1]),
+}
+
+# run_post_train.sh + post_train.py defaults; learning_rate is chosen so the batch-scaled lr (lr*batch/512) is ~1e-3
+# and three steps move the weights measurably; one warm-up epoch so both schedule branches are hit
+STAGE2_DEFAULTS = dict(learning_rate=0.064, weight_decay=0.05, max_grad_norm=1.0, epochs=10, warmup_epochs=1,
+                       warmup_lr=1e-6, min_lr=1e-5, decay_rate=0.1, opt_eps=1e-8, distillation_type="soft",
+                       distillation_alpha=0.1, distillation_tau=1.0)
+
+
+def stage2_recipe(name: str) -> dict:
+    r = dict(STAGE2_DEFAULTS)
+    r.update(STAGE2[name])
+    r["name"] = name
+    r["model_cfg"] = dict(MODELS[r["model"]])
+    return r
+
+
+def stage2_masks(r: dict, L: int, H: int, hd: int, F: int):
+    """Structured masks as prune_w_mask leaves them (uvc_utils.py:376-401) and the gate logits of a finished
+    Stage-1: per layer a 0/1 keep-vector over attn.proj input columns (whole heads + columns inside the kept heads)
+    and over the MLP hidden units (fc2 input columns = fc1 output rows); block_skip_gating = [1,-1] for skipped
+    blocks, [-1,1] otherwise."""
+    rs = np.random.RandomState(r["seed"] + 3000)
+    keep_proj = np.ones((L, H * hd), np.float32)
+    keep_hidden = np.ones((L, F), np.float32)
+    for l in range(L):
+        dead_heads = rs.choice(H, size=rs.randint(0, H), replace=False)
+        for h in range(H):
+            if h in dead_heads:
+                keep_proj[l, h * hd:(h + 1) * hd] = 0
+            else:
+                k = rs.randint(0, hd // 2)
+                keep_proj[l, h * hd + rs.choice(hd, size=k, replace=False)] = 0
+        keep_hidden[l, rs.choice(F, size=rs.randint(1, F // 2), replace=False)] = 0
+    gate = np.tile(np.array([-1.0, 1.0], np.float32), (L, 1))
+    for b in r["skip_blocks"]:
+        gate[b] = [1.0, -1.0]
+    return keep_proj, keep_hidden, gate

@@ -91,3 +91,40 @@ def split_draws(r, gold, step, L):
     e2 = draws.pop(0) if (gum and not r["warmup"]) else None
     assert not draws, f"unconsumed draws: {len(draws)}"
     return model, e1, e2
+
+
+# ----------------------------------------------------------------------------------------------------- Stage-2
+def stage2_state(r):
+    """The Stage-1 checkpoint a Stage-2 scenario starts from, as a state_dict of torch tensors (weights from the
+    portable recipe, structured masks, gate logits), plus the teacher's."""
+    cfg = vit_config(r)
+    m = r["model_cfg"]
+    params = OV.init_params_numpy(cfg, r["seed"], 0, weight_gain=m["weight_gain"])
+    teacher = OV.init_params_numpy(cfg, r["seed"] + 500, 0, weight_gain=m["weight_gain"])
+    keep_proj, keep_hidden, gate = SC.stage2_masks(r, cfg.depth, cfg.num_heads, cfg.head_dim, cfg.hidden)
+    params["block_skip_gating"] = torch.from_numpy(gate.copy())
+    D = cfg.embed_dim
+    masks = {}
+    for l in range(cfg.depth):
+        masks[f"blocks.{l}.attn.proj.weight"] = torch.from_numpy(keep_proj[l])[None, :].expand(D, -1).clone()
+        masks[f"blocks.{l}.mlp.fc2.weight"] = torch.from_numpy(keep_hidden[l])[None, :].expand(D, -1).clone()
+        masks[f"blocks.{l}.mlp.fc1.weight"] = torch.from_numpy(keep_hidden[l])[:, None].expand(-1, D).clone()
+    return cfg, params, masks, teacher
+
+
+def stage2_hyper(r):
+    from oracle import stage2 as O2
+    return O2.Stage2Hyper(learning_rate=r["learning_rate"], train_batch_size=r["batch"], weight_decay=r["weight_decay"],
+                          max_grad_norm=r["max_grad_norm"], epochs=r["epochs"], warmup_epochs=r["warmup_epochs"],
+                          warmup_lr=r["warmup_lr"], min_lr=r["min_lr"], decay_rate=r["decay_rate"], opt_eps=r["opt_eps"],
+                          distillation_type=r["distillation_type"], distillation_alpha=r["distillation_alpha"],
+                          distillation_tau=r["distillation_tau"])
+
+
+def build_oracle_stage2(name):
+    from oracle import stage2 as O2
+    r = SC.stage2_recipe(name)
+    cfg, params, masks, teacher = stage2_state(r)
+    S = O2.Stage2(cfg=cfg, params=params, masks=masks, teacher=teacher if r["distillation_type"] != "none" else None,
+                  hp=stage2_hyper(r))
+    return r, S

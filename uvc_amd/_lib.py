@@ -74,7 +74,7 @@ class uvc_loss_args(C.Structure):
 class uvc_adamw_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("p", "g", "m", "v", "p_shadow", "sq", "gnorm_out")] + [("n", C.c_int64)] + \
                [(n, C.c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "max_norm")] + \
-               [("step", C.c_int32)]
+               [("step", C.c_int32), ("flags", C.c_void_p)]
 
 
 UVC_F32, UVC_BF16 = 0, 1
@@ -116,6 +116,7 @@ _SIGNATURES = {
     "uvc_patch_topk_mask_bwd": [VP, VP, VP, VP, I32, I32, F32, VP],
     "uvc_add_outer": [VP, VP, VP, I32, I32, I32, I32, VP],
     "uvc_colsum_blocks": [I32],
+    "uvc_apply_masks": [VP, VP, I64, VP],
     "uvc_cast_transpose": [VP, I32, I32, VP, VP, I32, VP],
     "uvc_cast_transpose_multi": [VP, VP, I32, VP, VP, VP, VP, VP, I32, VP],
     "uvc_gate_distrib": [VP, VP, VP, I32, I32, F32, VP],

@@ -310,6 +310,22 @@ __global__ __launch_bounds__(256) void k_add_outer(T* __restrict__ X, const floa
   }
 }
 
+// Stage-2 `m.weight.data *= m.mask` over the whole flat parameter buffer (post_train.py:343-346)
+__global__ __launch_bounds__(256) void k_apply_masks(float* __restrict__ p, const float* __restrict__ mask, int64_t n) {
+  const int64_t n4 = n >> 2;
+  f32x4* p4 = reinterpret_cast<f32x4*>(p);
+  const f32x4* m4 = reinterpret_cast<const f32x4*>(mask);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 m = m4[i];
+    if (m[0] == 1.0f && m[1] == 1.0f && m[2] == 1.0f && m[3] == 1.0f) continue;      // unmasked: no write
+    f32x4 v = p4[i];
+    v[0] *= m[0]; v[1] *= m[1]; v[2] *= m[2]; v[3] *= m[3];
+    p4[i] = v;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) p[i] *= mask[i];
+}
+
 inline int grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -410,6 +426,14 @@ extern "C" int uvc_add_outer(void* X, const float* row_weight, const float* w, i
   if (!X || !row_weight || !w || rows <= 0 || D <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_add_outer: bad argument");
   if (dtype == UVC_F32 || x_is_f32) k_add_outer<float><<<grid_for((int64_t)rows * D), 256, 0, (hipStream_t)stream>>>((float*)X, row_weight, w, rows, D);
   else k_add_outer<bf16_t><<<grid_for((int64_t)rows * D), 256, 0, (hipStream_t)stream>>>((bf16_t*)X, row_weight, w, rows, D);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_apply_masks(float* params, const float* mask, int64_t n, void* stream) {
+  if (!params || !mask || n <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_apply_masks: bad argument");
+  if ((((uintptr_t)params | (uintptr_t)mask) & 15) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_apply_masks: buffers must be 16-byte aligned");
+  k_apply_masks<<<grid_for(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(params, mask, n);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void k_sqnorm_final(const float* partial, int 
   if (threadIdx.x == 0) sq[0] = (accumulate ? sq[0] : 0.f) + s;
 }
 
-template <bool SHADOW>
+// FLAGS: per-element byte, bit 0 = apply weight decay, bit 1 = frozen (no gradient reached it: untouched, like a
+// torch parameter whose .grad is None).  Without flags every element decays and updates.
+template <bool SHADOW, bool FLAGS>
 __global__ __launch_bounds__(256) void k_adamw(uvc_adamw_args a, float bc1, float bc2_sqrt) {
   const float total = sqrtf(a.sq[0]);
   const float coef = fminf(a.max_norm / (total + 1e-6f), 1.0f);
@@ -116,12 +118,18 @@ __global__ __launch_bounds__(256) void k_adamw(uvc_adamw_args a, float bc1, floa
   f32x4* m4 = reinterpret_cast<f32x4*>(a.m);
   f32x4* v4 = reinterpret_cast<f32x4*>(a.v);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    uint32_t fl = 0x01010101u;
+    if (FLAGS) {
+      fl = reinterpret_cast<const uint32_t*>(a.flags)[i];
+      if ((fl & 0x02020202u) == 0x02020202u) continue;
+    }
     f32x4 p = p4[i], m = m4[i], v = v4[i];
     const f32x4 g0 = g4[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+      if (FLAGS && ((fl >> (8 * e)) & 2u)) continue;
       const float g = g0[e] * coef;
-      p[e] *= decay;
+      p[e] *= (!FLAGS || ((fl >> (8 * e)) & 1u)) ? decay : 1.0f;
       m[e] = m[e] + w1 * (g - m[e]);
       v[e] = v[e] * a.beta2 + w2 * g * g;
       const float denom = sqrtf(v[e]) / bc2_sqrt + a.eps;
@@ -135,8 +143,10 @@ __global__ __launch_bounds__(256) void k_adamw(uvc_adamw_args a, float bc1, floa
   }
   if (blockIdx.x == 0) {
     for (int64_t i = (n4 << 2) + threadIdx.x; i < a.n; i += 256) {
+      const uint32_t f1 = FLAGS ? a.flags[i] : 1u;
+      if (f1 & 2u) continue;
       const float g = a.g[i] * coef;
-      float p = a.p[i] * decay;
+      float p = a.p[i] * ((f1 & 1u) ? decay : 1.0f);
       const float m = a.m[i] + w1 * (g - a.m[i]);
       const float v = a.v[i] * a.beta2 + w2 * g * g;
       p = p - step_size * (m / (sqrtf(v) / bc2_sqrt + a.eps));
@@ -191,8 +201,11 @@ extern "C" int uvc_adamw_step(const uvc_adamw_args* p, void* stream) {
   int nb = (int)((p->n / 4 + 255) / 256);
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
-  if (p->p_shadow) k_adamw<true><<<nb, 256, 0, st>>>(*p, (float)bc1, (float)sqrt(bc2));
-  else k_adamw<false><<<nb, 256, 0, st>>>(*p, (float)bc1, (float)sqrt(bc2));
+  if (p->flags && ((uintptr_t)p->flags & 3) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_adamw_step: flags must be 4-byte aligned");
+  if (p->p_shadow && p->flags) k_adamw<true, true><<<nb, 256, 0, st>>>(*p, (float)bc1, (float)sqrt(bc2));
+  else if (p->p_shadow) k_adamw<true, false><<<nb, 256, 0, st>>>(*p, (float)bc1, (float)sqrt(bc2));
+  else if (p->flags) k_adamw<false, true><<<nb, 256, 0, st>>>(*p, (float)bc1, (float)sqrt(bc2));
+  else k_adamw<false, false><<<nb, 256, 0, st>>>(*p, (float)bc1, (float)sqrt(bc2));
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

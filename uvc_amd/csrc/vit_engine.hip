@@ -332,16 +332,21 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     TRY(nt(c, w.patches, 0, wmat(c, o.patch_w, c.soff.patch_w), w.pe, 1, rows_p, d.D, d.K0, UVC_EPI_BIAS, P + o.patch_b));
   }
   if (fse < 2) return UVC_OK;
-  float* x0 = w.blk[0].x;
+  // hard block skip (:496-500).  In training the input of a block that runs must sit in its own w.blk[l].x (backward
+  // reads it there), so the buffer chain hops over skipped blocks: producer -> x of the next block that runs.
+  auto runs = [&](int l) { return io->gate_d || !io->run_block || io->run_block[l] != 0; };
+  auto next_in = [&](int l) -> float* {
+    for (int j = l; j < d.L; ++j)
+      if (runs(j)) return w.blk[j].x;
+    return w.xL;
+  };
+  float* x0 = io->training ? next_in(0) : w.blk[0].x;
   TRY(uvc_assemble_tokens(w.pe, P + o.cls_token, d.ntok == 2 ? P + o.dist_token : nullptr, P + o.pos_embed, io->patch_mask, x0, d.B, d.np,
                           d.D, d.ntok, stream));
   float* xin = x0;
   for (int l = 0; l < d.L; ++l) {
-    float* xout = io->training ? (l + 1 < d.L ? w.blk[l + 1].x : w.xL) : (xin == w.blk[0].x ? w.xL : w.blk[0].x);
-    if (!io->gate_d && io->run_block && !io->run_block[l]) {        // hard skip (:496-500)
-      if (io->training) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit_forward: hard block skip is an inference path");
-      continue;
-    }
+    if (!runs(l)) continue;
+    float* xout = io->training ? next_in(l + 1) : (xin == w.blk[0].x ? w.xL : w.blk[0].x);
     const BlockBufs& b = w.blk[l];
     const int64_t* q = o.blk[l];
     TRY(ln_fwd(c, xin, q[0], q[1], b.h1, b.mean1, b.rstd1, d.M, 1, d.D));
@@ -405,6 +410,7 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   for (int l = d.L - 1; l >= 0; --l) {
     const int stage = d.L - l;
     if (stage < sb || stage >= se) continue;
+    if (!io->gate_d && io->run_block && !io->run_block[l]) continue;   // skipped in forward: no gradient reaches its parameters
     const BlockBufs& b = w.blk[l];
     const int64_t* q = o.blk[l];
     const float* g0 = io->gate_d ? io->gate_d + 2 * l : nullptr;       // d0

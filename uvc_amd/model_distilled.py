@@ -204,6 +204,9 @@ class DistilledVisionTransformer(nn.Module):
         self._shadow = None
         self._last = None
         self._run_block_host = None
+        self._run_block_ver = -1
+        self._flat_mask = None
+        self._skip_grads_clean = False
         self.exp_source = lambda shape: torch.empty(shape, device=self._flat.device, dtype=torch.float32).exponential_()
         self.to(dev)
 
@@ -258,6 +261,7 @@ class DistilledVisionTransformer(nn.Module):
         self._shadow = torch.zeros(self._soff.n_total * tsz, device=device, dtype=torch.uint8)
         self._ws = {}
         self._shadow_fresh = False
+        self._run_block_host = None
 
     def _apply(self, fn, *a, **k):
         super()._apply(fn, *a, **k)
@@ -287,8 +291,12 @@ class DistilledVisionTransformer(nn.Module):
             dead |= {o.gumbel_w, o.gumbel_b}
         if not self.block_skip_gating.requires_grad or self._gate_mode() == 0:
             dead.add(o.gate)
+        skipped = self.skipped_block_ranges()
         for p, off in self._slots():
             if off in dead:
+                continue
+            if any(a <= off < a + n for a, n in skipped):
+                p.grad = None
                 continue
             if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
                 p.grad = self._flat_grad[off:off + p.numel()].view(p.shape)
@@ -296,9 +304,42 @@ class DistilledVisionTransformer(nn.Module):
     def mark_weights_changed(self):
         self._shadow_fresh = False
 
+    def no_weight_decay(self):
+        """model_distilled.py:330-331 (read by timm's create_optimizer in Stage-2)."""
+        return {"pos_embed", "cls_token", "dist_token"}
+
+    # -- Stage-2 masks ---------------------------------------------------------------------------------
+    def _mask_flat(self):
+        """One float32 buffer congruent with the flat parameter buffer: every module's ``mask`` buffer
+        (joint_train.py:169-171 / post_train.py:155-157) is a view at its weight's offset, 1 elsewhere.  Mask buffers
+        that were registered or moved after the fact are adopted (copied in and re-pointed) here."""
+        if self._flat_mask is None or self._flat_mask.device != self._flat.device:
+            self._flat_mask = torch.ones(self._off.n_total, device=self._flat.device, dtype=torch.float32)
+        base = self._flat_mask.data_ptr()
+        off_of = {id(p): off for p, off in self._slots()}
+        for _, m in self.named_modules():
+            mask = m._buffers.get("mask") if hasattr(m, "_buffers") else None
+            w = getattr(m, "weight", None)
+            if mask is None or w is None or id(w) not in off_of:
+                continue
+            off, k = off_of[id(w)], w.numel()
+            if mask.data_ptr() != base + 4 * off:
+                if mask.numel() != k:
+                    raise L.UvcHipError("mask buffer does not match its weight")
+                self._flat_mask[off:off + k].copy_(mask.reshape(-1).to(device=self._flat.device, dtype=torch.float32))
+                m._buffers["mask"] = self._flat_mask[off:off + k].view(w.shape)
+        return self._flat_mask
+
+    def apply_masks(self):
+        """``for m in modules: m.weight.data *= m.mask`` (post_train.py:343-346) as one launch over the flat buffer."""
+        self._check_flat()
+        ops.apply_masks(self._flat, self._mask_flat())
+        self.mark_weights_changed()
+
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self.mark_weights_changed()
+        self._run_block_host = None
         return r
 
     # -- engine calls ---------------------------------------------------------------------------------
@@ -374,12 +415,7 @@ class DistilledVisionTransformer(nn.Module):
             else:
                 mode = 2
         else:                                                          # :496-500 hard skip by logit order
-            if self._run_block_host is None or not self.frozen_weights:
-                g = self.block_skip_gating.detach().cpu()
-                self._run_block_host = (C.c_int32 * cfg.depth)(*[int(g[i, 1] > g[i, 0]) for i in range(cfg.depth)])
-            run_block = self._run_block_host
-            if training and not all(run_block):
-                raise NotImplementedError("hard block skipping inside a training forward is the Stage-2 path")
+            run_block = self._hard_run_blocks()
         io.x, io.logits, io.logits_dist = L.ptr(x), L.ptr(logits), L.ptr(logits_dist)
         io.run_block = run_block if run_block is not None else None
         # ---- patch gating (model_distilled.py:434-456): the mask needs the patch embedding, so the forward is cut there
@@ -409,10 +445,36 @@ class DistilledVisionTransformer(nn.Module):
             ops.gate_distrib(self.block_skip_gating.data, e, gate_d, cfg.depth, mode, float(self.eps))
         io.gate_d = L.ptr(gate_d)
         L.check(lib.uvc_vit_forward(C.byref(cfg), C.byref(io), stream), "uvc_vit_forward")
-        self._last = dict(x=x, gate_d=gate_d, patch=patch, B=B) if training else None
+        self._last = dict(x=x, gate_d=gate_d, patch=patch, B=B, run_block=run_block) if training else None
         self.last_distrib = gate_d
         self.last_patch_mask = patch["mask"] if patch else None
         return logits, logits_dist
+
+    def _hard_run_blocks(self):
+        """Host 0/1 list of the blocks the hard skip keeps (`block_skip_gating[i][1] > [i][0]`, :496-500).  The logits
+        live on the device; the host copy is refreshed only when they may have changed (in-place edits bump the
+        tensor version, FusedAdamW / load_state_dict / re-flattening drop the cache), so a Stage-2 step never syncs."""
+        ver = self.block_skip_gating._version
+        if self._run_block_host is None or self._run_block_ver != ver:
+            g = self.block_skip_gating.detach().cpu()
+            depth = self._cfg.depth
+            self._run_block_host = (C.c_int32 * depth)(*[int(g[i, 1] > g[i, 0]) for i in range(depth)])
+            self._run_block_ver = ver
+            self._skip_grads_clean = False
+        return self._run_block_host
+
+    def skipped_block_ranges(self):
+        """(offset, count) in the flat buffers of the parameters of hard-skipped blocks (empty with block gating on)."""
+        if self.enable_block_gating:
+            return []
+        run = self._hard_run_blocks()
+        o, depth = self._off, self._cfg.depth
+        out = []
+        for l in range(depth):
+            if not run[l]:
+                end = o.blk[l + 1][0] if l + 1 < depth else o.norm_w
+                out.append((o.blk[l][0], end - o.blk[l][0]))
+        return out
 
     def _patch_backward(self, st, dmask):
         """Gradients of the patch-gating parameters from d(mask) (model_distilled.py:434-456)."""
@@ -446,6 +508,13 @@ class DistilledVisionTransformer(nn.Module):
             d_logits_dist = d_logits_dist.contiguous()
             io.d_logits_dist = L.ptr(d_logits_dist)
         io.gate_d = L.ptr(st["gate_d"])
+        io.run_block = st["run_block"] if st["run_block"] is not None else None
+        if st["run_block"] is not None and not self._skip_grads_clean:
+            # hard-skipped blocks get no gradient (.grad stays None); their slice of the flat gradient buffer is zeroed
+            # once so the global-norm pass over the whole buffer sees nothing there
+            for off, n in self.skipped_block_ranges():
+                self._flat_grad[off:off + n].zero_()
+            self._skip_grads_clean = True
         if self.two_stream_backward:
             if self._wgrad_stream is None:
                 self._wgrad_stream = torch.cuda.Stream(device=self._flat.device)
@@ -490,6 +559,9 @@ class DistilledVisionTransformer(nn.Module):
         if self.enable_jumping:
             raise NotImplementedError("enable_jumping is off on the UVC hot path")
         macs = self.macs(x.shape[0])
+        if not self.enable_block_gating:                      # skipped blocks report an empty MAC list (:496-500)
+            run = self._hard_run_blocks()
+            macs = (macs[0], [m if run[l] else [] for l, m in enumerate(macs[1])])
         if self.training and torch.is_grad_enabled():
             out = _VitFunction.apply(self, x, self.cls_token, tau, number)
             return (out if self.num_tokens == 2 else (out, out)), macs       # x_dist = x without the dist token (:523-524)

@@ -145,12 +145,13 @@ def grad_sqnorm(g, partial, sq, accumulate=False, n=None):
 
 
 def adamw_step(p, g, m, v, sq, *, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, max_norm=1.0,
-               p_shadow=None, gnorm_out=None, n=None):
-    _chk(p, g, m, v, sq, p_shadow, gnorm_out)
+               p_shadow=None, gnorm_out=None, n=None, flags=None):
+    _chk(p, g, m, v, sq, p_shadow, gnorm_out, flags)
     a = L.uvc_adamw_args()
     a.p, a.g, a.m, a.v, a.p_shadow, a.sq, a.gnorm_out = (L.ptr(t) for t in (p, g, m, v, p_shadow, sq, gnorm_out))
     a.n = n if n is not None else p.numel()
     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.max_norm, a.step = lr, beta1, beta2, eps, weight_decay, max_norm, step
+    a.flags = L.ptr(flags)
     L.check(L.lib().uvc_adamw_step(C.byref(a), L.cur_stream()), "uvc_adamw_step")
 
 
@@ -216,6 +217,11 @@ def patch_topk_mask_bwd(dmask, ysoft, psoft, dscores, B, P, tau):
     _chk(dmask, ysoft, psoft, dscores)
     L.check(L.lib().uvc_patch_topk_mask_bwd(L.ptr(dmask), L.ptr(ysoft), L.ptr(psoft), L.ptr(dscores), B, P, tau, L.cur_stream()),
             "uvc_patch_topk_mask_bwd")
+
+
+def apply_masks(params, mask):
+    _chk(params, mask)
+    L.check(L.lib().uvc_apply_masks(L.ptr(params), L.ptr(mask), params.numel(), L.cur_stream()), "uvc_apply_masks")
 
 
 def add_outer(X, row_weight, w, rows, D, dtype):

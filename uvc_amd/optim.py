@@ -60,8 +60,17 @@ def _live_segments(model):
     return segs
 
 
+NO_DECAY, DECAY, FROZEN = 0, 1, 2      # uvc_adamw_args.flags bits
+
+
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_grad_norm=None):
+    """``filter_bias_and_bn=True`` reproduces timm's ``add_weight_decay`` grouping used by Stage-2
+    (post_train.py:299 -> timm.optim.create_optimizer): 1-D tensors, ``*.bias`` and the names in
+    ``model.no_weight_decay()`` get no decay.  Parameters of hard-skipped blocks (no gradient) are frozen
+    through the same per-element flag array; without either, no flag array is used."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_grad_norm=None,
+                 filter_bias_and_bn=False):
         if not hasattr(model, "_flat"):
             raise L.UvcHipError("FusedAdamW needs a uvc_amd DistilledVisionTransformer (flat parameter buffer)")
         model._check_flat()
@@ -73,6 +82,29 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(n, device=dev)
         self.exp_avg_sq = torch.zeros(n, device=dev)
         self.steps = {"main": 0}
+        self.filter_bias_and_bn = bool(filter_bias_and_bn and weight_decay)
+        self._flags = None
+        self._flags_key = None
+
+    def _element_flags(self):
+        """uint8 flag per element of the flat buffer (or None when every element decays and trains)."""
+        m = self.model
+        skipped = tuple(m.skipped_block_ranges())
+        if not self.filter_bias_and_bn and not skipped:
+            return None
+        if self._flags is None or self._flags_key != skipped:
+            fl = torch.full((m._off.n_total,), DECAY, dtype=torch.uint8)
+            if self.filter_bias_and_bn:
+                skip = m.no_weight_decay() if hasattr(m, "no_weight_decay") else set()
+                off_of = {id(p): off for p, off in m._slots()}
+                for name, p in m.named_parameters():
+                    if p.ndim == 1 or name.endswith(".bias") or name in skip:
+                        off = off_of[id(p)]
+                        fl[off:off + p.numel()] = NO_DECAY
+            for off, k in skipped:
+                fl[off:off + k] |= FROZEN
+            self._flags, self._flags_key = fl.to(m._flat.device), skipped
+        return self._flags
 
     def zero_grad(self, set_to_none: bool = True):
         """Gradients are overwritten by the next backward (beta = 0), so nothing has to be cleared; keeps
@@ -99,16 +131,34 @@ class FusedAdamW(torch.optim.Optimizer):
         common = dict(lr=float(g["lr"]), beta1=b1, beta2=b2, eps=g["eps"], weight_decay=g["weight_decay"], max_norm=float(max_norm))
         self.steps["main"] += 1
         n = m._off.n_main
+        flags = self._element_flags()
         ops.adamw_step(m._flat[:n], m._flat_grad[:n], self.exp_avg[:n], self.exp_avg_sq[:n], st["sq"], step=self.steps["main"],
-                       gnorm_out=st["gnorm"], **common)
+                       gnorm_out=st["gnorm"], flags=flags[:n] if flags is not None else None, **common)
         for name, p, off in _small_tensors(m):
             if p.grad is None:
                 continue
             self.steps[name] = self.steps.get(name, 0) + 1
             k = p.numel()
             ops.adamw_step(m._flat[off:off + k], m._flat_grad[off:off + k], self.exp_avg[off:off + k],
-                           self.exp_avg_sq[off:off + k], st["sq"], step=self.steps[name], **common)
+                           self.exp_avg_sq[off:off + k], st["sq"], step=self.steps[name],
+                           flags=flags[off:off + k] if flags is not None else None, **common)
+            if name == "gate":
+                m._run_block_host = None            # the hard-skip decision reads these logits
             if name == "gate" and max_norm != float("inf"):
                 ops.scale_by_clip(m._flat_grad[off:off + k], st["sq"], float(max_norm))   # uvc_optimizer.py:90 reads the clipped grad
         m.mark_weights_changed()
         return None
+
+
+def create_optimizer(args, model, filter_bias_and_bn=True):
+    """timm.optim.create_optimizer(args, model) as Stage-2 calls it (post_train.py:299; --opt adamw, :456-467): AdamW
+    with lr=args.lr, eps=args.opt_eps, betas=args.opt_betas (if given), weight decay only on the >=2-D weights."""
+    opt = str(getattr(args, "opt", "adamw")).lower()
+    if opt != "adamw":
+        raise NotImplementedError(f"--opt {opt}: the HIP optimizer is AdamW (the reference's Stage-2 default)")
+    kw = dict(lr=args.lr, weight_decay=args.weight_decay)
+    if getattr(args, "opt_eps", None) is not None:
+        kw["eps"] = args.opt_eps
+    if getattr(args, "opt_betas", None) is not None:
+        kw["betas"] = tuple(args.opt_betas)
+    return FusedAdamW(model, filter_bias_and_bn=filter_bias_and_bn, **kw)

@@ -1,0 +1,182 @@
+"""Stage-2 masked fine-tune on the MI355X engine (mirror of ``UVC/post_train.py``: ``setup`` :135-186, the
+checkpoint hand-over :676-683 and the loop body of ``post_training`` :270-403).
+
+Stage-2 consumes the Stage-1 checkpoint (bare state_dict with ``mask`` buffers and the learned
+``block_skip_gating`` logits) and fine-tunes the pruned network: every step starts with
+``weight *= mask`` for every module that carries a mask, the forward hard-skips the blocks whose gate
+logits say so (model_distilled.py:496-500, in training mode too), the gate logits are frozen, and the
+optimiser / schedule come from timm's factories (AdamW with no decay on 1-D tensors, biases and the
+tokens; cosine schedule stepped once per epoch on a learning rate scaled by batch * world / 512).
+
+``Stage2Trainer`` is what the CLI (``python -m uvc_amd.post_train``), ``bench.py --stage 2`` and the
+parity tests drive.  No CPU fallback: everything numeric is a kernel of libuvc_hip.so.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+from argparse import Namespace
+
+import torch
+
+from .ddp import DistributedDataParallel
+from .joint_train import count_mask, save_model
+from .losses import DistillationLoss, SoftTargetCrossEntropy
+from .model_distilled import DistilledVisionTransformer
+from .optim import clip_grad_norm_, create_optimizer
+from .scheduler import create_scheduler
+from .stage1 import CONFIGS
+
+
+def default_args(**over) -> Namespace:
+    """argparse defaults of post_train.py:412-600 overlaid with run_post_train.sh; keyword arguments override."""
+    a = dict(model_type="deit_tiny_patch16_224", img_size=224, num_classes=1000, train_batch_size=128, learning_rate=1e-4,
+             weight_decay=0.05, epochs=120, max_grad_norm=1.0, gradient_accumulation_steps=1, seed=42,
+             opt="adamw", opt_eps=1e-8, opt_betas=None, momentum=0.9, sched="cosine", lr_noise=None, warmup_lr=1e-6,
+             min_lr=1e-5, decay_epochs=30, warmup_epochs=5, cooldown_epochs=10, patience_epochs=10, decay_rate=0.1,
+             distillation_type="soft", distillation_alpha=0.1, distillation_tau=1.0, enable_deit=0, local_rank=-1,
+             precision="bf16", output_dir="output", name="post_train", steps_per_epoch=5005)
+    a.update(over)
+    return Namespace(**a)
+
+
+def register_masks(model):
+    """post_train.py:155-157: every module with a ``weight`` gets a ``mask`` buffer of ones."""
+    for _, m in model.named_modules():
+        if hasattr(m, "weight") and not hasattr(m, "mask"):
+            m.register_buffer("mask", torch.ones_like(m.weight))
+
+
+def setup(args, device="cuda", model_cfg=None):
+    """post_train.py:135-186 for the DeiT family: the student as Stage-2 builds it (default gate flags, i.e. hard
+    block skip; ``gumbel_hard=True``) with mask buffers registered."""
+    cfg = dict(CONFIGS[args.model_type]) if args.model_type in CONFIGS else dict(model_cfg or args.model_cfg)
+    kw = dict(patch_size=cfg["patch_size"], embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"],
+              mlp_ratio=cfg.get("mlp_ratio", 4), qkv_bias=True, drop_rate=0, img_size=args.img_size,
+              num_classes=args.num_classes, precision=args.precision, device=device)
+    model = DistilledVisionTransformer(enable_dist=args.enable_deit, gumbel_hard=True, **kw)
+    register_masks(model)
+    return args, model, kw
+
+
+class Stage2Trainer:
+    def __init__(self, args: Namespace, device="cuda", checkpoint=None, teacher_state=None, distributed=False, world_size=1):
+        self.args = args
+        args, model, kw = setup(args, device)
+        teacher = None
+        if args.distillation_type != "none":                                                        # :636-666
+            teacher = DistilledVisionTransformer(enable_dist=args.enable_deit, **kw)
+            if teacher_state is not None:
+                teacher.load_state_dict(teacher_state, strict=False)
+            teacher.eval()
+            teacher.frozen_weights = True
+        self.criterion = DistillationLoss(SoftTargetCrossEntropy(), teacher, args.distillation_type,
+                                          args.distillation_alpha, args.distillation_tau)          # :668-671
+        if checkpoint is not None:                                                                  # :676-683
+            model.load_state_dict(checkpoint)       # `hasattr(checkpoint, 'args')` is never true for a dict: bare state_dict
+        self.model, self.teacher = model, teacher
+        self.total_param = count_mask(model)
+        # post_training(): DDP, scaled learning rate, timm optimiser + schedule (:289-301)
+        self.ddp = DistributedDataParallel(model, message_size=250000000, gradient_predivide_factor=1.0) if distributed else None
+        args.train_batch_size = args.train_batch_size // args.gradient_accumulation_steps
+        args.lr = args.learning_rate * args.train_batch_size * world_size / 512.0
+        self.optimizer = create_optimizer(args, model)
+        self.scheduler, self.num_epochs = create_scheduler(args, self.optimizer)
+        model.block_skip_gating.requires_grad = False                                               # :313
+        model.train()
+        self.global_step = 0
+        self.epoch = 0
+
+    def begin_epoch(self, epoch: int):
+        """post_train.py:326-339."""
+        self.epoch = epoch
+        self.model.train()
+        self.model.block_skip_gating.requires_grad = False
+        self.scheduler.step(epoch)
+
+    def step(self, x, y, zero_grad=True):
+        """post_train.py:341-377 after the odd-batch trim and mixup: mask, forward (hard block skip), loss, backward,
+        clip, AdamW."""
+        a = self.args
+        self.model.apply_masks()                                                                    # :343-346
+        if getattr(a, "overlap_teacher", 1):
+            self.criterion.prefetch(x)
+        outputs, _ = self.model(x)                                                                  # :363
+        loss = self.criterion(x, outputs, y)
+        loss.backward()
+        gnorm = clip_grad_norm_(self.model, a.max_grad_norm)                                        # :377
+        self.optimizer.step()
+        self.global_step += 1
+        if zero_grad:
+            self.optimizer.zero_grad()
+        return dict(loss=loss.detach(), outputs=outputs, gnorm=gnorm)
+
+
+def post_training(trainer: Stage2Trainer, batches, epochs=None, valid_fn=None, log=print):
+    """The epoch loop of post_train.py:326-403 over an iterable factory ``batches(epoch)`` of device (x, y) pairs
+    (mixup already applied); ``valid_fn(model) -> accuracy`` drives the save-best policy (:393-399)."""
+    a = trainer.args
+    best_acc = 0.0
+    for epoch in range(epochs if epochs is not None else a.epochs):
+        trainer.begin_epoch(epoch)
+        t0 = time.time()
+        last = None
+        for x, y in batches(epoch):
+            if len(x) % 2 != 0:                                                                     # :348-350
+                x, y = x[:-1], y[:-1]
+            last = trainer.step(x, y)
+        lr = trainer.scheduler.get_epoch_values(epoch)[0]
+        if last is not None:
+            log(f"[Stage 2] epoch {epoch} steps {trainer.global_step} lr {lr:.6g} loss {float(last['loss']):.4f} "
+                f"({time.time() - t0:.1f}s)")
+        if valid_fn is not None and a.local_rank in (-1, 0):
+            acc = valid_fn(trainer.model)
+            if best_acc < acc:
+                save_model(a, trainer.model, None, trainer.global_step)
+                best_acc = acc
+            trainer.model.train()
+    return best_acc
+
+
+def main(argv=None):
+    """Synthetic-data Stage-2 run (the image has no dataset): loads a Stage-1 checkpoint and fine-tunes it."""
+    p = argparse.ArgumentParser(description="UVC Stage-2 masked fine-tune on MI355X (synthetic data)")
+    d = default_args()
+    for k, v in vars(d).items():
+        if v is None or isinstance(v, (list, tuple)):
+            p.add_argument("--" + k, default=v)
+        else:
+            p.add_argument("--" + k, type=type(v), default=v)
+    p.add_argument("--checkpoint_dir", type=str, default=None, help="Stage-1 checkpoint (bare state_dict)")
+    p.add_argument("--steps", type=int, default=20, help="steps per synthetic epoch")
+    args = p.parse_args(argv)
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl")
+        args.local_rank = local
+    ck = torch.load(args.checkpoint_dir, map_location="cpu") if args.checkpoint_dir else None
+    tr = Stage2Trainer(args, device=f"cuda:{local}", checkpoint=ck, distributed=world > 1, world_size=world)
+    dev = torch.device("cuda", local)
+    g = torch.Generator(device=dev).manual_seed(args.seed + rank)
+
+    def batches(epoch):
+        for _ in range(args.steps):
+            x = torch.randn(args.train_batch_size, 3, args.img_size, args.img_size, device=dev, generator=g)
+            y = torch.softmax(torch.randn(args.train_batch_size, args.num_classes, device=dev, generator=g), -1)
+            yield x, y
+
+    post_training(tr, batches, epochs=args.epochs, log=print if rank == 0 else (lambda *_: None))
+    if rank == 0:
+        print(json.dumps(dict(steps=tr.global_step, masked_params_M=float(tr.total_param))))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,10 @@ typedef struct uvc_vit_shadow_offsets {
 
 int uvc_vit_layout(const uvc_vit_cfg* cfg, uvc_vit_offsets* off, uvc_vit_shadow_offsets* soff);
 int64_t uvc_vit_workspace_bytes(const uvc_vit_cfg* cfg, int32_t batch, int32_t training);
+/* A HIP stream for uvc_vit_io.side_stream with a scheduling class: -1 = lowest priority the device offers (weight
+ * gradients / teacher forward that should only fill idle CUs), 0 = default, +1 = highest.  Never destroyed by the
+ * library; wrap it with the host framework's external-stream handle. */
+int uvc_stream_create(int32_t priority_class, void** out);
 int uvc_vit_ws_offsets(const uvc_vit_cfg* cfg, int32_t batch, int32_t training, int64_t* pe_off, int64_t* dpe_off);
 
 /* refresh the T-typed shadows (W and W^T) from the float32 master weights */

@@ -117,6 +117,7 @@ _SIGNATURES = {
     "uvc_add_outer": [VP, VP, VP, I32, I32, I32, I32, VP],
     "uvc_colsum_blocks": [I32],
     "uvc_apply_masks": [VP, VP, I64, VP],
+    "uvc_stream_create": [I32, C.POINTER(VP)],
     "uvc_cast_transpose": [VP, I32, I32, VP, VP, I32, VP],
     "uvc_cast_transpose_multi": [VP, VP, I32, VP, VP, VP, VP, VP, I32, VP],
     "uvc_gate_distrib": [VP, VP, VP, I32, I32, F32, VP],
@@ -127,6 +128,19 @@ _SIGNATURES = {
 # include/uvc_vit.h (bound in uvc_amd/model_distilled.py next to its ctypes structures)
 VIT_SYMBOLS = ["uvc_vit_layout", "uvc_vit_workspace_bytes", "uvc_vit_ws_offsets", "uvc_vit_update_shadows", "uvc_vit_forward",
                "uvc_vit_backward"]
+
+
+def side_stream(device, priority_class=None):
+    """A torch handle on a HIP stream created by the library with a scheduling class (see uvc_stream_create):
+    side work (wgrads, teacher forward) runs at the lowest priority so it only fills CUs the critical path leaves
+    idle.  UVC_SIDE_PRIORITY=-1|0|1 overrides the class."""
+    import torch
+    if priority_class is None:
+        priority_class = int(os.environ.get("UVC_SIDE_PRIORITY", "0"))
+    out = VP()
+    with torch.cuda.device(device):
+        check(lib().uvc_stream_create(priority_class, C.byref(out)), "uvc_stream_create")
+    return torch.cuda.ExternalStream(out.value, device=device)
 
 
 def exported_symbols():

@@ -68,7 +68,10 @@ template <> struct TrFrag<float> {
 
 constexpr int HD = 64;
 template <typename T> struct Geom {
-  static constexpr int ROWB = HD * (int)sizeof(T) + 16;      // LDS row stride (bytes)
+  // LDS row stride (bytes).  bf16: 128 + 32 -- with ds_read_b128's lane groups ({0-3,12-15,20-27}, ...) and the
+  // 2 x 32 groups of ds_read_b64_tr_b16, a 144-byte stride is 2-way conflicted on every operand read (PMC:
+  // SQ_LDS_BANK_CONFLICT = 45 % of SQ_LDS_IDX_ACTIVE); 160 is conflict-free for both.  float32 keeps 256 + 16.
+  static constexpr int ROWB = HD * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
   static constexpr int KS = HD / Mma<T>::KSTEP;              // MFMA k-steps across head_dim
   static constexpr int TPS = Mma<T>::KSTEP / 16;             // 16-row tiles consumed per "pair" step (2 bf16, 1 f32)
 };
@@ -178,7 +181,7 @@ struct AttnArgs {
 // ------------------------------------------------------------------------------------------------
 // forward.  NT16 = number of 16-key tiles (multiple of TPS).
 template <typename T, int NT16>
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+__global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
   typedef Mma<T> MM;
   typedef Geom<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   char* sK = smem;
   char* sV = smem + NP * G::ROWB;
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, g = lane >> 4, li = lane & 15;
   const size_t ldq = (size_t)3 * a.H * HD;
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
   const T* kb = qb + a.H * HD;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   __syncthreads();
   T* ob = reinterpret_cast<T*>(a.o) + (size_t)b * a.N * a.H * HD + h * HD;
   const int nqt = (a.N + 15) / 16;
-  for (int qt = w; qt < nqt; qt += 4) {
+  for (int qt = w; qt < nqt; qt += nw) {
     typename MM::Frag qf[G::KS];
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) qf[ks] = row_frag_global<T>(qb, ldq, qt * 16 + li, a.N, ks * 4 + g);
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward, dQ (and delta = rowsum(dO * O)).  K, V in LDS.
 template <typename T, int NT16>
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
+__global__ __launch_bounds__(512) void k_attn_bwd_dq(AttnArgs a) {
   typedef Mma<T> MM;
   typedef Geom<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
   char* sK = smem;
   char* sV = smem + NP * G::ROWB;
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, g = lane >> 4, li = lane & 15;
   const size_t ldq = (size_t)3 * a.H * HD, ldo = (size_t)a.H * HD;
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
   const T* kb = qb + a.H * HD;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
   stage_rows2<T>(sK, kb, ldq, sV, vb, ldq, a.N, NP);
   __syncthreads();
   const int nqt = (a.N + 15) / 16;
-  for (int qt = w; qt < nqt; qt += 4) {
+  for (int qt = w; qt < nqt; qt += nw) {
     const int q = qt * 16 + li;
     typename MM::Frag qf[G::KS], dof[G::KS];
     float dl = 0.f;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward, dK and dV.  Q, dO (+ lse, delta) in LDS; each wave owns 16-key tiles.
 template <typename T, int NT16>
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
+__global__ __launch_bounds__(512) void k_attn_bwd_dkv(AttnArgs a) {
   typedef Mma<T> MM;
   typedef Geom<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
   float* sLse = reinterpret_cast<float*>(smem + 2 * NP * G::ROWB);
   float* sDel = sLse + NP;
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, g = lane >> 4, li = lane & 15;
   const size_t ldq = (size_t)3 * a.H * HD, ldo = (size_t)a.H * HD;
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
   const T* kb = qb + a.H * HD;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
   const float c2 = a.scale * 1.44269504088896340736f;
   __syncthreads();
   const int nkt = (a.N + 15) / 16;
-  for (int kt = w; kt < nkt; kt += 4) {
+  for (int kt = w; kt < nkt; kt += nw) {
     const int key = kt * 16 + li;
     typename MM::Frag kf[G::KS], vf[G::KS];
 #pragma unroll
@@ -402,20 +405,23 @@ template <typename T, int NT16> int launch(const AttnArgs& a, int which, hipStre
   const int NP = NT16 * 16;
   size_t sh = (size_t)2 * NP * Geom<T>::ROWB;
   const int grid = a.B * a.H;
+  // forward: 4 waves per (image, head); backward: 8 (two workgroups per CU either way -- the LDS image is the limit --
+  // so backward runs 4 waves per SIMD, which hides its longer dependent MFMA -> exp -> MFMA chains: 153 -> 135 us)
+  const int threads = which == 0 ? 256 : 512;
   hipError_t e = hipSuccess;
   if (which == 0) {
     if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-    k_attn_fwd<T, NT16><<<grid, 256, sh, st>>>(a);
+    k_attn_fwd<T, NT16><<<grid, threads, sh, st>>>(a);
   } else if (which == 1) {
     if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_bwd_dq<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-    k_attn_bwd_dq<T, NT16><<<grid, 256, sh, st>>>(a);
+    k_attn_bwd_dq<T, NT16><<<grid, threads, sh, st>>>(a);
   } else {
     sh += (size_t)2 * NP * sizeof(float);
     if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_bwd_dkv<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-    k_attn_bwd_dkv<T, NT16><<<grid, 256, sh, st>>>(a);
+    k_attn_bwd_dkv<T, NT16><<<grid, threads, sh, st>>>(a);
   }
   UVC_CHECK_LAUNCH();
   return UVC_OK;

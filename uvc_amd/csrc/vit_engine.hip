@@ -282,6 +282,19 @@ extern "C" int uvc_vit_ws_offsets(const uvc_vit_cfg* cfg, int32_t batch, int32_t
   return UVC_OK;
 }
 
+extern "C" int uvc_stream_create(int32_t priority_class, void** out) {
+  if (!out) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_stream_create: null out");
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+  const int prio = priority_class < 0 ? least : (priority_class > 0 ? greatest : 0);
+  hipStream_t s = nullptr;
+  e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
+  if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+  *out = (void*)s;
+  return UVC_OK;
+}
+
 extern "C" int uvc_vit_update_shadows(const uvc_vit_cfg* cfg, const float* params, void* shadow, void* stream) {
   TRY(check_cfg(cfg));
   if (!params || !shadow) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_update_shadows: null pointer");

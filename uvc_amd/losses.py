@@ -68,7 +68,7 @@ class DistillationLoss(torch.nn.Module):
             return
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=inputs.device)
+            self._side = L.side_stream(inputs.device)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side), torch.no_grad():
             out, _ = self.teacher_model(inputs)

@@ -517,7 +517,7 @@ class DistilledVisionTransformer(nn.Module):
             self._skip_grads_clean = True
         if self.two_stream_backward:
             if self._wgrad_stream is None:
-                self._wgrad_stream = torch.cuda.Stream(device=self._flat.device)
+                self._wgrad_stream = L.side_stream(self._flat.device)
             io.side_stream = self._wgrad_stream.cuda_stream
         dmask = None
         if patch:

@@ -91,15 +91,17 @@ typedef struct uvc_ln_args {
   void* y; float* mean; float* rstd;
   /* backward */
   const void* dy;       /* dense [rows, D]; T, or float32 when dy_is_f32 */
-  float* dx;            /* same row addressing as x; dx = LN'(dy) + a1*add1 + a2*add2 */
-  const float* add1; const float* a1;   /* optional dense-as-x addends; a1/a2 device scalars (NULL = 1) */
-  const float* add2; const float* a2;
+  void* dx;             /* same row addressing as x; dx = LN'(dy) + a1*add1 + a2*add2; float32, or T when g_lowp */
+  const void* add1; const float* a1;    /* optional dense-as-x addends (same element type as dx); a1/a2 device scalars (NULL = 1) */
+  const void* add2; const float* a2;
   float* partial;       /* scratch [ln_bwd_blocks, 2*D + 2] */
   float* dgamma; float* dbeta;          /* [D], written as beta_acc*old + sum */
   float* dots;          /* optional [2]: { <dx, x>, <add2, x> } over all rows (gate-logit gradients) */
   float eps, beta_acc;
   int32_t rows, D, rows_per_group, dtype, y_is_f32, dy_is_f32;
   int64_t group_stride;
+  int32_t g_lowp;       /* backward: the gradient stream (dx, add1, add2) is stored as T (bf16) instead of float32;
+                           all arithmetic and the dots stay float32 */
 } uvc_ln_args;
 int uvc_layernorm_fwd(const uvc_ln_args* args, void* stream);
 int uvc_layernorm_bwd(const uvc_ln_args* args, void* stream);
@@ -146,10 +148,11 @@ int uvc_patchify(const float* x, void* out, int32_t B, int32_t C, int32_t S, int
 int uvc_assemble_tokens(const float* pe, const float* cls, const float* dist, const float* pos, const float* row_mask,
                         float* tok, int32_t B, int32_t P, int32_t D, int32_t ntok, void* stream);
 /* backward of uvc_assemble_tokens: dpe [B,P,D] (T or f32) = dtok rows * mask; dpos/dcls/ddist = sums over batch
- * (written as beta_acc*old + sum); optional dmask[B,P] = <dtok row, pe row>. */
-int uvc_assemble_tokens_bwd(const float* dtok, const float* pe, const float* row_mask, void* dpe, float* dpos, float* dcls,
+ * (written as beta_acc*old + sum); optional dmask[B,P] = <dtok row, pe row>.  dtok [B,N,D] is float32, or T when
+ * dtok_lowp (the bf16 gradient stream of the backward). */
+int uvc_assemble_tokens_bwd(const void* dtok, const float* pe, const float* row_mask, void* dpe, float* dpos, float* dcls,
                             float* ddist, float* dmask, int32_t B, int32_t P, int32_t D, int32_t ntok, int32_t dtype,
-                            int32_t dpe_is_f32, float beta_acc, void* stream);
+                            int32_t dpe_is_f32, int32_t dtok_lowp, float beta_acc, void* stream);
 /* column sums: out[n] = beta*out[n] + alpha * sum_m X[m,n];  X is T or float32.  partial: [uvc_colsum_blocks(M), N]. */
 int uvc_colsum(const void* X, int32_t M, int32_t N, int32_t ldx, int32_t dtype, int32_t x_is_f32, float* partial, float* out,
                float alpha, const float* alpha_ptr, float beta, const float* row_weight /* optional [M] */, void* stream);

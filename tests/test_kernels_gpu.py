@@ -229,6 +229,34 @@ def test_layernorm_fwd_bwd(dtype, rows, D):
                                rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("rows,D", [(1576, 192), (333, 384)])
+def test_layernorm_bwd_bf16_gradient_stream(rows, D):
+    """The throughput mode keeps dL/dx (dx, add1, add2) in bf16: loads are widened, all sums and the gate dots
+    stay float32, only the stored dx is rounded."""
+    from uvc_amd import ops
+    x, gamma, beta = rnd(rows, D, seed=31) * 2 + 0.5, rnd(D, seed=32) * 0.2 + 1.0, rnd(D, seed=33) * 0.1
+    y = torch.empty(rows, D, device=dev(), dtype=torch.bfloat16)
+    mean, rstd = torch.empty(rows, device=dev()), torch.empty(rows, device=dev())
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, BF16)
+    dy = to_t(rnd(rows, D, seed=34), BF16)
+    add1, add2 = rnd(rows, D, seed=35).bfloat16(), rnd(rows, D, seed=36).bfloat16()
+    a1, a2 = torch.tensor([0.7], device=dev()), torch.tensor([0.3], device=dev())
+    dx = torch.empty(rows, D, device=dev(), dtype=torch.bfloat16)
+    partial = torch.empty(ops.layernorm_bwd_blocks(rows) * (2 * D + 2), device=dev())
+    dg, db, dots = torch.zeros(D, device=dev()), torch.zeros(D, device=dev()), torch.empty(2, device=dev())
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dg, db, rows, D, BF16, add1=add1, a1=a1, add2=add2, a2=a2, dots=dots)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    F.layer_norm(xd, (D,), gd, bd, 1e-6).backward(dy.double())
+    dxr = xd.grad + 0.7 * add1.double() + 0.3 * add2.double()
+    torch.testing.assert_close(dx.double(), dxr, rtol=8e-3, atol=8e-3)              # one bf16 rounding of the result
+    torch.testing.assert_close(dg.double(), gd.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dots.double(), torch.stack([(dxr * x.double()).sum(), (add2.double() * x.double()).sum()]),
+                               rtol=1e-4, atol=1e-2)                                # from the unrounded values
+    with pytest.raises(Exception):
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dg, db, rows, D, BF16, add1=add1.float())
+
+
 def test_layernorm_class_token_rows():
     """Final norm on the class/dist-token rows only (model_distilled.py:507-508): strided rows."""
     from uvc_amd import ops
@@ -324,6 +352,13 @@ def test_patchify_assemble_colsum_transpose(dtype):
     torch.testing.assert_close(dcls, dtok[:, 0].sum(0), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(ddist, dtok[:, 1].sum(0), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(dmask, (dtok[:, ntok:] * pe).sum(-1), rtol=1e-4, atol=1e-4)
+    if dtype == BF16:          # the backward's bf16 gradient stream as input: same sums over the rounded values
+        d16 = dtok.bfloat16()
+        ops.assemble_tokens_bwd(d16, pe, mask, dpe, dpos, dcls, ddist, dmask, B, npatch, D, ntok, dtype)
+        torch.testing.assert_close(dpe.float(), d16[:, ntok:].float() * mask.unsqueeze(-1), rtol=0, atol=0)
+        torch.testing.assert_close(dpos, d16.float().sum(0), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dcls, d16[:, 0].float().sum(0), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dmask, (d16[:, ntok:].float() * pe).sum(-1), rtol=1e-4, atol=1e-4)
     for M, N in ((1576, 576), (300, 10), (5, 1000)):
         X = to_t(rnd(M, N, seed=68), dtype)
         partial = torch.empty(ops.colsum_blocks(M) * N, device=dev())

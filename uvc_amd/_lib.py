@@ -63,7 +63,7 @@ class uvc_ln_args(C.Structure):
                                           "a2", "partial", "dgamma", "dbeta", "dots")] + \
                [("eps", C.c_float), ("beta_acc", C.c_float)] + \
                [(n, C.c_int32) for n in ("rows", "D", "rows_per_group", "dtype", "y_is_f32", "dy_is_f32")] + \
-               [("group_stride", C.c_int64)]
+               [("group_stride", C.c_int64), ("g_lowp", C.c_int32)]
 
 
 class uvc_loss_args(C.Structure):
@@ -107,7 +107,7 @@ _SIGNATURES = {
     "uvc_scale_by_clip": [VP, I64, VP, F32, VP],
     "uvc_patchify": [VP, VP, I32, I32, I32, I32, I32, VP],
     "uvc_assemble_tokens": [VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, VP],
-    "uvc_assemble_tokens_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, I32, I32, F32, VP],
+    "uvc_assemble_tokens_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, I32, I32, I32, F32, VP],
     "uvc_colsum": [VP, I32, I32, I32, I32, I32, VP, VP, F32, VP, F32, VP, VP],
     "uvc_patch_gate_sigmoid": [VP, VP, I32, I32, I32, VP],
     "uvc_patch_gate_sigmoid_bwd": [VP, VP, VP, I32, I32, F32, VP],

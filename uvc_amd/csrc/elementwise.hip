@@ -44,15 +44,23 @@ __global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ pe, 
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_assemble_bwd_dpe(const float* __restrict__ dtok, const float* __restrict__ mask,
+// 4 consecutive elements of the token-gradient stream (float32, or bf16 when the backward keeps it in T)
+template <typename TD> __device__ __forceinline__ f32x4 ld_tok4(const TD* p);
+template <> __device__ __forceinline__ f32x4 ld_tok4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld_tok4<bf16_t>(const bf16_t* p) {
+  const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+  return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+}
+
+template <typename T, typename TD>
+__global__ __launch_bounds__(256) void k_assemble_bwd_dpe(const TD* __restrict__ dtok, const float* __restrict__ mask,
                                                           T* __restrict__ dpe, int B, int P, int D, int ntok) {
   const int N = P + ntok, D4 = D / 4;
   const int64_t total = (int64_t)B * P * D4;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int d4 = (int)(idx % D4);
     const int i = (int)((idx / D4) % P), b = (int)(idx / ((int64_t)D4 * P));
-    f32x4 v = *reinterpret_cast<const f32x4*>(dtok + ((size_t)b * N + ntok + i) * D + d4 * 4);
+    f32x4 v = ld_tok4<TD>(dtok + ((size_t)b * N + ntok + i) * D + d4 * 4);
     if (mask) { const float m = mask[(size_t)b * P + i]; v[0] *= m; v[1] *= m; v[2] *= m; v[3] *= m; }
     T* o = dpe + ((size_t)b * P + i) * D + d4 * 4;
     if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(o) = v;
@@ -62,7 +70,8 @@ __global__ __launch_bounds__(256) void k_assemble_bwd_dpe(const float* __restric
 
 // dpos[t,d] = sum_b dtok[b,t,d]; the class / dist token gradients are rows 0 / 1 of the same sum.
 // 256 threads = 32 column quads x 8 batch slices, 16-byte loads, fixed-order LDS reduction over the slices.
-__global__ __launch_bounds__(256) void k_assemble_bwd_dpos(const float* __restrict__ dtok, float* __restrict__ dpos,
+template <typename TD>
+__global__ __launch_bounds__(256) void k_assemble_bwd_dpos(const TD* __restrict__ dtok, float* __restrict__ dpos,
                                                            float* __restrict__ dcls, float* __restrict__ ddist, int B, int N,
                                                            int D, int ntok, float beta) {
   __shared__ f32x4 red[8][32];
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void k_assemble_bwd_dpos(const float* __restri
   if (col < ND) {
 #pragma unroll 4
     for (int b = sl; b < B; b += 8) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(dtok + (size_t)b * ND + col);
+      const f32x4 v = ld_tok4<TD>(dtok + (size_t)b * ND + col);
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
   }
@@ -93,15 +102,16 @@ __global__ __launch_bounds__(256) void k_assemble_bwd_dpos(const float* __restri
 }
 
 // dmask[b,i] = <dtok[b, ntok+i, :], pe[b, i, :]>  (one wave per row)
-__global__ __launch_bounds__(256) void k_assemble_bwd_dmask(const float* __restrict__ dtok, const float* __restrict__ pe,
+template <typename TD>
+__global__ __launch_bounds__(256) void k_assemble_bwd_dmask(const TD* __restrict__ dtok, const float* __restrict__ pe,
                                                             float* __restrict__ dmask, int B, int P, int D, int ntok) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= B * P) return;
   const int b = row / P, i = row % P, N = P + ntok;
-  const float* a = dtok + ((size_t)b * N + ntok + i) * D;
+  const TD* a = dtok + ((size_t)b * N + ntok + i) * D;
   const float* c = pe + (size_t)row * D;
   float s = 0.f;
-  for (int d = lane; d < D; d += 64) s += a[d] * c[d];
+  for (int d = lane; d < D; d += 64) s += ElemIO<TD>::load(a + d) * c[d];
   s = wave_sum(s);
   if (lane == 0) dmask[row] = s;
 }
@@ -347,20 +357,31 @@ extern "C" int uvc_assemble_tokens(const float* pe, const float* cls, const floa
   return UVC_OK;
 }
 
-extern "C" int uvc_assemble_tokens_bwd(const float* dtok, const float* pe, const float* row_mask, void* dpe, float* dpos, float* dcls,
+extern "C" int uvc_assemble_tokens_bwd(const void* dtok, const float* pe, const float* row_mask, void* dpe, float* dpos, float* dcls,
                                        float* ddist, float* dmask, int32_t B, int32_t P, int32_t D, int32_t ntok, int32_t dtype,
-                                       int32_t dpe_is_f32, float beta_acc, void* stream) {
+                                       int32_t dpe_is_f32, int32_t dtok_lowp, float beta_acc, void* stream) {
   if (!dtok || !dpe || !dpos || !dcls || D % 4 || (ntok != 1 && ntok != 2)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_assemble_tokens_bwd: bad argument");
   if (dmask && !pe) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_assemble_tokens_bwd: dmask needs pe");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == UVC_F32 || dpe_is_f32) k_assemble_bwd_dpe<float><<<grid_for((int64_t)B * P * D / 4), 256, 0, st>>>(dtok, row_mask, (float*)dpe, B, P, D, ntok);
-  else k_assemble_bwd_dpe<bf16_t><<<grid_for((int64_t)B * P * D / 4), 256, 0, st>>>(dtok, row_mask, (bf16_t*)dpe, B, P, D, ntok);
-  UVC_CHECK_LAUNCH();
-  k_assemble_bwd_dpos<<<ceil_div((P + ntok) * D, 128), 256, 0, st>>>(dtok, dpos, dcls, ddist, B, P + ntok, D, ntok, beta_acc);
-  UVC_CHECK_LAUNCH();
-  if (dmask) {
-    k_assemble_bwd_dmask<<<ceil_div(B * P, 4), 256, 0, st>>>(dtok, pe, dmask, B, P, D, ntok);
+  const bool out32 = dtype == UVC_F32 || dpe_is_f32, in16 = dtok_lowp && dtype == UVC_BF16;
+  const int g1 = grid_for((int64_t)B * P * D / 4), g2 = ceil_div((P + ntok) * D, 128), g3 = ceil_div(B * P, 4);
+  const int N = P + ntok;
+  if (in16) {
+    const bf16_t* t = (const bf16_t*)dtok;
+    if (out32) k_assemble_bwd_dpe<float, bf16_t><<<g1, 256, 0, st>>>(t, row_mask, (float*)dpe, B, P, D, ntok);
+    else k_assemble_bwd_dpe<bf16_t, bf16_t><<<g1, 256, 0, st>>>(t, row_mask, (bf16_t*)dpe, B, P, D, ntok);
     UVC_CHECK_LAUNCH();
+    k_assemble_bwd_dpos<bf16_t><<<g2, 256, 0, st>>>(t, dpos, dcls, ddist, B, N, D, ntok, beta_acc);
+    UVC_CHECK_LAUNCH();
+    if (dmask) { k_assemble_bwd_dmask<bf16_t><<<g3, 256, 0, st>>>(t, pe, dmask, B, P, D, ntok); UVC_CHECK_LAUNCH(); }
+  } else {
+    const float* t = (const float*)dtok;
+    if (out32) k_assemble_bwd_dpe<float, float><<<g1, 256, 0, st>>>(t, row_mask, (float*)dpe, B, P, D, ntok);
+    else k_assemble_bwd_dpe<bf16_t, float><<<g1, 256, 0, st>>>(t, row_mask, (bf16_t*)dpe, B, P, D, ntok);
+    UVC_CHECK_LAUNCH();
+    k_assemble_bwd_dpos<float><<<g2, 256, 0, st>>>(t, dpos, dcls, ddist, B, N, D, ntok, beta_acc);
+    UVC_CHECK_LAUNCH();
+    if (dmask) { k_assemble_bwd_dmask<float><<<g3, 256, 0, st>>>(t, pe, dmask, B, P, D, ntok); UVC_CHECK_LAUNCH(); }
   }
   return UVC_OK;
 }

@@ -83,15 +83,15 @@ __global__ __launch_bounds__(256) void k_ln_bwd(uvc_ln_args a) {
     }
     c1 = wave_sum(c1) * invD;
     c2 = wave_sum(c2) * invD;
-    float* dx = a.dx + off;
+    float* dx = reinterpret_cast<float*>(a.dx) + off;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < a.D) {
         float o = rstd * (gy[i] - c1 - xh[i] * c2);
         const float xv = x[c];
-        if (a.add1) o += a1 * a.add1[off + c];
-        if (a.add2) { const float t = a.add2[off + c]; o += a2 * t; dotB += t * xv; }
+        if (a.add1) o += a1 * reinterpret_cast<const float*>(a.add1)[off + c];
+        if (a.add2) { const float t = reinterpret_cast<const float*>(a.add2)[off + c]; o += a2 * t; dotB += t * xv; }
         dx[c] = o;
         dotA += o * xv;
       }
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void k_ln_fwd_v(uvc_ln_args a) {
   }
 }
 
-template <typename TDY, int NV4>
+// TG: element type of the gradient stream (dx, add1, add2): float32, or bf16 when uvc_ln_args.g_lowp is set.
+template <typename TDY, typename TG, int NV4>
 __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
   __shared__ float red[4][2 * 64 * NV4 + 2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane & 15, rg = lane >> 4;
@@ -221,8 +222,17 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
     const float* x = a.x + off;
     const TDY* dy = reinterpret_cast<const TDY*>(a.dy) + (size_t)(ok ? r : 0) * a.D;
     const float mean = ok ? a.mean[r] : 0.f, rstd = ok ? a.rstd[r] : 0.f;
-    f32x4 xv[NV4], gy[NV4];
+    f32x4 xv[NV4], gy[NV4], ad1[NV4], ad2[NV4];
     float c1 = 0.f, c2 = 0.f;
+    const TG* add1 = reinterpret_cast<const TG*>(a.add1);
+    const TG* add2 = reinterpret_cast<const TG*>(a.add2);
+    // every global load of the row is issued before the first reduction, so one HBM round trip covers them all
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ad1[i] = (ok && add1) ? Ld4<TG>::ld(add1 + off + (sub + 16 * i) * 4) : z;
+      ad2[i] = (ok && add2) ? Ld4<TG>::ld(add2 + off + (sub + 16 * i) * 4) : z;
+    }
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -241,22 +251,22 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
     c1 = sum16(c1) * invD;
     c2 = sum16(c2) * invD;
     if (ok) {
-      float* dx = a.dx + off;
+      TG* dx = reinterpret_cast<TG*>(a.dx) + off;
 #pragma unroll
       for (int i = 0; i < NV4; ++i) {
         const int c = (sub + 16 * i) * 4;
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[i][e] - c1 - ((xv[i][e] - mean) * rstd) * c2);
-        if (a.add1) { const f32x4 t = Ld4<float>::ld(a.add1 + off + c);
+        if (a.add1) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += a1 * t[e]; }
-        if (a.add2) { const f32x4 t = Ld4<float>::ld(a.add2 + off + c);
+          for (int e = 0; e < 4; ++e) o[e] += a1 * ad1[i][e]; }
+        if (a.add2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { o[e] += a2 * t[e]; dotB += t[e] * xv[i][e]; } }
+          for (int e = 0; e < 4; ++e) { o[e] += a2 * ad2[i][e]; dotB += ad2[i][e] * xv[i][e]; } }
 #pragma unroll
         for (int e = 0; e < 4; ++e) dotA += o[e] * xv[i][e];
-        Ld4<float>::st(dx + c, o);
+        Ld4<TG>::st(dx + c, o);
       }
     }
   }
@@ -337,15 +347,24 @@ template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
   const int grid = ceil_div(a.rows, LN_ROWS_PER_BLOCK);
   const int nv = ceil_div(a.D, 64);
   bool vec = a.D % 64 == 0 && (a.group_stride % 4) == 0;
-  if (vec) {
+  if (vec && a.g_lowp) {
     switch (a.D / 64) {
-      case 2: k_ln_bwd_v<T, 2><<<grid, 256, 0, st>>>(a); break;
-      case 3: k_ln_bwd_v<T, 3><<<grid, 256, 0, st>>>(a); break;
-      case 6: k_ln_bwd_v<T, 6><<<grid, 256, 0, st>>>(a); break;
-      case 12: k_ln_bwd_v<T, 12><<<grid, 256, 0, st>>>(a); break;
+      case 2: k_ln_bwd_v<T, bf16_t, 2><<<grid, 256, 0, st>>>(a); break;
+      case 3: k_ln_bwd_v<T, bf16_t, 3><<<grid, 256, 0, st>>>(a); break;
+      case 6: k_ln_bwd_v<T, bf16_t, 6><<<grid, 256, 0, st>>>(a); break;
+      case 12: k_ln_bwd_v<T, bf16_t, 12><<<grid, 256, 0, st>>>(a); break;
+      default: vec = false;
+    }
+  } else if (vec) {
+    switch (a.D / 64) {
+      case 2: k_ln_bwd_v<T, float, 2><<<grid, 256, 0, st>>>(a); break;
+      case 3: k_ln_bwd_v<T, float, 3><<<grid, 256, 0, st>>>(a); break;
+      case 6: k_ln_bwd_v<T, float, 6><<<grid, 256, 0, st>>>(a); break;
+      case 12: k_ln_bwd_v<T, float, 12><<<grid, 256, 0, st>>>(a); break;
       default: vec = false;
     }
   }
+  if (!vec && a.g_lowp) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "layernorm_bwd: a bf16 gradient stream needs D % 64 == 0");
   if (!vec) {
     if (nv <= 2) k_ln_bwd<T, 2><<<grid, 256, 0, st>>>(a);
     else if (nv <= 3) k_ln_bwd<T, 3><<<grid, 256, 0, st>>>(a);

@@ -51,7 +51,9 @@ struct Work {
   void* patches; float* pe; BlockBufs blk[UVC_VIT_MAX_DEPTH]; float* xL;
   void* hc; float* meanf; float* rstdf;
   // backward scratch
-  float* gA; float* gB; void* dA; void* dH; void* dqkv; float* delta; float* ln_partial; float* cs_partial;
+  void* gA; void* gB;      // dL/dx streams of the backward: T (bf16 in the throughput mode: every consumer is a bf16 GEMM
+                           // operand or a LayerNorm backward that accumulates in float32), float32 in the exact mode
+  void* dA; void* dH; void* dqkv; float* delta; float* ln_partial; float* cs_partial;
   void* tn_ws; int64_t tn_ws_bytes; float* dotsraw; void* dhc; void* dpe;
 };
 
@@ -86,7 +88,7 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
   w.hc = c.take((int64_t)d.B * d.ntok * d.D * d.tsz);
   w.meanf = (float*)c.take((int64_t)d.B * d.ntok * 4); w.rstdf = (float*)c.take((int64_t)d.B * d.ntok * 4);
   if (training) {
-    w.gA = (float*)c.take(MD * 4); w.gB = (float*)c.take(MD * 4);
+    w.gA = c.take(MD * d.tsz); w.gB = c.take(MD * d.tsz);
     w.dA = c.take(MF * d.tsz); w.dH = c.take(MD * d.tsz); w.dqkv = c.take(3 * MD * d.tsz);
     w.delta = (float*)c.take((int64_t)d.B * d.H * d.N * 4);
     w.ln_partial = (float*)c.take((int64_t)uvc_layernorm_bwd_blocks(d.M) * (2 * d.D + 2) * 4);
@@ -185,13 +187,14 @@ int ln_fwd(const Ctx& c, const float* x, int64_t pw, int64_t pb, void* y, float*
   a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
   return uvc_layernorm_fwd(&a, c.st);
 }
-int ln_bwd(const Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, float* dx,
-           const float* add1, const float* a1, const float* add2, const float* a2, float* dots, int rows, int rpg, int64_t gs) {
+int ln_bwd(const Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, void* dx,
+           const void* add1, const float* a1, const void* add2, const float* a2, float* dots, int rows, int rpg, int64_t gs) {
   uvc_ln_args a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.gamma = c.io->params + pw; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx; a.add1 = add1; a.a1 = a1;
   a.add2 = add2; a.a2 = a2; a.partial = c.w.ln_partial; a.dgamma = c.io->grads + pw; a.dbeta = c.io->grads + pb; a.dots = dots;
   a.eps = 1e-6f; a.beta_acc = c.io->accumulate; a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
+  a.g_lowp = c.d.dtype == UVC_BF16;
   return uvc_layernorm_bwd(&a, c.st);
 }
 int attn(const Ctx& c, const BlockBufs& b, bool bwd) {
@@ -402,6 +405,7 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   Work& w = c.w;
   hipStream_t hs = (hipStream_t)stream;
   const int rh = d.B * d.ntok;
+  const int gf = d.dtype == UVC_F32 ? 1 : 0;     // "operand is float32" flag of the gA / gB streams
   const int sb = io->stage_begin, se = (io->stage_begin == 0 && io->stage_end == 0) ? d.L + 3 : io->stage_end;
   if (sb < 0 || se > d.L + 3 || sb >= se) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_backward: bad stage range");
   if (sb == 0) {
@@ -415,7 +419,7 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     TRY(tn(c, io->d_logits_dist, 1, (const char*)w.hc + (size_t)d.D * d.tsz, G + o.headd_w, G + o.headd_b, d.B, d.NC, d.D, nullptr, 0, d.ntok * d.D));
   }
   // final norm backward -> gA = dL/dx_L (zero except the token rows)
-  hipError_t he = hipMemsetAsync(w.gA, 0, (size_t)d.M * d.D * 4, hs);
+  hipError_t he = hipMemsetAsync(w.gA, 0, (size_t)d.M * d.D * d.tsz, hs);
   if (he != hipSuccess) return uvc_set_error(he, __FILE__, __LINE__);
   TRY(ln_bwd(c, w.dhc, w.xL, o.norm_w, o.norm_b, w.meanf, w.rstdf, w.gA, nullptr, nullptr, nullptr, nullptr, w.dotsraw + 2 * d.L, rh, d.ntok,
              (int64_t)d.N * d.D));
@@ -430,15 +434,15 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     const float* g1 = io->gate_d ? io->gate_d + 2 * l + 1 : nullptr;   // d1
     // MLP: out = d1*(x1 + fc2(u)) + d0*x
     TRY(guard_overwrite(c, BUF_DA));
-    TRY(nt(c, w.gA, 1, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
-    TRY(tn(c, w.gA, 1, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1, 0, 0, BUF_GA));
+    TRY(nt(c, w.gA, gf, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
+    TRY(tn(c, w.gA, gf, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1, 0, 0, BUF_GA));
     TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
     TRY(tn(c, w.dA, 0, b.h2, G + q[8], G + q[9], d.M, d.F, d.D, nullptr, 0, 0, BUF_DA));
     TRY(guard_overwrite(c, BUF_GB));
     TRY(ln_bwd(c, w.dH, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr, d.M, 1, d.D));   // gB = dL/dx1
     // attention
-    TRY(nt(c, w.gB, 1, sh(c, so.blk_wt[l][1]), w.dH, 0, d.M, d.D, d.D, UVC_EPI_NONE));                                      // dO
-    TRY(tn(c, w.gB, 1, b.o, G + q[4], G + q[5], d.M, d.D, d.D, nullptr, 0, 0, BUF_GB));
+    TRY(nt(c, w.gB, gf, sh(c, so.blk_wt[l][1]), w.dH, 0, d.M, d.D, d.D, UVC_EPI_NONE));                                      // dO
+    TRY(tn(c, w.gB, gf, b.o, G + q[4], G + q[5], d.M, d.D, d.D, nullptr, 0, 0, BUF_GB));
     TRY(guard_overwrite(c, BUF_DQKV));
     TRY(attn(c, b, true));
     TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));
@@ -453,7 +457,7 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
       TRY(uvc_gate_grad(P + o.gate, io->gate_d, w.dotsraw, G + o.gate, d.L, io->gate_mode, io->gate_eps, io->accumulate, stream));
     // token assembly
     TRY(uvc_assemble_tokens_bwd(w.gA, w.pe, io->patch_mask, w.dpe, G + o.pos_embed, G + o.cls_token, d.ntok == 2 ? G + o.dist_token : nullptr,
-                                io->d_patch_mask, d.B, d.np, d.D, d.ntok, d.dtype, 0, io->accumulate, stream));
+                                io->d_patch_mask, d.B, d.np, d.D, d.ntok, d.dtype, 0, d.dtype == UVC_BF16, io->accumulate, stream));
   }
   if (se < d.L + 3) return join_side(c);
   // patch embedding (weight gradient only: the image needs no gradient)

@@ -126,6 +126,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, rows, D,
     a.add1, a.a1, a.add2, a.a2 = L.ptr(add1), L.ptr(a1), L.ptr(add2), L.ptr(a2)
     a.partial, a.dgamma, a.dbeta, a.dots = L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dots)
     a.beta_acc, a.dy_is_f32 = beta_acc, _is_f32(dy)
+    a.g_lowp = int(not _is_f32(dx))          # gradient stream (dx, add1, add2) kept in bf16
+    for t in (add1, add2):
+        if t is not None and t.dtype != dx.dtype:
+            raise L.UvcHipError("layernorm_bwd: add1/add2 must have dx's element type")
     L.check(L.lib().uvc_layernorm_bwd(C.byref(a), L.cur_stream()), "uvc_layernorm_bwd")
 
 
@@ -175,7 +179,7 @@ def assemble_tokens(pe, cls, dist, pos, row_mask, tok, B, P, D, ntok):
 def assemble_tokens_bwd(dtok, pe, row_mask, dpe, dpos, dcls, ddist, dmask, B, P, D, ntok, dtype, beta_acc=0.0):
     _chk(dtok, pe, row_mask, dpe, dpos, dcls, ddist, dmask)
     L.check(L.lib().uvc_assemble_tokens_bwd(L.ptr(dtok), L.ptr(pe), L.ptr(row_mask), L.ptr(dpe), L.ptr(dpos), L.ptr(dcls),
-                                            L.ptr(ddist), L.ptr(dmask), B, P, D, ntok, dtype, _is_f32(dpe), beta_acc,
+                                            L.ptr(ddist), L.ptr(dmask), B, P, D, ntok, dtype, _is_f32(dpe), int(not _is_f32(dtok)), beta_acc,
                                             L.cur_stream()), "uvc_assemble_tokens_bwd")
 
 

@@ -16,7 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libuvc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
+# -fno-slp-vectorize: no SLP vectorisation of scalar float math into packed-fp32 instructions.  hipcc turned the gate mix
+# `d1*v + d0*r` into v_pk_fma_f32 with op_sel-swapped halves written in place over its own addend (dest == src2); on
+# gfx950 that form returned wrong low halves in lanes 48-63, non-deterministically (k_gemm_wsn<float, GATE, 18>, caught
+# by tests/test_kernels_gpu.py).  Plain v_fma_f32 is exact, and the kernels are HBM-bound, so all files are built this way.
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-value", "-Wno-unused-result",
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
 # the scalar primal-dual update must round like the reference's separate float32 ops
 PER_FILE = {"uvc_engine.hip": ["-ffp-contract=off"]}

@@ -499,150 +499,82 @@ static int launch_ws(const NtArgs& a, int epi, hipStream_t st) {
 }
 
 // ================================================================================================
-//        NT, weights-stationary with the reduction dimension split over the waves (bf16, N == 192)
+//        NT, weights-stationary, one 16-column slice of the FULL reduction per wave (bf16, N == 192)
 // ================================================================================================
-// fc2 (+ residual + gate mix), dgrad of fc1, dgrad of qkv: K = 768 / 576 against N = 192.  W [192, K] does not
-// fit one wave's registers, so the workgroup is a KS x 3 grid of waves: wave (kw, nw) keeps the B fragments
-// of output columns nw*64.. and k-range kw*192.. (96 VGPRs), computes a partial 16x64 tile from the staged
-// A rows, and the KS partials are summed through LDS by the same waves (each takes a quarter of the rows)
-// in a fixed order, fused with the epilogue.  A streams through a double-buffered 32-row LDS image with
-// register prefetch, one persistent workgroup per CU; residual operands are prefetched one sub-tile ahead.
-constexpr int WK_BM = 32;
+// fc2 (+ residual + gate mix), dgrad of fc1, dgrad of qkv: K = 768 / 576 against N = 192.  W [192, K] does not fit one
+// wave's registers as a 64-column slice, and splitting K over waves needs a cross-wave reduction with two barriers per
+// sub-tile (tried: 141 us for fc2, 60 us for dgrad fc1; this kernel 136 / 45).  Here the workgroup is 12 waves, wave w owns output columns 16w..16w+15 and keeps that slice of W for the whole K in registers
+// (KT fragments = 96 VGPRs at K = 768).  With W as the MFMA A operand the accumulator of lane (row, g) is four
+// CONSECUTIVE output columns of one row, so the epilogue needs no LDS transpose and no barrier: residual rows are
+// read and results written as 16-byte vectors (64 contiguous bytes per row per wave, the neighbouring waves fill the
+// rest of the line).  A streams through a double-buffered 32-row LDS image (one barrier per tile); the two 16-row
+// sub-tiles are two independent MFMA chains; next tile's residual operands are prefetched under this tile's math.
+constexpr int WN_BM = 32;
 
-template <typename TC, int EPI, int KS>
-__global__ __launch_bounds__(KS * 192) void k_gemm_wsk(NtArgs g) {
+template <typename TC, int EPI, int KT>
+__global__ __launch_bounds__(768) void k_gemm_wsn(NtArgs g) {
   typedef bf16_t T;
   typedef Mma<T> MM;
-  constexpr int K = KS * 192, NTH = KS * 192;
-  constexpr int ROWB = K * 2 + 32, CPR = K / 8;   // words = 8 (K = 768) / 40 (K = 576) mod 64: conflict-free fragment reads
-  constexpr int NLD = (WK_BM * CPR + NTH - 1) / NTH;
-  constexpr int VN = OutVec<TC>::VN;                  // 4 (f32 out) or 8 (bf16 out)
-  constexpr int NVEC = 16 * 64 / VN;                  // output vectors per 16x64 sub-tile of one n-slice
-  constexpr int NIT = (NVEC + KS * 64 - 1) / (KS * 64);
+  constexpr int K = KT * 32, NTH = 768;
+  constexpr int ROWB = K * 2 + 32, CPR = K / 8;
+  constexpr int NLD = (WN_BM * CPR + NTH - 1) / NTH;
+  constexpr bool RES = EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA0 = smem;
-  char* sA1 = smem + WK_BM * ROWB;
-  float* sStage = reinterpret_cast<float*>(smem + 2 * WK_BM * ROWB);      // [3][KS][16][EP_LD]
+  char* sA1 = smem + WN_BM * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gq = lane >> 4, li = lane & 15;
-  const int kw = w / 3, nw = w % 3;
   const T* __restrict__ A = reinterpret_cast<const T*>(g.A);
   const T* __restrict__ W = reinterpret_cast<const T*>(g.B);
   TC* __restrict__ C = reinterpret_cast<TC*>(g.C);
-  const int ntiles = (g.M + WK_BM - 1) / WK_BM;
+  const int ntiles = (g.M + WN_BM - 1) / WN_BM;
+  const int n = w * 16 + gq * 4;                       // this lane's four output columns
 
-  typename MM::Frag bf[4][6];
+  typename MM::Frag bf[KT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks)
-      bf[j][ks] = __builtin_bit_cast(typename MM::Frag, *reinterpret_cast<const u32x4*>(W + (size_t)(nw * 64 + j * 16 + li) * g.ldb + kw * 192 + (ks * 4 + gq) * 8));
+  for (int ks = 0; ks < KT; ++ks)
+    bf[ks] = __builtin_bit_cast(typename MM::Frag, *reinterpret_cast<const u32x4*>(W + (size_t)(w * 16 + li) * g.ldb + (ks * 4 + gq) * 8));
   float alpha = g.alpha;
   if (g.alpha_ptr) alpha *= *g.alpha_ptr;
   float d0 = 0.f, d1 = 1.f;
   if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
-
-  // reduction/epilogue role: the KS waves of an n-slice share its 16x64 sub-tile; this lane owns vectors vid + it*KS*64
-  const int vlane = kw * 64 + lane;
-  float bias_v[NIT][VN];                              // this lane's output columns never change: bias stays in registers
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int vid = vlane + it * KS * 64;
-    const int cc = (vid % (64 / VN)) * VN;
-#pragma unroll
-    for (int e = 0; e < VN; ++e)
-      bias_v[it][e] = ((EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) && vid < NVEC) ? g.bias[nw * 64 + cc + e] : 0.f;
-  }
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == UVC_EPI_BIAS || RES) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
 
   u32x4 ra[NLD];
   auto gload = [&](int tile) {
-    const int m0 = tile * WK_BM;
+    const int m0 = tile * WN_BM;
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int id = tid + NTH * i, row = id / CPR, c = id % CPR;
       const int m = m0 + row;
-      ra[i] = (row < WK_BM && m < g.M) ? *reinterpret_cast<const u32x4*>(A + (size_t)m * g.lda + c * 8) : z;
+      ra[i] = (row < WN_BM && m < g.M) ? *reinterpret_cast<const u32x4*>(A + (size_t)m * g.lda + c * 8) : z;
     }
   };
   auto lstore = [&](char* buf) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int id = tid + NTH * i, row = id / CPR, c = id % CPR;
-      if (row < WK_BM) *reinterpret_cast<u32x4*>(buf + row * ROWB + c * 16) = ra[i];
+      if (row < WN_BM) *reinterpret_cast<u32x4*>(buf + row * ROWB + c * 16) = ra[i];
     }
   };
-  struct Epi { f32x4 r[NIT]; f32x4 r2[NIT]; };
-  auto eload = [&](Epi& E, int tile_, int sub_) {
-    if (!(EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE)) return;
+  struct Epi { f32x4 r[2]; f32x4 r2[2]; };
+  auto eload = [&](Epi& E, int tile_) {
+    if (!RES) return;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int vid = vlane + it * KS * 64;
-      const int r = vid / (64 / VN), cc = (vid % (64 / VN)) * VN;
-      const int m = tile_ * WK_BM + sub_ * 16 + r;
-      const bool ok = vid < NVEC && m < g.M && tile_ < ntiles;
-      const size_t off = ok ? (size_t)m * g.ldr + nw * 64 + cc : 0;
-      E.r[it] = *reinterpret_cast<const f32x4*>(g.R + off);
-      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[it] = *reinterpret_cast<const f32x4*>(g.R2 + off);
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int m = tile_ * WN_BM + s2 * 16 + li;
+      const size_t off = (m < g.M && tile_ < ntiles) ? (size_t)m * g.ldr + n : 0;
+      E.r[s2] = *reinterpret_cast<const f32x4*>(g.R + off);
+      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[s2] = *reinterpret_cast<const f32x4*>(g.R2 + off);
     }
-  };
-  auto subtile = [&](const char* buf, int m0_, int sub_, const Epi& E) {
-    float* stg = sStage + (size_t)(nw * KS + kw) * 16 * EP_LD;
-    {
-      f32x4 c[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) c[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks) {                       // one A fragment live at a time, four independent MFMA chains
-        const typename MM::Frag fa = lds_frag<T>(buf + (sub_ * 16 + li) * ROWB + (kw * 24 + ks * 4 + gq) * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = MM::mma(bf[j][ks], fa, c[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(stg + li * EP_LD + j * 16 + gq * 4) = c[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int vid = vlane + it * KS * 64;
-      const int r = vid / (64 / VN), cc = (vid % (64 / VN)) * VN;
-      const int m = m0_ + sub_ * 16 + r;
-      if (vid < NVEC) {
-        float v[VN];
-#pragma unroll
-        for (int e = 0; e < VN; ++e) v[e] = 0.f;
-#pragma unroll
-        for (int q = 0; q < KS; ++q) {                       // fixed summation order over the k-slices
-          float t[VN];
-          load_vec<float, VN>(sStage + (size_t)(nw * KS + q) * 16 * EP_LD + r * EP_LD + cc, t);
-#pragma unroll
-          for (int e = 0; e < VN; ++e) v[e] += t[e];
-        }
-        if (m < g.M) {
-          const int n = nw * 64 + cc;
-#pragma unroll
-          for (int e = 0; e < VN; ++e) v[e] *= alpha;
-#pragma unroll
-          for (int e = 0; e < VN; ++e) v[e] += bias_v[it][e];
-          if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += E.r[it][e];
-          }
-          if (EPI == UVC_EPI_BIAS_RESID_GATE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = d1 * v[e] + d0 * E.r2[it][e];
-          }
-          OutVec<TC>::st(C + (size_t)m * g.ldc + n, v);
-        }
-      }
-    }
-    __syncthreads();
   };
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
-  Epi E0, E1;
+  Epi E, En;
   gload(tile);
-  eload(E0, tile, 0);
+  eload(E, tile);
   lstore(sA0);
   __syncthreads();
   int par = 0;
@@ -650,42 +582,66 @@ __global__ __launch_bounds__(KS * 192) void k_gemm_wsk(NtArgs g) {
     const int next = tile + gridDim.x;
     if (next < ntiles) gload(next);
     const char* buf = par ? sA1 : sA0;
-    const int m0 = tile * WK_BM;
-    eload(E1, tile, 1);
-    subtile(buf, m0, 0, E0);
-    eload(E0, next, 0);
-    subtile(buf, m0, 1, E1);
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+      const typename MM::Frag f0 = lds_frag<T>(buf + li * ROWB + (ks * 4 + gq) * 16);
+      const typename MM::Frag f1 = lds_frag<T>(buf + (16 + li) * ROWB + (ks * 4 + gq) * 16);
+      c0 = MM::mma(bf[ks], f0, c0);
+      c1 = MM::mma(bf[ks], f1, c1);
+    }
+    eload(En, next);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int m = tile * WN_BM + s2 * 16 + li;
+      f32x4 v = s2 ? c1 : c0;
+      if (m < g.M) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] * alpha + bias4[e];
+        if (RES) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += E.r[s2][e];
+        }
+        if (EPI == UVC_EPI_BIAS_RESID_GATE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = d1 * o[e] + d0 * E.r2[s2][e];
+        }
+        if (sizeof(TC) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
+        else { u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]); *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = q; }
+      }
+    }
+    E = En;
     if (next < ntiles) lstore(par ? sA0 : sA1);
     __syncthreads();
     par ^= 1;
   }
 }
 
-static bool wsk_ok(const NtArgs& a, int epi, bool a_f32, int vn) {
-  // measured: wins for the float32-output residual epilogues (fc2: 131 vs 153 us), loses to the generic kernel for bf16 outputs
-  return !a_f32 && vn == 4 && a.N == 192 && (a.K == 768 || a.K == 576) && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % vn == 0 && a.ldr % 4 == 0 &&
-         a.M >= 4096 && (epi == UVC_EPI_NONE || epi == UVC_EPI_BIAS || epi == UVC_EPI_BIAS_RESID || epi == UVC_EPI_BIAS_RESID_GATE);
+static bool wsn_ok(const NtArgs& a, int epi, bool a_f32) {
+  return !a_f32 && a.N == 192 && (a.K == 768 || a.K == 576) && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % 4 == 0 && a.ldr % 4 == 0 && a.M >= 4096 &&
+         (epi == UVC_EPI_NONE || epi == UVC_EPI_BIAS || epi == UVC_EPI_BIAS_RESID || epi == UVC_EPI_BIAS_RESID_GATE);
 }
-template <typename TC, int KS>
-static int launch_wsk_ks(const NtArgs& a, int epi, hipStream_t st) {
-  const int ntiles = ceil_div(a.M, WK_BM);
+template <typename TC, int KT>
+static int launch_wsn_kt(const NtArgs& a, int epi, hipStream_t st) {
+  const int ntiles = ceil_div(a.M, WN_BM);
   const int grid = ntiles < 256 ? ntiles : 256;                 // one persistent workgroup per CU
-  const size_t sh = (size_t)2 * WK_BM * (KS * 192 * 2 + 32) + (size_t)3 * KS * 16 * EP_LD * 4;
-#define WK_CASE(E) case E: { \
-    hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsk<TC, E, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+  const size_t sh = (size_t)2 * WN_BM * (KT * 64 + 32);
+#define WN_CASE(E) case E: { \
+    hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsn<TC, E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
-    k_gemm_wsk<TC, E, KS><<<grid, KS * 192, sh, st>>>(a); } break;
+    k_gemm_wsn<TC, E, KT><<<grid, 768, sh, st>>>(a); } break;
   switch (epi) {
-    WK_CASE(UVC_EPI_NONE) WK_CASE(UVC_EPI_BIAS) WK_CASE(UVC_EPI_BIAS_RESID) WK_CASE(UVC_EPI_BIAS_RESID_GATE)
-    default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue not supported by the K-split streaming kernel");
+    WN_CASE(UVC_EPI_NONE) WN_CASE(UVC_EPI_BIAS) WN_CASE(UVC_EPI_BIAS_RESID) WN_CASE(UVC_EPI_BIAS_RESID_GATE)
+    default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue not supported by the column-sliced streaming kernel");
   }
-#undef WK_CASE
+#undef WN_CASE
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }
 template <typename TC>
-static int launch_wsk(const NtArgs& a, int epi, hipStream_t st) {
-  return a.K == 768 ? launch_wsk_ks<TC, 4>(a, epi, st) : launch_wsk_ks<TC, 3>(a, epi, st);
+static int launch_wsn(const NtArgs& a, int epi, hipStream_t st) {
+  return a.K == 768 ? launch_wsn_kt<TC, 24>(a, epi, st) : launch_wsn_kt<TC, 18>(a, epi, st);
 }
 
 template <typename TA, typename T, typename TC>
@@ -726,8 +682,8 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   }
   if (p->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dtype must be UVC_F32 or UVC_BF16");
   const bool ws = !p->force_generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
-  if (!p->force_generic && wsk_ok(a, e, p->a_is_f32 != 0, p->c_is_f32 ? 4 : 8))
-    return p->c_is_f32 ? launch_wsk<float>(a, e, st) : launch_wsk<bf16_t>(a, e, st);
+  if (!p->force_generic && wsn_ok(a, e, p->a_is_f32 != 0))
+    return p->c_is_f32 ? launch_wsn<float>(a, e, st) : launch_wsn<bf16_t>(a, e, st);
   if (p->a_is_f32) {
     if ((p->lda % 8) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: lda");
     if (ws) return p->c_is_f32 ? launch_ws<float, float>(a, e, st) : launch_ws<float, bf16_t>(a, e, st);

@@ -107,6 +107,20 @@ int uvc_layernorm_fwd(const uvc_ln_args* args, void* stream);
 int uvc_layernorm_bwd(const uvc_ln_args* args, void* stream);
 int uvc_layernorm_bwd_blocks(int32_t rows);
 
+/* Fused inference MLP half of a block: out = x + fc2(GELU(fc1(LayerNorm(x)))) (model_distilled.py:153-166,186-189) for the
+ * no-grad forwards (teacher: utils/losses.py:47-49; eval).  x, out float32 [M, D]; w1 [F, D], w2 [D, F] are the bf16
+ * weight shadows; gamma/beta/b1/b2 float32.  Requires uvc_mlp_fused_supported(D, F, dtype) (D == 192, F % 64 == 0, bf16).
+ * The [M, F] hidden activation never reaches memory. */
+typedef struct uvc_mlp_args {
+  const float* x; const float* gamma; const float* beta;
+  const void* w1; const float* b1; const void* w2; const float* b2;
+  float* out;
+  int32_t M, D, F;
+  float eps;
+} uvc_mlp_args;
+int uvc_mlp_fused_supported(int32_t D, int32_t F, int32_t dtype);
+int uvc_mlp_fused_fwd(const uvc_mlp_args* args, void* stream);
+
 /* DistillationLoss over SoftTargetCrossEntropy (UVC/utils/losses.py:25-65, joint_train.py:940):
  * loss = (1-alpha) * mean_b sum_c -y log_softmax(o) + alpha * KL(softmax(t/T) || softmax(o_kd/T)) * T^2 / (B*C).
  * All float32 [B,C].  Writes loss[0] and the gradients d_o, d_okd (d_okd may alias d_o when

@@ -406,3 +406,36 @@ def test_gate_distrib_and_grad():
         dg = torch.empty(Lb, 2, device=dev())
         ops.gate_grad(g, d, dots, dg, Lb, mode, 0.1)
         torch.testing.assert_close(dg.double(), gd.grad, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,F_", [(1576, 768), (300, 768), (4096 + 37, 768), (515, 128)])
+def test_fused_inference_mlp(M, F_):
+    """uvc_mlp_fused_fwd = x + fc2(GELU(fc1(LayerNorm(x)))) with the hidden activation kept in registers, against float64
+    math on the same bf16-rounded weights (LayerNorm output and GELU output are rounded to bf16 as in the unfused path),
+    and against the unfused kernel sequence."""
+    from uvc_amd import ops
+    D = 192
+    x = rnd(M, D, seed=101) * 1.5 + 0.2
+    gamma, beta = rnd(D, seed=102) * 0.2 + 1.0, rnd(D, seed=103) * 0.1
+    W1, b1 = rnd(F_, D, seed=104, scale=0.06).bfloat16(), rnd(F_, seed=105) * 0.1
+    W2, b2 = rnd(D, F_, seed=106, scale=0.04).bfloat16(), rnd(D, seed=107) * 0.1
+    out = torch.full((M, D), float("nan"), device=dev())
+    ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, out)
+    xd = x.double()
+    h = F.layer_norm(xd, (D,), gamma.double(), beta.double(), 1e-6).bfloat16().double()
+    u = F.gelu(h @ W1.double().t() + b1.double()).bfloat16().double()
+    ref = xd + u @ W2.double().t() + b2.double()
+    torch.testing.assert_close(out.double(), ref, rtol=2e-3, atol=6e-3)
+    # the unfused sequence of the same library
+    hb = torch.empty(M, D, device=dev(), dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.layernorm_fwd(x, gamma, beta, hb, mean, rstd, M, D, BF16)
+    ub = torch.empty(M, F_, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(hb, W1, ub, dtype=BF16, epilogue=ops.EPI_BIAS_GELU_OUT, bias=b1)
+    o2 = torch.empty(M, D, device=dev())
+    ops.gemm_nt(ub, W2, o2, dtype=BF16, epilogue=ops.EPI_BIAS_RESID, bias=b2, R=x)
+    torch.testing.assert_close(out, o2, rtol=2e-3, atol=6e-3)
+    for _ in range(2):                       # deterministic
+        o3 = torch.empty_like(out)
+        ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, o3)
+        assert torch.equal(o3, out)

@@ -95,6 +95,11 @@ def main():
         dg, db, dots = torch.empty(D, device=dev), torch.empty(D, device=dev), torch.empty(2, device=dev)
         rec("ln_bwd +add1", timeit(lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx, part, dg, db, M, D, dt, add1=g32, a1=gate[1:])), M * D * 14)
         rec("ln_bwd +add1+add2+dots", timeit(lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx, part, dg, db, M, D, dt, add1=g32, add2=dx, a2=gate[:1], dots=dots)), M * D * 18)
+    if want("mlp_fused"):
+        gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+        o32 = torch.empty(M, D, device=dev)
+        rec("mlp_fused (LN+fc1+GELU+fc2+resid, inference)", timeit(lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32)),
+            M * D * 8, 4.0 * M * D * F)
     if want("attn"):
         qkv = torch.randn(B, N, 3 * D, device=dev).to(bf)
         o = torch.empty(B, N, D, device=dev, dtype=bf)

@@ -66,6 +66,11 @@ class uvc_ln_args(C.Structure):
                [("group_stride", C.c_int64), ("g_lowp", C.c_int32)]
 
 
+class uvc_mlp_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "gamma", "beta", "w1", "b1", "w2", "b2", "out")] + \
+               [(n, C.c_int32) for n in ("M", "D", "F")] + [("eps", C.c_float)]
+
+
 class uvc_loss_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("o", "o_kd", "y_soft", "teacher", "loss", "d_o", "d_okd", "row_scratch")] + \
                [("alpha", C.c_float), ("tau", C.c_float), ("B", C.c_int32), ("C", C.c_int32), ("kind", C.c_int32)]
@@ -118,6 +123,8 @@ _SIGNATURES = {
     "uvc_colsum_blocks": [I32],
     "uvc_apply_masks": [VP, VP, I64, VP],
     "uvc_stream_create": [I32, C.POINTER(VP)],
+    "uvc_mlp_fused_supported": [I32, I32, I32],
+    "uvc_mlp_fused_fwd": [C.POINTER(uvc_mlp_args), VP],
     "uvc_cast_transpose": [VP, I32, I32, VP, VP, I32, VP],
     "uvc_cast_transpose_multi": [VP, VP, I32, VP, VP, VP, VP, VP, I32, VP],
     "uvc_gate_distrib": [VP, VP, VP, I32, I32, F32, VP],

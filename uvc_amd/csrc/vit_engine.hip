@@ -369,6 +369,15 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, UVC_EPI_BIAS, P + q[3]));
     TRY(attn(c, b, false));
     TRY(nt(c, b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), b.x1, 1, d.M, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xin));
+    if (!io->training && !io->gate_d && uvc_mlp_fused_supported(d.D, d.F, d.dtype)) {
+      // no-grad forward (teacher / eval): LayerNorm + fc1 + GELU + fc2 + residual in one kernel, hidden activation in registers
+      uvc_mlp_args m;
+      m.x = b.x1; m.gamma = P + q[6]; m.beta = P + q[7]; m.w1 = wmat(c, q[8], c.soff.blk_w[l][2]); m.b1 = P + q[9];
+      m.w2 = wmat(c, q[10], c.soff.blk_w[l][3]); m.b2 = P + q[11]; m.out = xout; m.M = d.M; m.D = d.D; m.F = d.F; m.eps = 1e-6f;
+      TRY(uvc_mlp_fused_fwd(&m, c.st));
+      xin = xout;
+      continue;
+    }
     TRY(ln_fwd(c, b.x1, q[6], q[7], b.h2, b.mean2, b.rstd2, d.M, 1, d.D));
     if (io->training)
       TRY(nt(c, b.h2, 0, wmat(c, q[8], c.soff.blk_w[l][2]), b.a, 0, d.M, d.F, d.D, UVC_EPI_BIAS_GELU, P + q[9], nullptr, nullptr, nullptr, nullptr, b.u));

@@ -133,6 +133,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, rows, D,
     L.check(L.lib().uvc_layernorm_bwd(C.byref(a), L.cur_stream()), "uvc_layernorm_bwd")
 
 
+def mlp_fused_fwd(x, gamma, beta, w1, b1, w2, b2, out, eps=1e-6):
+    """out = x + fc2(GELU(fc1(LayerNorm(x)))) for [M, 192] float32 rows; w1 [F,192] / w2 [192,F] bf16."""
+    _chk(x, gamma, beta, w1, b1, w2, b2, out)
+    a = L.uvc_mlp_args()
+    a.x, a.gamma, a.beta, a.w1, a.b1, a.w2, a.b2, a.out = (L.ptr(t) for t in (x, gamma, beta, w1, b1, w2, b2, out))
+    a.M, a.D, a.F, a.eps = x.shape[0], x.shape[1], w1.shape[0], eps
+    L.check(L.lib().uvc_mlp_fused_fwd(C.byref(a), L.cur_stream()), "uvc_mlp_fused_fwd")
+
+
 def distill_loss(o, o_kd, y_soft, teacher, loss, d_o, d_okd, row_scratch, alpha, tau, kind=1):
     _chk(o, o_kd, y_soft, teacher, loss, d_o, d_okd, row_scratch)
     a = L.uvc_loss_args()

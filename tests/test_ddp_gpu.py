@@ -1,0 +1,37 @@
+"""GPU: the data-parallel path on a real RCCL communicator.  The GPU box has one device, so the communicator has one
+rank; what this checks is that the product's bucketed backward issues its collectives (async ReduceOp.AVG on slices of
+the flat gradient buffer from a side stream, broadcast, barrier) correctly through torch.distributed's "nccl" backend and
+that the overlapped result is bit-identical to the single-process step.  Multi-rank arithmetic is covered on CPU/gloo
+(tests/test_ddp_cpu.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bucketed_allreduce_on_rccl_single_rank():
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(here, "ddp_single_rank_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DDP_SINGLE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_contract_under_torchrun_single_rank():
+    """The driver's launch line with one rank: RANK/LOCAL_RANK/WORLD_SIZE from the environment, one JSON line on stdout."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "32",
+           "--no_cpu_baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0

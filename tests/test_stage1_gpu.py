@@ -175,3 +175,41 @@ def test_bucketed_backward_is_identical_to_the_single_call_backward():
         grads.append((run.model._flat_grad[:run.model._off.n_total].clone(), float(out["loss"]), float(run.minimax.z)))
     assert grads[0][1] == grads[1][1] and grads[0][2] == grads[1][2]
     assert torch.equal(grads[0][0], grads[1][0])
+
+
+def test_training_state_resume_is_bit_identical(tmp_path):
+    """the engine's own training state (model + masks, s r y p z, gate momentum / accumulators, eps, AdamW
+    moments and step counts, schedule position) restores a fresh trainer so that the next step is bit-identical to the
+    uninterrupted run."""
+    name = "micro_pruned"
+    gold = load_golden(name)
+
+    def steps(run, lo, hi):
+        r = run.r
+        x_all, y_all = SC.make_inputs(r)
+        out = None
+        for st in range(lo, hi):
+            md, e1, e2 = split_draws(r, gold, st, run.cfg.depth)
+            run.inject_draws(md, e1, e2)
+            out = run.step(torch.from_numpy(x_all[st]).cuda(), torch.from_numpy(y_all[st]).cuda())
+            run.optimizer.zero_grad()
+        return out
+
+    a = Stage1Run(name, precision="fp32")
+    out_a = steps(a, 0, 4)
+    b = Stage1Run(name, precision="fp32")
+    steps(b, 0, 3)
+    path = str(tmp_path / "state.pth.tar")
+    torch.save(b.trainer.state_dict(), path)
+    c = Stage1Run(name, precision="fp32")                 # fresh process-equivalent: new model, optimiser, minimax
+    c.trainer.load_state_dict(torch.load(path, map_location="cuda"))
+    out_c = steps(c, 3, 4)
+    assert float(out_a["loss"]) == float(out_c["loss"]) and float(out_a["cur"]) == float(out_c["cur"])
+    assert torch.equal(a.model._flat, c.model._flat)
+    for k in ("s", "r", "y", "p", "z"):
+        assert torch.equal(getattr(a.minimax, k).data, getattr(c.minimax, k).data), k
+    assert torch.equal(a.optimizer.exp_avg, c.optimizer.exp_avg) and a.optimizer.steps == c.optimizer.steps
+    assert a.trainer.global_step == c.trainer.global_step == 4
+    assert a.optimizer.param_groups[0]["lr"] == c.optimizer.param_groups[0]["lr"]
+    with pytest.raises(ValueError):
+        c.trainer.load_state_dict(a.model.state_dict())   # the reference-format checkpoint is not a training state

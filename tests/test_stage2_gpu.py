@@ -137,3 +137,25 @@ def test_skipped_blocks_are_untouched_and_masked_weights_are_zeroed():
     with torch.no_grad():
         _, macs = model(torch.from_numpy(x_all[0]).cuda())
     assert [int(len(b) > 0) for b in macs[1]] == [int(b != skipped) for b in range(cfg.depth)]
+
+
+def test_stage2_state_resume_is_bit_identical(tmp_path):
+    r, cfg, a = build("stage2_micro_skip", "fp32")
+    x_all, y_all = SC.make_inputs(r)
+    xs = [torch.from_numpy(x).cuda() for x in x_all]; ys = [torch.from_numpy(y).cuda() for y in y_all]
+    a.begin_epoch(1)
+    for i in range(3):
+        out_a = a.step(xs[i], ys[i])
+    _, _, b = build("stage2_micro_skip", "fp32")
+    b.begin_epoch(1)
+    for i in range(2):
+        b.step(xs[i], ys[i])
+    path = str(tmp_path / "s2.pth.tar")
+    torch.save(b.state_dict(), path)
+    _, _, c = build("stage2_micro_skip", "fp32")
+    c.load_state_dict(torch.load(path, map_location="cuda"))
+    c.begin_epoch(c.epoch)
+    out_c = c.step(xs[2], ys[2])
+    assert float(out_a["loss"]) == float(out_c["loss"])
+    assert torch.equal(a.model._flat, c.model._flat) and torch.equal(a.optimizer.exp_avg_sq, c.optimizer.exp_avg_sq)
+    assert a.global_step == c.global_step == 3

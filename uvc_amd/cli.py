@@ -74,6 +74,8 @@ def build_parser():
     a("--synthetic", type=int, default=1, help="synthetic ImageNet-shaped batches (no torchvision in this image)")
     a("--steps_per_epoch", type=int, default=5005, help="len(train_loader) for synthetic data (ImageNet @256 = 5005)")
     a("--num_classes", type=int, default=1000)
+    a("--resume", type=str, default=None, help="engine training state written by --save_state (complete: s r y p z, AdamW, schedule)")
+    a("--save_state", type=int, default=1, help="also write <name>/<model>_state_<epoch>.pth.tar (resumable) next to the reference-format checkpoint")
     return p
 
 
@@ -112,7 +114,13 @@ def main(argv=None):
         print("***** [Stage 1] Training with ADMM *****")
         print(f"  Instantaneous batch size per GPU = {args.train_batch_size}")
         print(f"  Total train batch size (w. parallel, distributed & accumulation) = {args.train_batch_size * args.gradient_accumulation_steps * world}")
-    for epoch in range(1, args.num_epochs + 2):       # `while epoch <= num_epochs: epoch += 1` (:331-335)
+    first_epoch = 1
+    if args.resume:
+        tr.load_state_dict(torch.load(args.resume, map_location=device))
+        first_epoch = tr.epoch + 1
+        if rank == 0:
+            print(f"resumed from {args.resume}: epoch {tr.epoch} done, global step {tr.global_step}")
+    for epoch in range(first_epoch, args.num_epochs + 2):       # `while epoch <= num_epochs: epoch += 1` (:331-335)
         tr.begin_epoch(epoch)
         stage = "Warm Up" if tr.model.enable_warmup else "UVC Train"
         remained = float(count_mask(tr.model))
@@ -137,6 +145,8 @@ def main(argv=None):
         prune_w_mask(tr.minimax, tr.optimizer)                                                   # :500
         remained = float(count_mask(tr.model))
         save_model(args, tr.model, tr.minimax, epoch)                                            # :502
+        if args.save_state and rank == 0:
+            torch.save(tr.state_dict(), os.path.join(out_dir, f"{args.model_type}_state_{epoch}.pth.tar"))
         if rank == 0:
             print(f"[Validation Sparsity|Step {tr.global_step}|Epoch {epoch}]")
             print(f"Parameter size: {remained:.2f}M / {float(args.total_param):.2f}M = {remained / float(args.total_param) * 100:.2f}%")

@@ -114,6 +114,22 @@ class Stage2Trainer:
         return dict(loss=loss.detach(), outputs=outputs, gnorm=gnorm)
 
 
+    # resumable state (the reference saves only the best model's bare state_dict, post_train.py:395-397)
+    def state_dict(self):
+        o = self.optimizer
+        return dict(format="uvc_amd.stage2.v1", model=self.model.state_dict(),
+                    adamw=dict(exp_avg=o.exp_avg.clone(), exp_avg_sq=o.exp_avg_sq.clone(), steps=dict(o.steps), lr=o.param_groups[0]["lr"]),
+                    progress=dict(global_step=self.global_step, epoch=self.epoch))
+
+    def load_state_dict(self, sd):
+        if sd.get("format") != "uvc_amd.stage2.v1":
+            raise ValueError("not a uvc_amd Stage-2 training state")
+        self.model.load_state_dict(sd["model"])
+        a, o = sd["adamw"], self.optimizer
+        o.exp_avg.copy_(a["exp_avg"]); o.exp_avg_sq.copy_(a["exp_avg_sq"]); o.steps = dict(a["steps"]); o.param_groups[0]["lr"] = a["lr"]
+        self.global_step, self.epoch = int(sd["progress"]["global_step"]), int(sd["progress"]["epoch"])
+
+
 def post_training(trainer: Stage2Trainer, batches, epochs=None, valid_fn=None, log=print):
     """The epoch loop of post_train.py:326-403 over an iterable factory ``batches(epoch)`` of device (x, y) pairs
     (mixup already applied); ``valid_fn(model) -> accuracy`` drives the save-best policy (:393-399)."""

@@ -143,3 +143,57 @@ class Stage1Trainer:
         if zero_grad:
             self.optimizer.zero_grad()
         return dict(loss=loss.detach(), outputs=outputs, gnorm=gnorm, cur=cur, s=s, r=r, g=g)
+
+    # -- resumable training state.  The reference's checkpoint is the bare model state_dict and it cannot
+    # resume Stage-1: s, r, y, p, z, eps, the optimiser moments and the schedule position are lost (Q10).  save_model keeps
+    # writing that file unchanged (Stage-2 loads it); this is the engine's own, separate, complete state.
+    def state_dict(self):
+        mm, opt = self.minimax, self.optimizer
+        return dict(
+            format="uvc_amd.stage1.v1",
+            model=self.model.state_dict(),
+            uvc=dict(s=mm.s.data.clone(), r=mm.r.data.clone(), y=mm.y.data.clone(), p=mm.p.data.clone(), z=mm.z.data.clone(),
+                     gate_momentum=mm._gate_momentum.clone(), gate_gsum=mm._gate_gsum.clone(), gate_counters=mm._gate_counters.clone(),
+                     gating_list_len=mm.gating_list_len, eps=float(self.model.eps),
+                     patch_gating=None if mm.patch_gating is None else mm.patch_gating.data.clone()),
+            adamw=dict(exp_avg=opt.exp_avg.clone(), exp_avg_sq=opt.exp_avg_sq.clone(), steps=dict(opt.steps),
+                       lr=opt.param_groups[0]["lr"]),
+            scheduler=self.scheduler.state_dict(),
+            lrs=dict(s=self.s_opt.param_groups[0]["lr"], r=self.r_opt.param_groups[0]["lr"],
+                     g=None if self.g_opt is None else self.g_opt.param_groups[0]["lr"],
+                     dual=[g["lr"] for g in self.dual_opt.param_groups]),
+            progress=dict(global_step=self.global_step, epoch=self.epoch, gating_grad_list_len=len(self.gating_grad_list),
+                          enable_warmup=int(self.model.enable_warmup), args_enable_warmup=int(self.args.enable_warmup)),
+        )
+
+    def load_state_dict(self, sd):
+        if sd.get("format") != "uvc_amd.stage1.v1":
+            raise ValueError("not a uvc_amd Stage-1 training state (the reference's checkpoint is the bare model state_dict: "
+                             "load that with model.load_state_dict)")
+        mm, opt = self.minimax, self.optimizer
+        self.model.load_state_dict(sd["model"])
+        u = sd["uvc"]
+        for k in ("s", "r", "y", "p", "z"):
+            getattr(mm, k).data.copy_(u[k])
+        mm._gate_momentum.copy_(u["gate_momentum"]); mm._gate_gsum.copy_(u["gate_gsum"]); mm._gate_counters.copy_(u["gate_counters"])
+        mm.gating_list_len = int(u["gating_list_len"])
+        self.model.eps = float(u["eps"])
+        if u.get("patch_gating") is not None and mm.patch_gating is not None:
+            mm.patch_gating.data.copy_(u["patch_gating"])
+        a = sd["adamw"]
+        opt.exp_avg.copy_(a["exp_avg"]); opt.exp_avg_sq.copy_(a["exp_avg_sq"]); opt.steps = dict(a["steps"])
+        self.scheduler.load_state_dict(sd["scheduler"])
+        opt.param_groups[0]["lr"] = a["lr"]
+        l = sd["lrs"]
+        self.s_opt.param_groups[0]["lr"] = l["s"]; self.r_opt.param_groups[0]["lr"] = l["r"]
+        if self.g_opt is not None and l["g"] is not None:
+            self.g_opt.param_groups[0]["lr"] = l["g"]
+        for g, v in zip(self.dual_opt.param_groups, l["dual"]):
+            g["lr"] = v
+        pr = sd["progress"]
+        self.global_step, self.epoch = int(pr["global_step"]), int(pr["epoch"])
+        self.gating_grad_list = [None] * int(pr["gating_grad_list_len"])
+        self.model.enable_warmup = int(pr["enable_warmup"])
+        self.args.enable_warmup = int(pr["args_enable_warmup"])
+        self.model.block_skip_gating.requires_grad = not self.model.enable_warmup
+        self.model.mark_weights_changed()

@@ -184,6 +184,14 @@ int uvc_patch_topk_mask_bwd(const float* dmask, const float* ysoft, const float*
 /* X[row,:] += row_weight[row] * w[:]   (X of type T, or float32 when x_is_f32) */
 int uvc_add_outer(void* X, const float* row_weight, const float* w, int32_t rows, int32_t D, int32_t dtype, int32_t x_is_f32, void* stream);
 int uvc_colsum_blocks(int32_t M);
+/* timm.data.Mixup in "batch" mode (joint_train.py:409,924-933; post_train.py:362,618-621), in place on the device:
+ * uvc_mixup_batch: x [B,C,H,W] float32, B even; mixup: x = x*lam + x.flip(0)*(1-lam) (both factors passed already rounded
+ * to float32); cutmix: x[:,:,yl:yh,xl:xh] = x.flip(0)[:,:,yl:yh,xl:xh].
+ * uvc_mixup_target: y [B,C] = onehot(t)*lam + onehot(t.flip(0))*(1-lam) with on/off values of label smoothing. */
+int uvc_mixup_batch(float* x, int32_t B, int32_t C, int32_t H, int32_t W, float lam, float one_minus_lam, int32_t use_cutmix,
+                    int32_t yl, int32_t yh, int32_t xl, int32_t xh, void* stream);
+int uvc_mixup_target(const int64_t* labels, float* y, int32_t B, int32_t C, float lam, float one_minus_lam, float on_value,
+                     float off_value, void* stream);
 /* params[i] *= mask[i] over a flat parameter buffer: the Stage-2 `m.weight.data *= m.mask` for every module with a
  * mask buffer (post_train.py:343-346); mask is 1 where no module mask covers the element (biases, tokens). */
 int uvc_apply_masks(float* params, const float* mask, int64_t n, void* stream);

@@ -17,6 +17,7 @@ import json
 import os
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -79,11 +80,31 @@ def build_parser():
     return p
 
 
-def iterate_batches(args, device, rank):
+def build_mixup(args):
+    """joint_train.py:922-933."""
+    from .mixup import Mixup
+    mixup_active = args.mixup > 0 or args.cutmix > 0. or args.cutmix_minmax is not None
+    if not mixup_active:
+        return None
+    return Mixup(mixup_alpha=args.mixup, cutmix_alpha=args.cutmix, cutmix_minmax=args.cutmix_minmax, prob=args.mixup_prob,
+                 switch_prob=args.mixup_switch_prob, mode=args.mixup_mode, label_smoothing=args.smoothing, num_classes=args.num_classes)
+
+
+def iterate_batches(args, device, rank, mixup_fn=None):
+    """Synthetic ImageNet-shaped batches with hard labels, passed through the on-device Mixup / CutMix exactly where the
+    reference calls mixup_fn (joint_train.py:399-409: odd batches lose their last sample first); without mixup the
+    labels become smoothed one-hot soft targets."""
     g = torch.Generator(device=device).manual_seed(args.seed + 1000 * rank)
     for _ in range(args.steps_per_epoch):
         x = torch.randn(args.train_batch_size, 3, args.img_size, args.img_size, device=device, generator=g)
-        y = torch.softmax(2 * torch.randn(args.train_batch_size, args.num_classes, device=device, generator=g), -1)
+        t = torch.randint(0, args.num_classes, (args.train_batch_size,), device=device, generator=g)
+        if len(x) % 2 != 0:
+            x, t = x[:-1].contiguous(), t[:-1]
+        if mixup_fn is not None:
+            x, y = mixup_fn(x, t)
+        else:
+            off = args.smoothing / args.num_classes
+            y = torch.full((len(x), args.num_classes), off, device=device).scatter_(1, t.view(-1, 1), 1.0 - args.smoothing + off)
         yield x, y
 
 
@@ -104,6 +125,10 @@ def main(argv=None):
     torch.manual_seed(args.seed)                      # same seed on every rank (joint_train.py:191-196,914)
     args.train_batch_size = args.train_batch_size // args.gradient_accumulation_steps
     tr = Stage1Trainer(args, device=device, distributed=world > 1)
+    np.random.seed(args.seed)                         # Mixup draws from numpy's global RNG (set_seed, joint_train.py:191-196)
+    mixup_fn = build_mixup(args)
+    if rank == 0:
+        print(f"mixup active: {mixup_fn is not None}")
     out_dir = os.path.join(args.output_dir, args.name)
     stamp = time.strftime("%Y-%m-%d-%H:%M:%S", time.localtime())
     logs = {k: os.path.join(out_dir, f"{k}_{stamp}.json") for k in ("s", "r", "gating")}
@@ -129,7 +154,7 @@ def main(argv=None):
             print(f"Start [Epoch {epoch}] at Stage {stage}")
             print(f"[Initial Sparsity|Epoch {epoch}] Parameter size: {remained:.2f}M / {float(args.total_param):.2f}M = {remained / float(args.total_param) * 100:.2f}%")
         t0 = time.time()
-        for step, (x, y) in enumerate(iterate_batches(args, device, rank)):
+        for step, (x, y) in enumerate(iterate_batches(args, device, rank, mixup_fn)):
             out = tr.step(x, y)
             gs = tr.global_step
             if rank == 0 and gs % args.log_interval == 0:

@@ -336,6 +336,52 @@ __global__ __launch_bounds__(256) void k_apply_masks(float* __restrict__ p, cons
     for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) p[i] *= mask[i];
 }
 
+// ---------------------------------------------------------------------------- Mixup / CutMix (timm.data.Mixup, mode "batch")
+// image b is mixed with image B-1-b (x.flip(0)); a thread owns the same 4 pixels of both images of a pair, so the in-place
+// update needs no temporary.  Products and sum are rounded separately, like x.mul_(lam).add_(x.flip(0).mul_(1 - lam)).
+__global__ __launch_bounds__(256) void k_mixup(float* __restrict__ x, int B, int64_t chw4, float lam, float oml) {
+  // three separately rounded operations: hipcc contracts a*b + c*d (also through __fmul_rn / __fadd_rn and under a contract(off)
+  // pragma) into v_fmac; fma(a, b, 0) is the correctly rounded product and cannot be fused with the following add
+  const int64_t total = (int64_t)(B / 2) * chw4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int b = (int)(idx / chw4);
+    const int64_t i = idx % chw4;
+    f32x4* pa = reinterpret_cast<f32x4*>(x) + (int64_t)b * chw4 + i;
+    f32x4* pc = reinterpret_cast<f32x4*>(x) + (int64_t)(B - 1 - b) * chw4 + i;
+    const f32x4 a = *pa, c = *pc;
+    f32x4 na, nc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      na[e] = __builtin_fmaf(a[e], lam, 0.0f) + __builtin_fmaf(c[e], oml, 0.0f);
+      nc[e] = __builtin_fmaf(c[e], lam, 0.0f) + __builtin_fmaf(a[e], oml, 0.0f);
+    }
+    *pa = na; *pc = nc;
+  }
+}
+// x[:, :, yl:yh, xl:xh] = x.flip(0)[:, :, yl:yh, xl:xh]: the box is swapped inside each pair
+__global__ __launch_bounds__(256) void k_cutmix(float* __restrict__ x, int B, int C, int H, int W, int yl, int yh, int xl, int xh) {
+  const int bw = xh - xl, bh = yh - yl;
+  const int64_t total = (int64_t)(B / 2) * C * bh * bw;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int px = (int)(idx % bw), py = (int)((idx / bw) % bh), c = (int)((idx / ((int64_t)bw * bh)) % C), b = (int)(idx / ((int64_t)bw * bh * C));
+    const int64_t o = ((int64_t)c * H + (yl + py)) * W + xl + px;
+    float* pa = x + (int64_t)b * C * H * W + o;
+    float* pc = x + (int64_t)(B - 1 - b) * C * H * W + o;
+    const float a = *pa, cc = *pc;
+    *pa = cc; *pc = a;
+  }
+}
+// mixup_target: y = onehot_smooth(t) * lam + onehot_smooth(t.flip(0)) * (1 - lam)
+__global__ __launch_bounds__(256) void k_mixup_target(const int64_t* __restrict__ t, float* __restrict__ y, int B, int C, float lam, float oml,
+                                                      float on, float off) {
+  const int64_t total = (int64_t)B * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int b = (int)(idx / C), c = (int)(idx % C);
+    const float v1 = t[b] == c ? on : off, v2 = t[B - 1 - b] == c ? on : off;
+    y[idx] = __builtin_fmaf(v1, lam, 0.0f) + __builtin_fmaf(v2, oml, 0.0f);
+  }
+}
+
 inline int grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -447,6 +493,31 @@ extern "C" int uvc_add_outer(void* X, const float* row_weight, const float* w, i
   if (!X || !row_weight || !w || rows <= 0 || D <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_add_outer: bad argument");
   if (dtype == UVC_F32 || x_is_f32) k_add_outer<float><<<grid_for((int64_t)rows * D), 256, 0, (hipStream_t)stream>>>((float*)X, row_weight, w, rows, D);
   else k_add_outer<bf16_t><<<grid_for((int64_t)rows * D), 256, 0, (hipStream_t)stream>>>((bf16_t*)X, row_weight, w, rows, D);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_mixup_batch(float* x, int32_t B, int32_t C, int32_t H, int32_t W, float lam, float one_minus_lam, int32_t use_cutmix,
+                               int32_t yl, int32_t yh, int32_t xl, int32_t xh, void* stream) {
+  if (!x || B <= 0 || (B & 1) || C <= 0 || H <= 0 || W <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mixup_batch: needs an even batch (timm asserts the same)");
+  hipStream_t st = (hipStream_t)stream;
+  if (use_cutmix) {
+    if (yl < 0 || xl < 0 || yh > H || xh > W || yl > yh || xl > xh) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mixup_batch: bad box");
+    if (yh == yl || xh == xl) return UVC_OK;
+    k_cutmix<<<grid_for((int64_t)(B / 2) * C * (yh - yl) * (xh - xl)), 256, 0, st>>>(x, B, C, H, W, yl, yh, xl, xh);
+  } else {
+    const int64_t chw = (int64_t)C * H * W;
+    if (chw % 4 || ((uintptr_t)x & 15)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mixup_batch: image size must be a multiple of 4 floats, 16-byte aligned");
+    k_mixup<<<grid_for((int64_t)(B / 2) * (chw / 4)), 256, 0, st>>>(x, B, chw / 4, lam, one_minus_lam);
+  }
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_mixup_target(const int64_t* labels, float* y, int32_t B, int32_t C, float lam, float one_minus_lam, float on_value,
+                                float off_value, void* stream) {
+  if (!labels || !y || B <= 0 || C <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mixup_target: bad argument");
+  k_mixup_target<<<grid_for((int64_t)B * C), 256, 0, (hipStream_t)stream>>>(labels, y, B, C, lam, one_minus_lam, on_value, off_value);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -40,6 +40,7 @@ def parse():
     p.add_argument("--stage", type=int, default=1, choices=[1, 2],
                    help="1 = the headline Stage-1 UVC-train step; 2 = the Stage-2 masked fine-tune step (SURVEY §8 f-1)")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--serialize", type=int, default=0, help="diagnostic: 1 = teacher forward and weight gradients on the main stream (no overlap)")
     p.add_argument("--cpu_steps", type=int, default=6)
     return p.parse_args()
 
@@ -180,6 +181,9 @@ def main():
         tr = Stage1Trainer(a, device=f"cuda:{local}", distributed=world > 1)
         pruned_state(tr)
         tr.begin_epoch(a.warmup_epochs + 1)             # UVC-train phase (post warm-up), SURVEY.md §8d
+    if args.serialize:
+        tr.model.two_stream_backward = False
+        a.overlap_teacher = 0
     dev = torch.device("cuda", local)
     g = torch.Generator(device=dev).manual_seed(730 + rank)
     x = torch.randn(args.batch, 3, a.img_size, a.img_size, device=dev, generator=g)

@@ -47,6 +47,7 @@ def main():
     xb = x32.to(bf)
     hF = torch.randn(M, F, device=dev).to(bf)
     g32 = torch.randn(M, D, device=dev)
+    g16 = g32.to(bf)               # the backward's dL/dx streams are bf16 in the throughput mode
     bD, bF, b3 = torch.zeros(D, device=dev), torch.zeros(F, device=dev), torch.zeros(3 * D, device=dev)
     Wqkv = (torch.randn(3 * D, D, device=dev) * .02).to(bf)
     Wp = (torch.randn(D, D, device=dev) * .02).to(bf)
@@ -66,12 +67,12 @@ def main():
         rec("gemm_nt fc2   resid+gate   K=F N=D", timeit(lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate)),
             M * F * 2 + M * D * 12, 2.0 * M * D * F)
         dA = torch.empty(M, F, device=dev, dtype=bf)
-        rec("gemm_nt dfc2  dgelu f32src K=D N=F", timeit(lambda: ops.gemm_nt(g32, W1, dA, dtype=dt, epilogue=ops.EPI_DGELU, aux=hF, alpha_ptr=gate)),
+        rec("gemm_nt dfc2  dgelu        K=D N=F", timeit(lambda: ops.gemm_nt(g16, W1, dA, dtype=dt, epilogue=ops.EPI_DGELU, aux=hF, alpha_ptr=gate)),
             M * D * 4 + 2 * M * F * 2, 2.0 * M * D * F)
         dH = torch.empty(M, D, device=dev, dtype=bf)
         rec("gemm_nt dfc1  none         K=F N=D", timeit(lambda: ops.gemm_nt(hF, W2, dH, dtype=dt, epilogue=ops.EPI_NONE)),
             M * F * 2 + M * D * 2, 2.0 * M * D * F)
-        rec("gemm_nt dproj none f32src  K=D N=D", timeit(lambda: ops.gemm_nt(g32, Wp, dH, dtype=dt, epilogue=ops.EPI_NONE)),
+        rec("gemm_nt dproj none         K=D N=D", timeit(lambda: ops.gemm_nt(g16, Wp, dH, dtype=dt, epilogue=ops.EPI_NONE)),
             M * D * 4 + M * D * 2, 2.0 * M * D * D)
         q3 = torch.randn(M, 3 * D, device=dev).to(bf)
         Wt = (torch.randn(D, 3 * D, device=dev) * .02).to(bf)
@@ -81,9 +82,9 @@ def main():
         ws = torch.empty(max(ops.gemm_tn_workspace_bytes(M, F, D), ops.gemm_tn_workspace_bytes(M, D, F), ops.gemm_tn_workspace_bytes(M, 3 * D, D)) // 4, device=dev)
         C1, C2, C3, C4 = torch.empty(D, F, device=dev), torch.empty(F, D, device=dev), torch.empty(D, D, device=dev), torch.empty(3 * D, D, device=dev)
         q3 = torch.randn(M, 3 * D, device=dev).to(bf)
-        rec("gemm_tn dW2 f32src  [D,F]", timeit(lambda: ops.gemm_tn(g32, hF, C1, ws, dtype=dt)), M * D * 4 + M * F * 2, 2.0 * M * D * F)
+        rec("gemm_tn dW2         [D,F]", timeit(lambda: ops.gemm_tn(g16, hF, C1, ws, dtype=dt)), M * D * 2 + M * F * 2, 2.0 * M * D * F)
         rec("gemm_tn dW1         [F,D]", timeit(lambda: ops.gemm_tn(hF, xb, C2, ws, dtype=dt)), M * D * 2 + M * F * 2, 2.0 * M * D * F)
-        rec("gemm_tn dWp f32src  [D,D]", timeit(lambda: ops.gemm_tn(g32, xb, C3, ws, dtype=dt)), M * D * 6, 2.0 * M * D * D)
+        rec("gemm_tn dWp         [D,D]", timeit(lambda: ops.gemm_tn(g16, xb, C3, ws, dtype=dt)), M * D * 4, 2.0 * M * D * D)
         rec("gemm_tn dWqkv       [3D,D]", timeit(lambda: ops.gemm_tn(q3, xb, C4, ws, dtype=dt)), M * D * 8, 2.0 * M * D * 3 * D)
     if want("ln"):
         gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)

@@ -968,6 +968,154 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_big(TnArgs g) {
   }
 }
 
+// ---- big-tile variant with LDS-DMA staging (bf16 A and B): same tiles and split-M scheme as k_gemm_tn_big, but the operand
+// rows go HBM -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write phase) through a ring of four 32-row
+// images, three of them in flight while the fourth is multiplied: ~90 KB outstanding per CU instead of one 57 KB tile that
+// was requested a single MFMA phase before it was needed (the register-staged kernel stalls ~3 us of every 4.6 us step on
+// it).  One raw s_barrier per step; the waves wait on their own DMA with a counted s_waitcnt vmcnt, so the two younger
+// stages stay in flight across the barrier (hipcc would drain vmcnt(0) at a __syncthreads()).  The LDS destination of a
+// DMA instruction is wave-base + lane*16, so an image is the lane-linear sequence of 16-byte slots [row][chunk] with the two
+// pad slots of every row (conflict-free transpose reads) filled by lanes that re-load chunk 0.
+constexpr int TD_BM = 32, TD_NST = 4;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Transposing fragment read issued as inline assembly: for a compiler-visible LDS load hipcc inserts s_waitcnt vmcnt(0) (any
+// outstanding LDS-DMA may alias it), which would drain the whole ring before every step.  Same k-slot map as TrFrag<bf16_t>.
+__device__ __forceinline__ s16x4 ds_tr16_asm(const char* p) {
+  s16x4 v;
+  const unsigned addr = (unsigned)(size_t)(LDS_PTR(char))p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ bf16x8 tr_frag_asm(const char* tile, int ld, int c0, int lane) {
+  const int i = lane & 15, gq = lane >> 4;
+  const char* p = tile + (4 * gq + (i >> 2)) * ld + (c0 + (i & 3) * 4) * 2;
+  const s16x4 lo = ds_tr16_asm(p), hi = ds_tr16_asm(p + 16 * ld);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int B1, int B2, int W1, int W2>
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  constexpr int LD1 = B1 * 2 + 32, LD2 = B2 * 2 + 32;
+  constexpr int S1 = LD1 / 16, S2 = LD2 / 16;
+  constexpr int NSLOT = TD_BM * (S1 + S2);
+  constexpr int NWI = (NSLOT + 63) / 64;                 // DMA wave-instructions per stage
+  constexpr int PER = (NWI + 7) / 8;                     // per wave (waves past NWI aim theirs at a dummy KB)
+  constexpr int IMG = NWI * 1024;
+  constexpr int TI = B1 / W1 / 16, TJ = B2 / W2 / 16;
+  static_assert(W1 * W2 == 8 && PER <= 4, "tile config");
+  extern __shared__ __attribute__((aligned(16))) char smem_td[];
+  char* const dummy = smem_td + TD_NST * IMG;
+  const char* __restrict__ A = reinterpret_cast<const char*>(g.A);
+  const char* __restrict__ B = reinterpret_cast<const char*>(g.B);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int w1 = w / W2, w2 = w % W2;
+  const int n10 = blockIdx.x * B1, n20 = blockIdx.y * B2;
+  const int mbeg = blockIdx.z * g.rows_per_split;
+  const int mend = min(g.M, mbeg + g.rows_per_split);
+  const bool do_cs = g.bpart != nullptr && blockIdx.y == 0 && w2 == 0;
+
+  // this lane's source of DMA instruction q of a stage: byte offset at row 0 of the stage, bytes per row, row inside the stage
+  int64_t goff[PER];
+  int gstr[PER], grow[PER];
+  bool isA[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    int slot = (w + 8 * q) * 64 + lane;
+    if (slot >= NSLOT) slot = 0;                          // dummy instruction / tail lanes: any valid source
+    if (slot < TD_BM * S1) {
+      const int row = slot / S1, c = slot % S1;
+      isA[q] = true; grow[q] = row; gstr[q] = g.lda * 2;
+      goff[q] = (int64_t)row * g.lda * 2 + (n10 + (c < B1 / 8 ? c : 0) * 8) * 2;
+    } else {
+      const int s2 = slot - TD_BM * S1, row = s2 / S2, c = s2 % S2;
+      isA[q] = false; grow[q] = row; gstr[q] = g.ldb * 2;
+      goff[q] = (int64_t)row * g.ldb * 2 + (n20 + (c < B2 / 8 ? c : 0) * 8) * 2;
+    }
+  }
+  auto issue = [&](int t) {                              // full stages only: every row is inside the split
+    const int m0 = mbeg + t * TD_BM;
+    char* img = smem_td + (t % TD_NST) * IMG;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const char* src = (isA[q] ? A : B) + goff[q] + (int64_t)m0 * gstr[q];
+      char* dst = (w + 8 * q < NWI) ? img + (w + 8 * q) * 1024 : dummy;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TI][TJ], cs[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const typename MM::Frag ones = __builtin_bit_cast(typename MM::Frag, ones_u);
+
+  auto compute = [&](const char* sA) {
+    const char* sB = sA + TD_BM * LD1;
+    typename MM::Frag fa[TI], fb[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) fa[i] = tr_frag_asm(sA, LD1, w1 * (B1 / W1) + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) fb[j] = tr_frag_asm(sB, LD2, w2 * (B2 / W2) + j * 16, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);                       // no MFMA may move above the wait of the hand-issued reads
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[i][j] = MM::mma(fb[j], fa[i], acc[i][j]);
+      if (do_cs) cs[i] = MM::mma(ones, fa[i], cs[i]);
+    }
+  };
+  const int rows = mbeg < mend ? mend - mbeg : 0;
+  const int nfull = rows / TD_BM;
+  for (int t = 0; t < TD_NST - 1 && t < nfull; ++t) issue(t);
+  for (int t = 0; t < nfull; ++t) {
+    const int younger = min(TD_NST - 2, nfull - 1 - t);      // stages issued after t that may stay in flight
+    if (younger >= 2) wait_vmcnt<2 * PER>();
+    else if (younger == 1) wait_vmcnt<PER>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                            // stage t complete for every wave; image (t-1) % 4 is free again
+    if (t + TD_NST - 1 < nfull) issue(t + TD_NST - 1);
+    compute(smem_td + (t % TD_NST) * IMG);
+  }
+  if (rows % TD_BM) {                                        // partial last stage of the split: through registers, rows past mend = 0
+    __builtin_amdgcn_s_barrier();
+    const int m0 = mbeg + nfull * TD_BM;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m0 + grow[q] < mend) v = *reinterpret_cast<const u32x4*>((isA[q] ? A : B) + goff[q] + (int64_t)m0 * gstr[q]);
+      if (w + 8 * q < NWI) *reinterpret_cast<u32x4*>(smem_td + (w + 8 * q) * 1024 + lane * 16) = v;
+    }
+    __syncthreads();
+    compute(smem_td);
+  }
+  if (do_cs && (lane >> 4) == 0) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) g.bpart[(size_t)blockIdx.z * g.N1 + n10 + w1 * (B1 / W1) + i * 16 + (lane & 15)] = cs[i][0];
+  }
+  float* P = g.part + (size_t)blockIdx.z * g.N1 * g.N2;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int n1 = n10 + w1 * (B1 / W1) + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int n2 = n20 + w2 * (B2 / W2) + j * 16 + (lane >> 4) * 4;
+      *reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];
+    }
+  }
+}
+
 // sum the split-M partial tiles (and partial column sums) in a fixed order.  VEC = 4: 16-byte accesses, 4 slices in flight
 template <int VEC>
 __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ part, float* __restrict__ C, int n, int ldc,
@@ -1064,7 +1212,16 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
       if (cfg == 1) k_gemm_tn_big<TA_, 192, 256, 2, 4><<<grid, 512, 0, st>>>(a); \
       else if (cfg == 2) k_gemm_tn_big<TA_, 256, 192, 4, 2><<<grid, 512, 0, st>>>(a); \
       else k_gemm_tn_big<TA_, 192, 192, 2, 4><<<grid, 512, 0, st>>>(a);
-      if (p->a_is_f32) { TN_BIG(float) } else { TN_BIG(bf16_t) }
+#define TN_DMA_ONE(B1_, B2_, W1_, W2_) { \
+        const int sh_ = TD_NST * (((TD_BM * (((B1_) * 2 + 32) / 16 + ((B2_) * 2 + 32) / 16) + 63) / 64) * 1024) + 1024; \
+        hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_tn_dma<B1_, B2_, W1_, W2_>, hipFuncAttributeMaxDynamicSharedMemorySize, sh_); \
+        if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
+        k_gemm_tn_dma<B1_, B2_, W1_, W2_><<<grid, 512, sh_, st>>>(a); }
+      if (p->a_is_f32) { TN_BIG(float) }           // float32 A (converted on load): register-staged kernel
+      else if (cfg == 1) TN_DMA_ONE(192, 256, 2, 4)
+      else if (cfg == 2) TN_DMA_ONE(256, 192, 4, 2)
+      else TN_DMA_ONE(192, 192, 2, 4)
+#undef TN_DMA_ONE
 #undef TN_BIG
     }
   } else return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: dtype must be UVC_F32 or UVC_BF16");

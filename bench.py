@@ -40,6 +40,7 @@ def parse():
     p.add_argument("--stage", type=int, default=1, choices=[1, 2],
                    help="1 = the headline Stage-1 UVC-train step; 2 = the Stage-2 masked fine-tune step (SURVEY §8 f-1)")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--compact_mlp", type=int, default=1, help="stage 2: skip pruned MLP hidden units (0 = dense masked computation)")
     p.add_argument("--serialize", type=int, default=0, help="diagnostic: 1 = teacher forward and weight gradients on the main stream (no overlap)")
     p.add_argument("--cpu_steps", type=int, default=6)
     return p.parse_args()
@@ -174,6 +175,7 @@ def main():
         a = default_args(model_type=args.model_type, precision=args.precision, train_batch_size=args.batch, local_rank=local)
         tr = Stage2Trainer(a, device=f"cuda:{local}", distributed=world > 1, world_size=world)
         stage2_checkpoint_state(tr.model)
+        tr.mlp_widths = tr.model.set_mlp_compaction() if args.compact_mlp else tr.model.set_mlp_compaction(False)
         tr.begin_epoch(a.warmup_epochs + 1)
     else:
         from uvc_amd.stage1 import Stage1Trainer, default_args

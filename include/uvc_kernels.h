@@ -192,6 +192,14 @@ int uvc_mixup_batch(float* x, int32_t B, int32_t C, int32_t H, int32_t W, float 
                     int32_t yl, int32_t yh, int32_t xl, int32_t xh, void* stream);
 int uvc_mixup_target(const int64_t* labels, float* y, int32_t B, int32_t C, float lam, float one_minus_lam, float on_value,
                      float off_value, void* stream);
+/* MLP compaction helpers (uvc_vit.h: uvc_mlp_compact).  idx [width]: hidden unit of each compact slot; inv [F]: slot or -1.
+ * gather: w1c[s,:] = W1[idx[s],:], w1t = w1c^T, w2c[:,s] = W2[:,idx[s]], w2t = w2c^T (cast to T), b1c[s] = b1[idx[s]].
+ * scatter: dW1[j,:] = dw1c[inv[j],:] or 0; db1[j] = db1c[inv[j]] or 0; dW2[:,j] = dw2c[:,inv[j]] or GELU(b1[j]) * db2[:]
+ * (GELU as the forward of that precision mode evaluates and stores it); written as beta_acc*old + value. */
+int uvc_mlp_gather_shadows(const float* W1, const float* b1, const float* W2, const int32_t* idx, int32_t D, int32_t F, int32_t width,
+                           void* w1c, void* w1t, void* w2c, void* w2t, float* b1c, int32_t dtype, void* stream);
+int uvc_mlp_scatter_grads(const float* dw1c, const float* dw2c, const float* db1c, const int32_t* inv, const float* b1, const float* db2,
+                          int32_t D, int32_t F, int32_t width, float* dW1, float* dW2, float* db1, float beta_acc, int32_t dtype, void* stream);
 /* params[i] *= mask[i] over a flat parameter buffer: the Stage-2 `m.weight.data *= m.mask` for every module with a
  * mask buffer (post_train.py:343-346); mask is 1 where no module mask covers the element (biases, tokens). */
 int uvc_apply_masks(float* params, const float* mask, int64_t n, void* stream);

@@ -60,6 +60,20 @@ int uvc_vit_ws_offsets(const uvc_vit_cfg* cfg, int32_t batch, int32_t training, 
 /* refresh the T-typed shadows (W and W^T) from the float32 master weights */
 int uvc_vit_update_shadows(const uvc_vit_cfg* cfg, const float* params, void* shadow, void* stream);
 
+/* Stage-2 structured sparsity of one block's MLP: the hidden units whose fc1 row and fc2 column are masked
+ * out are skipped instead of multiplied as zeros.  `width` (a multiple of 64; padding slots are pruned units, whose weights
+ * are zero) compact units; w1 [width, D], w1t [D, width], w2 [D, width], w2t [width, D] of the model's operand type T and
+ * b1 [width] float32 are gathered copies (uvc_mlp_gather_shadows); dw1 [width, D], dw2 [D, width], db1 [width] float32 are
+ * scratch for the compact weight gradients, which uvc_mlp_scatter_grads expands into the full gradient tensors -- rows of
+ * pruned units are exact zeros, and the fc2 gradient column of a pruned unit j is the rank-1 GELU(b1[j]) * db2 that the
+ * dense computation produces (its activation is the constant GELU(b1[j])), so global-norm clipping sees the same norm. */
+typedef struct uvc_mlp_compact {
+  int32_t width; int32_t reserved;
+  const void* w1; const void* w1t; const void* w2; const void* w2t; const float* b1;
+  float* dw1; float* dw2; float* db1;
+  const int32_t* inv;       /* device [F]: compact slot of hidden unit j, or -1 */
+} uvc_mlp_compact;
+
 typedef struct uvc_vit_io {
   const float* params;      /* flat float32 parameters */
   void* shadow;             /* flat T shadows */
@@ -90,6 +104,7 @@ typedef struct uvc_vit_io {
    * enqueued there and overlap the chain on `stream`; events order operand reads against buffer reuse, and
    * `stream` waits for the side stream before the call's last stage returns. */
   void* side_stream;
+  const uvc_mlp_compact* mlp_compact;  /* HOST [L] or NULL; entries with width 0 or width == hidden run dense */
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

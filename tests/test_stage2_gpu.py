@@ -13,7 +13,7 @@ from test_stage1_gpu import close
 pytestmark = pytest.mark.gpu
 
 
-def build(name, precision):
+def build(name, precision, compact=1):
     from uvc_amd.post_train import Stage2Trainer, default_args
     r = SC.stage2_recipe(name)
     cfg, params, masks, teacher = stage2_state(r)
@@ -25,7 +25,7 @@ def build(name, precision):
                         max_grad_norm=r["max_grad_norm"], epochs=r["epochs"], warmup_epochs=r["warmup_epochs"],
                         warmup_lr=r["warmup_lr"], min_lr=r["min_lr"], decay_rate=r["decay_rate"], opt_eps=r["opt_eps"],
                         distillation_type=r["distillation_type"], distillation_alpha=r["distillation_alpha"],
-                        distillation_tau=r["distillation_tau"])
+                        distillation_tau=r["distillation_tau"], compact_mlp=compact, compact_multiple=64)
     # the Stage-1 checkpoint as save_model writes it: a bare state_dict with every module's mask buffer
     from uvc_amd.post_train import setup
     _, probe, _ = setup(default_args(**vars(args)), device="cuda")
@@ -159,3 +159,36 @@ def test_stage2_state_resume_is_bit_identical(tmp_path):
     assert float(out_a["loss"]) == float(out_c["loss"])
     assert torch.equal(a.model._flat, c.model._flat) and torch.equal(a.optimizer.exp_avg_sq, c.optimizer.exp_avg_sq)
     assert a.global_step == c.global_step == 3
+
+
+@pytest.mark.parametrize("name,precision", [("stage2_micro_skip", "fp32"), ("stage2_tiny8", "fp32"), ("stage2_tiny8", "bf16")])
+def test_mlp_compaction_equals_the_dense_masked_computation(name, precision):
+    """Skipping the pruned hidden units gives the loss, the global gradient norm (pruned fc2 columns included: they are the
+    rank-1 GELU(b1_j) * db2) and every gradient of the dense masked step, up to float32 summation order."""
+    r, cfg, dense = build(name, precision, compact=0)
+    _, _, comp = build(name, precision, compact=1)
+    assert dense.mlp_widths is None and any(w < cfg.hidden for w in comp.mlp_widths), comp.mlp_widths
+    x_all, y_all = SC.make_inputs(r)
+    x, y = torch.from_numpy(x_all[0]).cuda(), torch.from_numpy(y_all[0]).cuda()
+    outs = []
+    for tr in (dense, comp):
+        tr.begin_epoch(1)
+        o = tr.step(x, y, zero_grad=False)
+        n = tr.model._off.n_total
+        outs.append((float(o["loss"]), float(o["gnorm"]), tr.model._flat_grad[:n].clone(), tr.model._flat.clone()))
+    (l0, g0, f0, p0), (l1, g1, f1, p1) = outs
+    tol = 1e-5 if precision == "fp32" else 2e-3
+    assert abs(l0 - l1) <= tol * abs(l0)
+    assert abs(g0 - g1) <= tol * g0
+    scale = f0.abs().max().item()
+    # bf16: other GEMM kernels are selected for the compact widths, so bf16-rounded intermediates (dA, dH) differ in the last bit
+    assert (f0 - f1).abs().max().item() <= (tol if precision == "fp32" else 1e-2) * scale
+    # one AdamW step moves an element by up to lr in the direction m/sqrt(v), which is ill-conditioned where |g| ~ eps
+    assert (p0 - p1).abs().max().item() <= (0.1 if precision == "fp32" else 2.0) * comp.args.lr
+    # rows of pruned units in dW1 / db1 are exact zeros
+    m = comp.model
+    for l, w in enumerate(comp.mlp_widths):
+        if w < cfg.hidden and m.blocks[l].mlp.fc1.weight.grad is not None:        # hard-skipped blocks have no gradient
+            inv = m._mlp_bufs[l]["inv"]
+            assert float(m.blocks[l].mlp.fc1.weight.grad[inv < 0].abs().sum()) == 0.0
+            assert float(m.blocks[l].mlp.fc2.weight.grad[:, inv < 0].abs().sum()) > 0.0      # the rank-1 columns are there

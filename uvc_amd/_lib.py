@@ -122,6 +122,8 @@ _SIGNATURES = {
     "uvc_add_outer": [VP, VP, VP, I32, I32, I32, I32, VP],
     "uvc_colsum_blocks": [I32],
     "uvc_apply_masks": [VP, VP, I64, VP],
+    "uvc_mlp_gather_shadows": [VP, VP, VP, VP, I32, I32, I32, VP, VP, VP, VP, VP, I32, VP],
+    "uvc_mlp_scatter_grads": [VP, VP, VP, VP, VP, VP, I32, I32, I32, VP, VP, VP, F32, I32, VP],
     "uvc_mixup_batch": [VP, I32, I32, I32, I32, F32, F32, I32, I32, I32, I32, I32, VP],
     "uvc_mixup_target": [VP, VP, I32, I32, F32, F32, F32, F32, VP],
     "uvc_stream_create": [I32, C.POINTER(VP)],

@@ -382,6 +382,49 @@ __global__ __launch_bounds__(256) void k_mixup_target(const int64_t* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------- Stage-2 MLP compaction
+template <typename T>
+__global__ __launch_bounds__(256) void k_mlp_gather(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                                                    const int* __restrict__ idx, int D, int F, int Fe, T* __restrict__ w1c, T* __restrict__ w1t,
+                                                    T* __restrict__ w2c, T* __restrict__ w2t, float* __restrict__ b1c) {
+  const int64_t total = (int64_t)Fe * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int s = (int)(i / D), d = (int)(i % D), j = idx[s];
+    const float a = W1[(size_t)j * D + d], b = W2[(size_t)d * F + j];
+    ElemIO<T>::store(w1c + (size_t)s * D + d, a);
+    ElemIO<T>::store(w1t + (size_t)d * Fe + s, a);
+    ElemIO<T>::store(w2c + (size_t)d * Fe + s, b);
+    ElemIO<T>::store(w2t + (size_t)s * D + d, b);
+    if (d == 0) b1c[s] = b1[j];
+  }
+}
+template <bool LOWP>
+__global__ __launch_bounds__(256) void k_mlp_scatter(const float* __restrict__ dw1c, const float* __restrict__ dw2c, const float* __restrict__ db1c,
+                                                     const int* __restrict__ inv, const float* __restrict__ b1, const float* __restrict__ db2, int D,
+                                                     int F, int Fe, float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ db1,
+                                                     float beta) {
+  const int64_t total = (int64_t)F * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    {   // dW1 [F, D], row-major walk
+      const int j = (int)(i / D), d = (int)(i % D), sl = inv[j];
+      const float v = sl >= 0 ? dw1c[(size_t)sl * D + d] : 0.f;
+      dW1[i] = (beta != 0.f ? beta * dW1[i] : 0.f) + v;
+      if (d == 0) db1[j] = (beta != 0.f ? beta * db1[j] : 0.f) + (sl >= 0 ? db1c[sl] : 0.f);
+    }
+    {   // dW2 [D, F]
+      const int d = (int)(i / F), j = (int)(i % F), sl = inv[j];
+      float v;
+      if (sl >= 0) v = dw2c[(size_t)d * Fe + sl];
+      else {
+        float u = LOWP ? gelu_fast(b1[j]) : gelu_f(b1[j]);
+        if (LOWP) u = bf16_to_f32(f32_to_bf16(u));        // the forward stores GELU(a) in bf16
+        v = u * db2[d];
+      }
+      dW2[i] = (beta != 0.f ? beta * dW2[i] : 0.f) + v;
+    }
+  }
+}
+
 inline int grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -518,6 +561,28 @@ extern "C" int uvc_mixup_target(const int64_t* labels, float* y, int32_t B, int3
                                 float off_value, void* stream) {
   if (!labels || !y || B <= 0 || C <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mixup_target: bad argument");
   k_mixup_target<<<grid_for((int64_t)B * C), 256, 0, (hipStream_t)stream>>>(labels, y, B, C, lam, one_minus_lam, on_value, off_value);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_mlp_gather_shadows(const float* W1, const float* b1, const float* W2, const int32_t* idx, int32_t D, int32_t F, int32_t width,
+                                      void* w1c, void* w1t, void* w2c, void* w2t, float* b1c, int32_t dtype, void* stream) {
+  if (!W1 || !b1 || !W2 || !idx || !w1c || !w1t || !w2c || !w2t || !b1c || D <= 0 || F <= 0 || width <= 0 || width > F)
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_gather_shadows: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UVC_F32) k_mlp_gather<float><<<grid_for((int64_t)width * D), 256, 0, st>>>(W1, b1, W2, idx, D, F, width, (float*)w1c, (float*)w1t, (float*)w2c, (float*)w2t, b1c);
+  else k_mlp_gather<bf16_t><<<grid_for((int64_t)width * D), 256, 0, st>>>(W1, b1, W2, idx, D, F, width, (bf16_t*)w1c, (bf16_t*)w1t, (bf16_t*)w2c, (bf16_t*)w2t, b1c);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_mlp_scatter_grads(const float* dw1c, const float* dw2c, const float* db1c, const int32_t* inv, const float* b1, const float* db2,
+                                     int32_t D, int32_t F, int32_t width, float* dW1, float* dW2, float* db1, float beta_acc, int32_t dtype, void* stream) {
+  if (!dw1c || !dw2c || !db1c || !inv || !b1 || !db2 || !dW1 || !dW2 || !db1 || D <= 0 || F <= 0 || width <= 0)
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_scatter_grads: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UVC_F32) k_mlp_scatter<false><<<grid_for((int64_t)F * D), 256, 0, st>>>(dw1c, dw2c, db1c, inv, b1, db2, D, F, width, dW1, dW2, db1, beta_acc);
+  else k_mlp_scatter<true><<<grid_for((int64_t)F * D), 256, 0, st>>>(dw1c, dw2c, db1c, inv, b1, db2, D, F, width, dW1, dW2, db1, beta_acc);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -619,7 +619,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn(NtArgs g) {
 }
 
 static bool wsn_ok(const NtArgs& a, int epi, bool a_f32) {
-  return !a_f32 && a.N == 192 && (a.K == 768 || a.K == 576) && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % 4 == 0 && a.ldr % 4 == 0 && a.M >= 4096 &&
+  return !a_f32 && a.N == 192 && (a.K == 768 || a.K == 576 || a.K == 512 || a.K == 256) && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % 4 == 0 && a.ldr % 4 == 0 && a.M >= 4096 &&
          (epi == UVC_EPI_NONE || epi == UVC_EPI_BIAS || epi == UVC_EPI_BIAS_RESID || epi == UVC_EPI_BIAS_RESID_GATE);
 }
 template <typename TC, int KT>
@@ -641,7 +641,12 @@ static int launch_wsn_kt(const NtArgs& a, int epi, hipStream_t st) {
 }
 template <typename TC>
 static int launch_wsn(const NtArgs& a, int epi, hipStream_t st) {
-  return a.K == 768 ? launch_wsn_kt<TC, 24>(a, epi, st) : launch_wsn_kt<TC, 18>(a, epi, st);
+  switch (a.K) {                                      // 512 / 256: compacted MLP widths of Stage-2
+    case 768: return launch_wsn_kt<TC, 24>(a, epi, st);
+    case 576: return launch_wsn_kt<TC, 18>(a, epi, st);
+    case 512: return launch_wsn_kt<TC, 16>(a, epi, st);
+    default: return launch_wsn_kt<TC, 8>(a, epi, st);
+  }
 }
 
 template <typename TA, typename T, typename TC>

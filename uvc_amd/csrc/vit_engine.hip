@@ -155,7 +155,7 @@ int nt(const Ctx& c, const void* A, int a_f32, const void* B, void* C, int c_f32
 // weight gradient + (same pass over A) bias gradient.  With a side stream the launch goes there: it waits for
 // everything the main stream has enqueued so far (its operands) and records ev_done[buf] for the overwrite guard.
 int tn(Ctx& c, const void* A, int a_f32, const void* B, float* C, float* bias_grad, int M, int N1, int N2, const float* alpha_ptr = nullptr,
-       int lda = 0, int ldb = 0, int buf = BUF_OTHER) {
+       int lda = 0, int ldb = 0, int buf = BUF_OTHER, bool scratch = false) {
   void* stream = c.st;
   if (c.side) {
     hipError_t e = hipEventRecord(g_ev_raw, (hipStream_t)c.st);
@@ -167,7 +167,7 @@ int tn(Ctx& c, const void* A, int a_f32, const void* B, float* C, float* bias_gr
   memset(&a, 0, sizeof(a));
   a.colsum_out = bias_grad;
   a.A = A; a.B = B; a.C = C; a.workspace = c.w.tn_ws; a.workspace_bytes = c.w.tn_ws_bytes; a.alpha_ptr = alpha_ptr; a.alpha = 1.0f;
-  a.beta = c.io->accumulate; a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda ? lda : N1; a.ldb = ldb ? ldb : N2; a.ldc = N2;
+  a.beta = scratch ? 0.f : c.io->accumulate; a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda ? lda : N1; a.ldb = ldb ? ldb : N2; a.ldc = N2;
   a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32;
   if (int e = uvc_gemm_tn(&a, stream)) return e;
   if (c.side) {
@@ -369,24 +369,30 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, UVC_EPI_BIAS, P + q[3]));
     TRY(attn(c, b, false));
     TRY(nt(c, b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), b.x1, 1, d.M, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xin));
-    if (!io->training && !io->gate_d && uvc_mlp_fused_supported(d.D, d.F, d.dtype)) {
+    // Stage-2 compaction: pruned hidden units are skipped (compact weights gathered by the host, uvc_mlp_compact)
+    const uvc_mlp_compact* mc = (io->mlp_compact && io->mlp_compact[l].width > 0 && io->mlp_compact[l].width < d.F) ? &io->mlp_compact[l] : nullptr;
+    const int Fe = mc ? mc->width : d.F;
+    const void* w1 = mc ? mc->w1 : wmat(c, q[8], c.soff.blk_w[l][2]);
+    const void* w2 = mc ? mc->w2 : wmat(c, q[10], c.soff.blk_w[l][3]);
+    const float* b1 = mc ? mc->b1 : P + q[9];
+    if (!io->training && !io->gate_d && uvc_mlp_fused_supported(d.D, Fe, d.dtype)) {
       // no-grad forward (teacher / eval): LayerNorm + fc1 + GELU + fc2 + residual in one kernel, hidden activation in registers
       uvc_mlp_args m;
-      m.x = b.x1; m.gamma = P + q[6]; m.beta = P + q[7]; m.w1 = wmat(c, q[8], c.soff.blk_w[l][2]); m.b1 = P + q[9];
-      m.w2 = wmat(c, q[10], c.soff.blk_w[l][3]); m.b2 = P + q[11]; m.out = xout; m.M = d.M; m.D = d.D; m.F = d.F; m.eps = 1e-6f;
+      m.x = b.x1; m.gamma = P + q[6]; m.beta = P + q[7]; m.w1 = w1; m.b1 = b1;
+      m.w2 = w2; m.b2 = P + q[11]; m.out = xout; m.M = d.M; m.D = d.D; m.F = Fe; m.eps = 1e-6f;
       TRY(uvc_mlp_fused_fwd(&m, c.st));
       xin = xout;
       continue;
     }
     TRY(ln_fwd(c, b.x1, q[6], q[7], b.h2, b.mean2, b.rstd2, d.M, 1, d.D));
     if (io->training)
-      TRY(nt(c, b.h2, 0, wmat(c, q[8], c.soff.blk_w[l][2]), b.a, 0, d.M, d.F, d.D, UVC_EPI_BIAS_GELU, P + q[9], nullptr, nullptr, nullptr, nullptr, b.u));
+      TRY(nt(c, b.h2, 0, w1, b.a, 0, d.M, Fe, d.D, UVC_EPI_BIAS_GELU, b1, nullptr, nullptr, nullptr, nullptr, b.u));
     else   // inference (teacher / eval): the pre-activation is not needed, write GELU(a) only
-      TRY(nt(c, b.h2, 0, wmat(c, q[8], c.soff.blk_w[l][2]), b.u, 0, d.M, d.F, d.D, UVC_EPI_BIAS_GELU_OUT, P + q[9]));
+      TRY(nt(c, b.h2, 0, w1, b.u, 0, d.M, Fe, d.D, UVC_EPI_BIAS_GELU_OUT, b1));
     if (io->gate_d)
-      TRY(nt(c, b.u, 0, wmat(c, q[10], c.soff.blk_w[l][3]), xout, 1, d.M, d.D, d.F, UVC_EPI_BIAS_RESID_GATE, P + q[11], b.x1, xin, nullptr, io->gate_d + 2 * l));
+      TRY(nt(c, b.u, 0, w2, xout, 1, d.M, d.D, Fe, UVC_EPI_BIAS_RESID_GATE, P + q[11], b.x1, xin, nullptr, io->gate_d + 2 * l));
     else
-      TRY(nt(c, b.u, 0, wmat(c, q[10], c.soff.blk_w[l][3]), xout, 1, d.M, d.D, d.F, UVC_EPI_BIAS_RESID, P + q[11], b.x1));
+      TRY(nt(c, b.u, 0, w2, xout, 1, d.M, d.D, Fe, UVC_EPI_BIAS_RESID, P + q[11], b.x1));
     xin = xout;
   }
   if (io->training && xin != w.xL) return uvc_set_error_msg(UVC_ERR_LAUNCH, "uvc_vit_forward: internal buffer chain broken");
@@ -442,11 +448,24 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     const float* g0 = io->gate_d ? io->gate_d + 2 * l : nullptr;       // d0
     const float* g1 = io->gate_d ? io->gate_d + 2 * l + 1 : nullptr;   // d1
     // MLP: out = d1*(x1 + fc2(u)) + d0*x
+    const uvc_mlp_compact* mc = (io->mlp_compact && io->mlp_compact[l].width > 0 && io->mlp_compact[l].width < d.F) ? &io->mlp_compact[l] : nullptr;
     TRY(guard_overwrite(c, BUF_DA));
-    TRY(nt(c, w.gA, gf, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
-    TRY(tn(c, w.gA, gf, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1, 0, 0, BUF_GA));
-    TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
-    TRY(tn(c, w.dA, 0, b.h2, G + q[8], G + q[9], d.M, d.F, d.D, nullptr, 0, 0, BUF_DA));
+    if (!mc) {
+      TRY(nt(c, w.gA, gf, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
+      TRY(tn(c, w.gA, gf, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1, 0, 0, BUF_GA));
+      TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
+      TRY(tn(c, w.dA, 0, b.h2, G + q[8], G + q[9], d.M, d.F, d.D, nullptr, 0, 0, BUF_DA));
+    } else {
+      const int Fe = mc->width;
+      if (io->accumulate != 0.f) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit_backward: gradient accumulation with MLP compaction");
+      TRY(nt(c, w.gA, gf, mc->w2t, w.dA, 0, d.M, Fe, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
+      TRY(tn(c, w.gA, gf, b.u, mc->dw2, G + q[11], d.M, d.D, Fe, g1, 0, 0, BUF_GA, true));     // db2 goes straight to its place
+      TRY(nt(c, w.dA, 0, mc->w1t, w.dH, 0, d.M, d.D, Fe, UVC_EPI_NONE));
+      TRY(tn(c, w.dA, 0, b.h2, mc->dw1, mc->db1, d.M, Fe, d.D, nullptr, 0, 0, BUF_DA, true));
+      // expand into the full gradient tensors on the stream the wgrads ran on (rank-1 columns for the pruned units)
+      TRY(uvc_mlp_scatter_grads(mc->dw1, mc->dw2, mc->db1, mc->inv, P + q[9], G + q[11], d.D, d.F, Fe, G + q[8], G + q[10], G + q[9], 0.f, d.dtype,
+                                c.side ? c.side : c.st));
+    }
     TRY(guard_overwrite(c, BUF_GB));
     TRY(ln_bwd(c, w.dH, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr, d.M, 1, d.D));   // gB = dL/dx1
     // attention

@@ -51,7 +51,13 @@ class uvc_vit_io(C.Structure):
                 ("d_logits", C.c_void_p), ("d_logits_dist", C.c_void_p), ("gate_d", C.c_void_p),
                 ("run_block", C.POINTER(C.c_int32)), ("patch_mask", C.c_void_p), ("d_patch_mask", C.c_void_p),
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
-                ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p)]
+                ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
+                ("mlp_compact", C.c_void_p)]
+
+
+class uvc_mlp_compact(C.Structure):
+    _fields_ = [("width", C.c_int32), ("reserved", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("w1", "w1t", "w2", "w2t", "b1", "dw1", "dw2", "db1", "inv")]
 
 
 def _bind():
@@ -206,6 +212,8 @@ class DistilledVisionTransformer(nn.Module):
         self._run_block_host = None
         self._run_block_ver = -1
         self._flat_mask = None
+        self._mlp_compact = None
+        self._mlp_bufs = None
         self._skip_grads_clean = False
         self.exp_source = lambda shape: torch.empty(shape, device=self._flat.device, dtype=torch.float32).exponential_()
         self.to(dev)
@@ -330,6 +338,65 @@ class DistilledVisionTransformer(nn.Module):
                 m._buffers["mask"] = self._flat_mask[off:off + k].view(w.shape)
         return self._flat_mask
 
+    def set_mlp_compaction(self, keep=None, multiple=256):
+        """Skip pruned MLP hidden units (Stage-2 structured sparsity, uvc_vit.h: uvc_mlp_compact).  ``keep``: per layer a
+        bool tensor [hidden] of the units that are NOT pruned, or None to derive it from the mask buffers (a unit is pruned
+        when its fc1 mask row and its fc2 mask column are both all-zero).  The compact width is the kept count rounded up to
+        ``multiple`` (the streaming GEMMs take 256 / 512 / 576 / 768) and padded with pruned units, which is exact.
+        ``keep=False`` switches compaction off.  Returns the list of widths."""
+        cfg = self._cfg
+        Lz, D, F = cfg.depth, cfg.embed_dim, cfg.hidden
+        if keep is False:
+            self._mlp_compact, self._mlp_bufs = None, None
+            return [F] * Lz
+        self._check_flat()
+        dev = self._flat.device
+        tdt = torch.float32 if self.precision == "fp32" else torch.bfloat16
+        arr = (uvc_mlp_compact * Lz)()
+        bufs, widths = [], []
+        for l, blk in enumerate(self.blocks):
+            if keep is None:
+                m1, m2 = getattr(blk.mlp.fc1, "mask", None), getattr(blk.mlp.fc2, "mask", None)
+                k = torch.ones(F, dtype=torch.bool) if m1 is None or m2 is None else ((m1 != 0).any(dim=1) | (m2 != 0).any(dim=0)).cpu()
+            else:
+                k = keep[l].cpu().bool()
+            kept = torch.nonzero(k).flatten()
+            width = min(F, max(multiple, -(-int(kept.numel()) // multiple) * multiple))
+            if width >= F:
+                widths.append(F); bufs.append(None)
+                continue
+            pad = torch.nonzero(~k).flatten()[: width - kept.numel()]
+            idx = torch.cat([kept, pad]).to(torch.int32)
+            inv = torch.full((F,), -1, dtype=torch.int32)
+            inv[idx.long()] = torch.arange(width, dtype=torch.int32)
+            b = dict(idx=idx.to(dev), inv=inv.to(dev), width=width,
+                     w1=torch.empty(width, D, device=dev, dtype=tdt), w1t=torch.empty(D, width, device=dev, dtype=tdt),
+                     w2=torch.empty(D, width, device=dev, dtype=tdt), w2t=torch.empty(width, D, device=dev, dtype=tdt),
+                     b1=torch.empty(width, device=dev), dw1=torch.empty(width, D, device=dev), dw2=torch.empty(D, width, device=dev),
+                     db1=torch.empty(width, device=dev))
+            e = arr[l]
+            e.width = width
+            for n in ("w1", "w1t", "w2", "w2t", "b1", "dw1", "dw2", "db1", "inv"):
+                setattr(e, n, L.ptr(b[n]))
+            bufs.append(b); widths.append(width)
+        if all(b is None for b in bufs):
+            self._mlp_compact, self._mlp_bufs = None, None
+        else:
+            self._mlp_compact, self._mlp_bufs = arr, bufs
+        self._shadow_fresh = False
+        return widths
+
+    def _gather_compact(self, stream):
+        """Refresh the gathered operand copies of the compacted MLPs from the (masked) master weights."""
+        dt = ops.UVC_F32 if self.precision == "fp32" else ops.UVC_BF16
+        cfg = self._cfg
+        for blk, b in zip(self.blocks, self._mlp_bufs):
+            if b is None:
+                continue
+            L.check(L.lib().uvc_mlp_gather_shadows(L.ptr(blk.mlp.fc1.weight.data), L.ptr(blk.mlp.fc1.bias.data), L.ptr(blk.mlp.fc2.weight.data),
+                                                   L.ptr(b["idx"]), cfg.embed_dim, cfg.hidden, b["width"], L.ptr(b["w1"]), L.ptr(b["w1t"]),
+                                                   L.ptr(b["w2"]), L.ptr(b["w2t"]), L.ptr(b["b1"]), dt, stream), "uvc_mlp_gather_shadows")
+
     def apply_masks(self):
         """``for m in modules: m.weight.data *= m.mask`` (post_train.py:343-346) as one launch over the flat buffer."""
         self._check_flat()
@@ -366,6 +433,7 @@ class DistilledVisionTransformer(nn.Module):
         io.batch, io.training = B, int(training)
         io.gate_mode, io.gate_eps = self._gate_mode(), float(self.eps)
         io.accumulate = 1.0 if self.grad_accumulate else 0.0
+        io.mlp_compact = C.addressof(self._mlp_compact) if self._mlp_compact is not None else None
         return io
 
     def _ws_view(self, B, training, which):
@@ -399,6 +467,8 @@ class DistilledVisionTransformer(nn.Module):
         stream = L.cur_stream()
         if not (self.frozen_weights and self._shadow_fresh):
             L.check(lib.uvc_vit_update_shadows(C.byref(cfg), L.ptr(self._flat), L.ptr(self._shadow), stream), "uvc_vit_update_shadows")
+            if self._mlp_compact is not None:
+                self._gather_compact(stream)
             self._shadow_fresh = True
         io = self._io(B, training)
         dev = self._flat.device

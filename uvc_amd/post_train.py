@@ -37,7 +37,7 @@ def default_args(**over) -> Namespace:
              opt="adamw", opt_eps=1e-8, opt_betas=None, momentum=0.9, sched="cosine", lr_noise=None, warmup_lr=1e-6,
              min_lr=1e-5, decay_epochs=30, warmup_epochs=5, cooldown_epochs=10, patience_epochs=10, decay_rate=0.1,
              distillation_type="soft", distillation_alpha=0.1, distillation_tau=1.0, enable_deit=0, local_rank=-1,
-             precision="bf16", output_dir="output", name="post_train", steps_per_epoch=5005)
+             precision="bf16", output_dir="output", name="post_train", steps_per_epoch=5005, compact_mlp=1)
     a.update(over)
     return Namespace(**a)
 
@@ -78,6 +78,8 @@ class Stage2Trainer:
             model.load_state_dict(checkpoint)       # `hasattr(checkpoint, 'args')` is never true for a dict: bare state_dict
         self.model, self.teacher = model, teacher
         self.total_param = count_mask(model)
+        # structured sparsity: MLP hidden units whose fc1 row and fc2 column are masked out are skipped, not multiplied
+        self.mlp_widths = model.set_mlp_compaction(multiple=getattr(args, "compact_multiple", 256)) if getattr(args, "compact_mlp", 1) else None
         # post_training(): DDP, scaled learning rate, timm optimiser + schedule (:289-301)
         self.ddp = DistributedDataParallel(model, message_size=250000000, gradient_predivide_factor=1.0) if distributed else None
         args.train_batch_size = args.train_batch_size // args.gradient_accumulation_steps

@@ -40,6 +40,9 @@ def parse():
     p.add_argument("--stage", type=int, default=1, choices=[1, 2],
                    help="1 = the headline Stage-1 UVC-train step; 2 = the Stage-2 masked fine-tune step (SURVEY §8 f-1)")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--phase", default="train", choices=["train", "warmup"],
+                   help="stage 1: 'train' = the UVC-train step the metric is quoted on; 'warmup' = the warm-up-phase step (gates fixed at .5/.5, "
+                        "gate logits frozen, lr = warmup_lr), reported for reference (SURVEY 8d)")
     p.add_argument("--compact_mlp", type=int, default=1, help="stage 2: skip pruned MLP hidden units (0 = dense masked computation)")
     p.add_argument("--serialize", type=int, default=0, help="diagnostic: 1 = teacher forward and weight gradients on the main stream (no overlap)")
     p.add_argument("--cpu_steps", type=int, default=6)
@@ -182,7 +185,7 @@ def main():
         a = default_args(model_type=args.model_type, precision=args.precision, train_batch_size=args.batch, local_rank=local)
         tr = Stage1Trainer(a, device=f"cuda:{local}", distributed=world > 1)
         pruned_state(tr)
-        tr.begin_epoch(a.warmup_epochs + 1)             # UVC-train phase (post warm-up), SURVEY.md §8d
+        tr.begin_epoch(a.warmup_epochs + 1 if args.phase == "train" else 1)      # UVC-train phase (post warm-up) is the metric, SURVEY.md §8d
     if args.serialize:
         tr.model.two_stream_backward = False
         a.overlap_teacher = 0
@@ -213,7 +216,8 @@ def main():
     if rank == 0:
         imgs = world * args.batch * args.steps / dt
         gf = GFLOP_PER_IMG.get(args.model_type)
-        metric = "images/sec UVC Stage-1 step, DeiT-Tiny budget=0.5" if args.stage == 1 else \
+        metric = ("images/sec UVC Stage-1 step, DeiT-Tiny budget=0.5" if args.phase == "train" else
+                  "images/sec UVC Stage-1 WARM-UP-phase step, DeiT-Tiny (for reference, not the headline)") if args.stage == 1 else \
                  "images/sec UVC Stage-2 masked fine-tune step, DeiT-Tiny (SURVEY 8 f-1, not the headline)"
         line = {"metric": metric, "value": round(imgs, 1), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),

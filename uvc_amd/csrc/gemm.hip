@@ -118,6 +118,11 @@ template <> __device__ __forceinline__ void load_vec<bf16_t, 4>(const bf16_t* p,
   v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
 }
 
+// Epilogue arithmetic with the rounding points spelled out (hipcc contracts a*b + c*d differently from kernel to kernel):
+// every NT kernel computes the same bits for the same accumulator, so a row's result does not depend on which kernel the
+// problem size selects (tests/test_fullsize_gpu.py compares a 512-image run with an 8-image run bit for bit).
+__device__ __forceinline__ float epi_scale_bias(float acc, float alpha, float bias) { return __builtin_fmaf(acc, alpha, bias); }
+__device__ __forceinline__ float epi_gate_mix(float v, float r2, float d0, float d1) { return __builtin_fmaf(d1, v, __builtin_fmaf(d0, r2, 0.0f)); }
 constexpr int EP_LD = 68;   // floats per staged accumulator row (64 + 4 pad: conflict-free 16-byte LDS writes)
 
 template <typename TA, typename T, typename TC, int EPI>
@@ -228,10 +233,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
       if (m < g.M && n < g.N) {
         const size_t mo = (size_t)m;
 #pragma unroll
-        for (int e = 0; e < VN; ++e) v[e] *= alpha;
-        if (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
-#pragma unroll
-          for (int e = 0; e < VN; ++e) if (n + e < g.N) v[e] += g.bias[n + e];
+        for (int e = 0; e < VN; ++e) {
+          const bool has_bias = EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID ||
+                                EPI == UVC_EPI_BIAS_RESID_GATE;
+          v[e] = epi_scale_bias(v[e], alpha, (has_bias && n + e < g.N) ? g.bias[n + e] : 0.f);
         }
         if (EPI == UVC_EPI_BIAS_GELU_OUT) {
 #pragma unroll
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
             for (int e = 0; e < VN; ++e) rv[e] = (n + e < g.N) ? rp[e] : 0.f;
           }
 #pragma unroll
-          for (int e = 0; e < VN; ++e) v[e] = d1 * v[e] + d0 * rv[e];
+          for (int e = 0; e < VN; ++e) v[e] = epi_gate_mix(v[e], rv[e], d0, d1);
         }
         if (EPI == UVC_EPI_DGELU) {
           const T* ap = reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n;
@@ -410,14 +415,14 @@ __global__ __launch_bounds__(64 * WS_NW, 2) void k_gemm_ws(NtArgs g, int ngroups
       if (m < g.M) {
         const size_t mo = (size_t)m;
 #pragma unroll
-        for (int e = 0; e < VN; ++e) v[e] = v[e] * alpha + bias_v[e];
+        for (int e = 0; e < VN; ++e) v[e] = epi_scale_bias(v[e], alpha, bias_v[e]);
         if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += E.r[it][e];
         }
         if (EPI == UVC_EPI_BIAS_RESID_GATE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = d1 * v[e] + d0 * E.r2[it][e];
+          for (int e = 0; e < 4; ++e) v[e] = epi_gate_mix(v[e], E.r2[it][e], d0, d1);
         }
         if (EPI == UVC_EPI_DGELU) {
 #pragma unroll
@@ -598,14 +603,118 @@ __global__ __launch_bounds__(768) void k_gemm_wsn(NtArgs g) {
       if (m < g.M) {
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = v[e] * alpha + bias4[e];
+        for (int e = 0; e < 4; ++e) o[e] = epi_scale_bias(v[e], alpha, bias4[e]);
         if (RES) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] += E.r[s2][e];
         }
         if (EPI == UVC_EPI_BIAS_RESID_GATE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = d1 * o[e] + d0 * E.r2[s2][e];
+          for (int e = 0; e < 4; ++e) o[e] = epi_gate_mix(o[e], E.r2[s2][e], d0, d1);
+        }
+        if (sizeof(TC) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
+        else { u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]); *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = q; }
+      }
+    }
+    E = En;
+    if (next < ntiles) lstore(par ? sA0 : sA1);
+    __syncthreads();
+    par ^= 1;
+  }
+}
+
+template <typename TC, int EPI, int KT>
+__global__ __launch_bounds__(768) void k_gemm_wsn16(NtArgs g) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  constexpr int K = KT * 32, NTH = 768;
+  constexpr int ROWB = K * 2 + 32, CPR = K / 8;
+  constexpr int NLD = (16 * CPR + NTH - 1) / NTH;
+  constexpr bool RES = EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA0 = smem;
+  char* sA1 = smem + 16 * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gq = lane >> 4, li = lane & 15;
+  const T* __restrict__ A = reinterpret_cast<const T*>(g.A);
+  const T* __restrict__ W = reinterpret_cast<const T*>(g.B);
+  TC* __restrict__ C = reinterpret_cast<TC*>(g.C);
+  const int ntiles = (g.M + 16 - 1) / 16;
+  const int n = w * 16 + gq * 4;                       // this lane's four output columns
+
+  typename MM::Frag bf[KT];
+#pragma unroll
+  for (int ks = 0; ks < KT; ++ks)
+    bf[ks] = __builtin_bit_cast(typename MM::Frag, *reinterpret_cast<const u32x4*>(W + (size_t)(w * 16 + li) * g.ldb + (ks * 4 + gq) * 8));
+  float alpha = g.alpha;
+  if (g.alpha_ptr) alpha *= *g.alpha_ptr;
+  float d0 = 0.f, d1 = 1.f;
+  if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == UVC_EPI_BIAS || RES) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+
+  u32x4 ra[NLD];
+  auto gload = [&](int tile) {
+    const int m0 = tile * 16;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int id = tid + NTH * i, row = id / CPR, c = id % CPR;
+      const int m = m0 + row;
+      ra[i] = (row < 16 && m < g.M) ? *reinterpret_cast<const u32x4*>(A + (size_t)m * g.lda + c * 8) : z;
+    }
+  };
+  auto lstore = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int id = tid + NTH * i, row = id / CPR, c = id % CPR;
+      if (row < 16) *reinterpret_cast<u32x4*>(buf + row * ROWB + c * 16) = ra[i];
+    }
+  };
+  struct Epi { f32x4 r[1]; f32x4 r2[1]; };
+  auto eload = [&](Epi& E, int tile_) {
+    if (!RES) return;
+#pragma unroll
+    for (int s2 = 0; s2 < 1; ++s2) {
+      const int m = tile_ * 16 + s2 * 16 + li;
+      const size_t off = (m < g.M && tile_ < ntiles) ? (size_t)m * g.ldr + n : 0;
+      E.r[s2] = *reinterpret_cast<const f32x4*>(g.R + off);
+      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[s2] = *reinterpret_cast<const f32x4*>(g.R2 + off);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  Epi E, En;
+  gload(tile);
+  eload(E, tile);
+  lstore(sA0);
+  __syncthreads();
+  int par = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) gload(next);
+    const char* buf = par ? sA1 : sA0;
+    // one accumulation chain in k order: the same summation order as every other NT kernel of the library, so a row's result
+    // does not depend on which kernel the batch size selects (tests/test_fullsize_gpu.py); the 12 waves hide the chain latency
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) c0 = MM::mma(bf[ks], lds_frag<T>(buf + li * ROWB + (ks * 4 + gq) * 16), c0);
+    eload(En, next);
+#pragma unroll
+    for (int s2 = 0; s2 < 1; ++s2) {
+      const int m = tile * 16 + s2 * 16 + li;
+      f32x4 v = c0;
+      if (m < g.M) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = epi_scale_bias(v[e], alpha, bias4[e]);
+        if (RES) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += E.r[s2][e];
+        }
+        if (EPI == UVC_EPI_BIAS_RESID_GATE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = epi_gate_mix(o[e], E.r2[s2][e], d0, d1);
         }
         if (sizeof(TC) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
         else { u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]); *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = q; }
@@ -623,7 +732,27 @@ static bool wsn_ok(const NtArgs& a, int epi, bool a_f32) {
          (epi == UVC_EPI_NONE || epi == UVC_EPI_BIAS || epi == UVC_EPI_BIAS_RESID || epi == UVC_EPI_BIAS_RESID_GATE);
 }
 template <typename TC, int KT>
+static int launch_wsn16_kt(const NtArgs& a, int epi, hipStream_t st) {
+  const int ntiles = ceil_div(a.M, 16);
+  const int grid = ntiles < 256 ? ntiles : 256;
+  const size_t sh = (size_t)2 * 16 * (KT * 64 + 32);
+#define WN_CASE(E) case E: { \
+    hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsn16<TC, E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
+    k_gemm_wsn16<TC, E, KT><<<grid, 768, sh, st>>>(a); } break;
+  switch (epi) {
+    WN_CASE(UVC_EPI_NONE) WN_CASE(UVC_EPI_BIAS) WN_CASE(UVC_EPI_BIAS_RESID) WN_CASE(UVC_EPI_BIAS_RESID_GATE)
+    default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue");
+  }
+#undef WN_CASE
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+template <typename TC, int KT>
 static int launch_wsn_kt(const NtArgs& a, int epi, hipStream_t st) {
+  // float32 outputs (fc2 with its residual / gate operands) run on 16-row tiles: with 32 rows the two sub-tiles' residual
+  // prefetch spilled 24-45 VGPRs next to the 96 of W and cost a third of the time (129 -> 88 us); bf16 outputs keep 32 rows
+  if (sizeof(TC) == 4) return launch_wsn16_kt<TC, KT>(a, epi, st);
   const int ntiles = ceil_div(a.M, WN_BM);
   const int grid = ntiles < 256 ? ntiles : 256;                 // one persistent workgroup per CU
   const size_t sh = (size_t)2 * WN_BM * (KT * 64 + 32);

@@ -181,7 +181,7 @@ struct AttnArgs {
 // ------------------------------------------------------------------------------------------------
 // forward.  NT16 = number of 16-key tiles (multiple of TPS).
 template <typename T, int NT16>
-__global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   typedef Mma<T> MM;
   typedef Geom<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -752,7 +752,9 @@ template <typename TC, int KT>
 static int launch_wsn_kt(const NtArgs& a, int epi, hipStream_t st) {
   // float32 outputs (fc2 with its residual / gate operands) run on 16-row tiles: with 32 rows the two sub-tiles' residual
   // prefetch spilled 24-45 VGPRs next to the 96 of W and cost a third of the time (129 -> 88 us); bf16 outputs keep 32 rows
-  if (sizeof(TC) == 4) return launch_wsn16_kt<TC, KT>(a, epi, st);
+  if constexpr (sizeof(TC) == 4) {
+    return launch_wsn16_kt<TC, KT>(a, epi, st);
+  } else {
   const int ntiles = ceil_div(a.M, WN_BM);
   const int grid = ntiles < 256 ? ntiles : 256;                 // one persistent workgroup per CU
   const size_t sh = (size_t)2 * WN_BM * (KT * 64 + 32);
@@ -760,13 +762,14 @@ static int launch_wsn_kt(const NtArgs& a, int epi, hipStream_t st) {
     hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsn<TC, E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
     k_gemm_wsn<TC, E, KT><<<grid, 768, sh, st>>>(a); } break;
-  switch (epi) {
-    WN_CASE(UVC_EPI_NONE) WN_CASE(UVC_EPI_BIAS) WN_CASE(UVC_EPI_BIAS_RESID) WN_CASE(UVC_EPI_BIAS_RESID_GATE)
+  switch (epi) {                       // bf16 outputs only (float32 outputs run k_gemm_wsn16; residual epilogues need float32 C)
+    WN_CASE(UVC_EPI_NONE) WN_CASE(UVC_EPI_BIAS)
     default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue not supported by the column-sliced streaming kernel");
   }
 #undef WN_CASE
   UVC_CHECK_LAUNCH();
   return UVC_OK;
+  }
 }
 template <typename TC>
 static int launch_wsn(const NtArgs& a, int epi, hipStream_t st) {

@@ -94,8 +94,9 @@ def stage2_checkpoint_state(model, seed=732, skip_blocks=(4, 9)):
 
 
 def kernel_roofline(tr, args, iters=30):
-    """Dominant kernel (rocprof: the fc1 GEMM with fused bias+GELU, profiles/): algorithmic FLOPs of one
-    launch / its average duration measured with HIP events on the launch stream."""
+    """The largest GEMM kernel of the student's forward/backward chain: fc1 with its fused epilogue (bias, GELU and GELU' -- the
+    two [M, F] outputs the backward needs), as the step launches it: algorithmic bytes of one launch / its average duration
+    measured with HIP events on the launch stream."""
     from uvc_amd import ops
     m = tr.model
     cfg = m._cfg
@@ -110,18 +111,18 @@ def kernel_roofline(tr, args, iters=30):
     a_out, u_out = torch.empty(M, F, device=dev, dtype=dt), torch.empty(M, F, device=dev, dtype=dt)
     dtype = ops.UVC_BF16 if args.precision == "bf16" else ops.UVC_F32
     for _ in range(3):
-        ops.gemm_nt(A, W, a_out, dtype=dtype, epilogue=ops.EPI_BIAS_GELU, bias=bias, C2=u_out)
+        ops.gemm_nt(A, W, a_out, dtype=dtype, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bias, C2=u_out)
     st = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(iters):
-        ops.gemm_nt(A, W, a_out, dtype=dtype, epilogue=ops.EPI_BIAS_GELU, bias=bias, C2=u_out)
+        ops.gemm_nt(A, W, a_out, dtype=dtype, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bias, C2=u_out)
     e1.record(st)
     e1.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * D * F
     esz = 2 if args.precision == "bf16" else 4
-    bytes_alg = (M * D + F * D + 2 * M * F) * esz          # A once + W once + the two outputs (a, GELU(a)) once
+    bytes_alg = (M * D + F * D + 2 * M * F) * esz          # A once + W once + the two outputs (GELU'(a), GELU(a)) once
     gbs = bytes_alg / (ms * 1e-3) / 1e9
     tf = flops / (ms * 1e-3) / 1e12
     mfma_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
@@ -129,7 +130,7 @@ def kernel_roofline(tr, args, iters=30):
     # r1_pmc_hbm_traffic_kbench.csv); only valid for the profiled configuration
     traffic = 351281180 if (args.precision == "bf16" and args.batch == 512 and args.model_type == "deit_tiny_patch16_224") else None
     # intensity 2*M*D*F / bytes = 85 flop/B << the ~400 flop/B ridge: this kernel's roofline is HBM
-    return {"bound": "hbm", "kernel": "k_gemm_ws<bf16,bf16,EPI_BIAS_GELU,6> (mlp.fc1 + bias + GELU, M=%d K=%d N=%d)" % (M, D, F),
+    return {"bound": "hbm", "kernel": "k_gemm_ws<bf16,bf16,EPI_BIAS_GELU_GRAD,6> (mlp.fc1 + bias + GELU and GELU', M=%d K=%d N=%d)" % (M, D, F),
             "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
             "traffic": traffic, "algorithmic_bytes": bytes_alg, "launch_ms": round(ms, 4),
             "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / mfma_peak, 4)}

@@ -27,7 +27,10 @@ enum {
   UVC_EPI_BIAS_RESID = 3,      /* C = acc + bias + R[m,n]                       (x + proj(...), :240)   */
   UVC_EPI_BIAS_RESID_GATE = 4, /* C = g1*(acc + bias + R[m,n]) + g0*R2[m,n]     (:244 then :493)        */
   UVC_EPI_DGELU = 5,           /* C = alpha*acc * GELU'(aux[m,n])               (backward of :118)      */
-  UVC_EPI_BIAS_GELU_OUT = 6    /* C = GELU_erf(acc + bias)   (inference: pre-activation not kept)        */
+  UVC_EPI_BIAS_GELU_OUT = 6,   /* C = GELU_erf(acc + bias)   (inference: pre-activation not kept)        */
+  UVC_EPI_BIAS_GELU_GRAD = 7,  /* a = acc + bias ; C = GELU'(a) ; C2 = GELU_erf(a): training forward of fc1 -- the backward
+                                  needs the pre-activation only through GELU'(a), so that is what is kept            */
+  UVC_EPI_MUL_AUX = 8          /* C = alpha*acc * aux[m,n]   (backward of the activation with aux = stored GELU'(a)) */
 };
 
 /* C[M,N] = epilogue( A[M,K] . B[N,K]^T ); A, B row-major with K contiguous. */
@@ -35,11 +38,11 @@ typedef struct uvc_gemm_nt_args {
   const void* A;       /* [M,K]  T, or float32 when a_is_f32 (converted to T while staging) */
   const void* B;       /* [N,K]  T */
   void* C;             /* [M,N]  T, or float32 when c_is_f32 */
-  void* C2;            /* second output of UVC_EPI_BIAS_GELU, same type/ld as C */
+  void* C2;            /* second output of UVC_EPI_BIAS_GELU / _GELU_GRAD, same type/ld as C */
   const float* bias;   /* [N] */
   const float* R;      /* [M,N] float32 residual */
   const float* R2;     /* [M,N] float32, gate epilogue */
-  const void* aux;     /* [M,N] T, pre-activation for UVC_EPI_DGELU */
+  const void* aux;     /* [M,N] T: pre-activation for UVC_EPI_DGELU, multiplier for UVC_EPI_MUL_AUX */
   const float* gate;   /* device float[2] = (g0, g1) block-gate distribution */
   const float* alpha_ptr; /* optional device scalar multiplied into alpha */
   float alpha;

@@ -76,6 +76,16 @@ def test_gemm_nt_f32_source_and_epilogues(dtype):
     x = aux.double().requires_grad_(True)
     F.gelu(x).sum().backward()
     torch.testing.assert_close(Cd.double(), 0.6 * (Aeff.double() @ Bt.double().t()) * x.grad, **tol(dtype))
+    # training forward of fc1: C = GELU'(a), C2 = GELU(a); and its backward partner C = alpha*acc * aux
+    Cg, Cu2 = torch.empty(M, N, device=dev(), dtype=T), torch.empty(M, N, device=dev(), dtype=T)
+    ops.gemm_nt(to_t(A, dtype), Bt, Cg, dtype=dtype, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bias, C2=Cu2)
+    xl = lin.clone().requires_grad_(True)
+    F.gelu(xl).sum().backward()
+    torch.testing.assert_close(Cu2.double(), F.gelu(lin), **tol(dtype))
+    torch.testing.assert_close(Cg.double(), xl.grad, **tol(dtype))
+    Cm = torch.empty(M, N, device=dev(), dtype=T)
+    ops.gemm_nt(A, Bt, Cm, dtype=dtype, epilogue=ops.EPI_MUL_AUX, aux=aux, alpha_ptr=alpha)
+    torch.testing.assert_close(Cm.double(), 0.6 * (Aeff.double() @ Bt.double().t()) * aux.double(), **tol(dtype))
 
 
 @pytest.mark.parametrize("K,N", [(192, 192), (192, 576), (192, 768), (128, 128), (128, 512)])
@@ -97,6 +107,7 @@ def test_gemm_nt_streaming_kernel_matches_generic(K, N):
         (A, torch.float32, dict(epilogue=ops.EPI_BIAS_RESID_GATE, bias=bias, R=R, R2=R2, gate=gate)),
         (A32, torch.bfloat16, dict(epilogue=ops.EPI_DGELU, aux=aux, alpha_ptr=alpha)),
         (A32, torch.bfloat16, dict(epilogue=ops.EPI_NONE)),
+        (A, torch.bfloat16, dict(epilogue=ops.EPI_MUL_AUX, aux=aux, alpha_ptr=alpha)),
     ]
     for Ain, cdt, kw in cases:
         C1, C2 = torch.empty(M, N, device=dev(), dtype=cdt), torch.empty(M, N, device=dev(), dtype=cdt)
@@ -106,6 +117,12 @@ def test_gemm_nt_streaming_kernel_matches_generic(K, N):
     Ca, Cu = torch.empty(M, N, device=dev(), dtype=torch.bfloat16), torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
     ops.gemm_nt(A, W, Ca, dtype=BF16, epilogue=ops.EPI_BIAS_GELU, bias=bias, C2=Cu)
     torch.testing.assert_close(Ca.double(), ref + bias.double(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(Cu.double(), F.gelu(ref + bias.double()), rtol=2e-2, atol=2e-2)
+    Cg = torch.empty_like(Ca)
+    ops.gemm_nt(A, W, Cg, dtype=BF16, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bias, C2=Cu)
+    xl = (ref + bias.double()).requires_grad_(True)
+    F.gelu(xl).sum().backward()
+    torch.testing.assert_close(Cg.double(), xl.grad, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(Cu.double(), F.gelu(ref + bias.double()), rtol=2e-2, atol=2e-2)
 
 

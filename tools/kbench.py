@@ -64,10 +64,14 @@ def main():
         aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
         rec("gemm_nt fc1   bias+gelu    K=D N=F", timeit(lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU, bias=bF, C2=uu)),
             M * D * 2 + 2 * M * F * 2, 2.0 * M * D * F)
+        rec("gemm_nt fc1   gelu + gelu'  K=D N=F", timeit(lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu)),
+            M * D * 2 + 2 * M * F * 2, 2.0 * M * D * F)
         rec("gemm_nt fc2   resid+gate   K=F N=D", timeit(lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate)),
             M * F * 2 + M * D * 12, 2.0 * M * D * F)
         dA = torch.empty(M, F, device=dev, dtype=bf)
         rec("gemm_nt dfc2  dgelu        K=D N=F", timeit(lambda: ops.gemm_nt(g16, W1, dA, dtype=dt, epilogue=ops.EPI_DGELU, aux=hF, alpha_ptr=gate)),
+            M * D * 4 + 2 * M * F * 2, 2.0 * M * D * F)
+        rec("gemm_nt dfc2  x stored g'  K=D N=F", timeit(lambda: ops.gemm_nt(g16, W1, dA, dtype=dt, epilogue=ops.EPI_MUL_AUX, aux=hF, alpha_ptr=gate)),
             M * D * 4 + 2 * M * F * 2, 2.0 * M * D * F)
         dH = torch.empty(M, D, device=dev, dtype=bf)
         rec("gemm_nt dfc1  none         K=F N=D", timeit(lambda: ops.gemm_nt(hF, W2, dH, dtype=dt, epilogue=ops.EPI_NONE)),

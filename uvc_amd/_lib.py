@@ -83,7 +83,7 @@ class uvc_adamw_args(C.Structure):
 
 
 UVC_F32, UVC_BF16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_BIAS_GELU_OUT = range(7)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_BIAS_GELU_OUT, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX = range(9)
 
 _lib = None
 VP = C.c_void_p

@@ -90,10 +90,18 @@ template <typename T> struct Gelu;
 template <> struct Gelu<float> {
   static __device__ __forceinline__ float f(float x) { return gelu_f(x); }
   static __device__ __forceinline__ float g(float x) { return gelu_grad_f(x); }
+  static __device__ __forceinline__ void fg(float x, float& fo, float& go) { fo = gelu_f(x); go = gelu_grad_f(x); }
 };
 template <> struct Gelu<bf16_t> {
   static __device__ __forceinline__ float f(float x) { return gelu_fast(x); }
   static __device__ __forceinline__ float g(float x) { return gelu_grad_fast(x); }
+  // value and derivative from one evaluation of the cdf / exponential (the forward stores both, so the backward's
+  // epilogue is a single multiply)
+  static __device__ __forceinline__ void fg(float x, float& fo, float& go) {
+    float c, e; gelu_parts_fast(x, c, e);
+    fo = x * c;
+    go = c + x * (0.39894228040143267794f * e);
+  }
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
           const bool has_bias = EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID ||
-                                EPI == UVC_EPI_BIAS_RESID_GATE;
+                                EPI == UVC_EPI_BIAS_RESID_GATE || EPI == UVC_EPI_BIAS_GELU_GRAD;
           v[e] = epi_scale_bias(v[e], alpha, (has_bias && n + e < g.N) ? g.bias[n + e] : 0.f);
         }
         if (EPI == UVC_EPI_BIAS_GELU_OUT) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
 #pragma unroll
           for (int e = 0; e < VN; ++e) v[e] = epi_gate_mix(v[e], rv[e], d0, d1);
         }
-        if (EPI == UVC_EPI_DGELU) {
+        if (EPI == UVC_EPI_DGELU || EPI == UVC_EPI_MUL_AUX) {
           const T* ap = reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n;
           float av[VN];
           if (nfull && (g.ldaux % VN) == 0) load_vec<T, VN>(ap, av);
@@ -273,7 +273,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
             for (int e = 0; e < VN; ++e) av[e] = (n + e < g.N) ? ElemIO<T>::load(ap + e) : 0.f;
           }
 #pragma unroll
-          for (int e = 0; e < VN; ++e) v[e] *= Gelu<T>::g(av[e]);
+          for (int e = 0; e < VN; ++e) v[e] *= (EPI == UVC_EPI_MUL_AUX) ? av[e] : Gelu<T>::g(av[e]);
+        }
+        float u[VN];
+        if (EPI == UVC_EPI_BIAS_GELU_GRAD) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) { float fo, go; Gelu<T>::fg(v[e], fo, go); u[e] = fo; v[e] = go; }
         }
         TC* cp = C + mo * g.ldc + n;
         if (nfull) OutVec<TC>::st(cp, v);
@@ -281,11 +286,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
 #pragma unroll
           for (int e = 0; e < VN; ++e) if (n + e < g.N) ElemIO<TC>::store(cp + e, v[e]);
         }
-        if (EPI == UVC_EPI_BIAS_GELU) {
+        if (EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_GRAD) {
           TC* c2 = reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n;
-          float u[VN];
+          if (EPI == UVC_EPI_BIAS_GELU) {
 #pragma unroll
-          for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
+            for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
+          }
           if (nfull) OutVec<TC>::st(c2, u);
           else {
 #pragma unroll
@@ -348,7 +354,8 @@ __global__ __launch_bounds__(64 * WS_NW, 2) void k_gemm_ws(NtArgs g, int ngroups
   float bias_v[VN];
 #pragma unroll
   for (int e = 0; e < VN; ++e) bias_v[e] = 0.f;
-  if (active && (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE)) {
+  if (active && (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE ||
+                 EPI == UVC_EPI_BIAS_GELU_GRAD)) {
 #pragma unroll
     for (int e = 0; e < VN; ++e) bias_v[e] = g.bias[n + e];
   }
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(64 * WS_NW, 2) void k_gemm_ws(NtArgs g, int ngroups
       const size_t mo = (size_t)(ok ? m : 0);
       if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) E.r[it] = *reinterpret_cast<const f32x4*>(g.R + mo * g.ldr + n);
       if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[it] = *reinterpret_cast<const f32x4*>(g.R2 + mo * g.ldr + n);
-      if (EPI == UVC_EPI_DGELU) E.ax[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n);
+      if (EPI == UVC_EPI_DGELU || EPI == UVC_EPI_MUL_AUX) E.ax[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n);
     }
   };
   auto subtile = [&](int buf_, int m0_, int sub_, const Epi& E) {
@@ -431,15 +438,28 @@ __global__ __launch_bounds__(64 * WS_NW, 2) void k_gemm_ws(NtArgs g, int ngroups
             v[2 * e + 1] *= Gelu<T>::g(__uint_as_float(E.ax[it][e] & 0xffff0000u));
           }
         }
+        if (EPI == UVC_EPI_MUL_AUX) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] *= __uint_as_float(E.ax[it][e] << 16);
+            v[2 * e + 1] *= __uint_as_float(E.ax[it][e] & 0xffff0000u);
+          }
+        }
         if (EPI == UVC_EPI_BIAS_GELU_OUT) {
 #pragma unroll
           for (int e = 0; e < VN; ++e) v[e] = Gelu<T>::f(v[e]);
         }
-        OutVec<TC>::st(C + mo * g.ldc + n, v);
-        if (EPI == UVC_EPI_BIAS_GELU) {
-          float u[VN];
+        float u[VN];
+        if (EPI == UVC_EPI_BIAS_GELU_GRAD) {
 #pragma unroll
-          for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
+          for (int e = 0; e < VN; ++e) { float fo, go; Gelu<T>::fg(v[e], fo, go); u[e] = fo; v[e] = go; }
+        }
+        OutVec<TC>::st(C + mo * g.ldc + n, v);
+        if (EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_GRAD) {
+          if (EPI == UVC_EPI_BIAS_GELU) {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
+          }
           OutVec<TC>::st(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
         }
       }
@@ -489,7 +509,7 @@ static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
 #define WS_CASE(E) case E: k_gemm_ws<TA, TC, E, KT, WS_NW><<<grid, 64 * WS_NW, 0, st>>>(a, ngroups, nslots); break;
   switch (epi) {
     WS_CASE(UVC_EPI_NONE) WS_CASE(UVC_EPI_BIAS) WS_CASE(UVC_EPI_BIAS_GELU) WS_CASE(UVC_EPI_BIAS_RESID)
-    WS_CASE(UVC_EPI_BIAS_RESID_GATE) WS_CASE(UVC_EPI_DGELU) WS_CASE(UVC_EPI_BIAS_GELU_OUT)
+    WS_CASE(UVC_EPI_BIAS_RESID_GATE) WS_CASE(UVC_EPI_DGELU) WS_CASE(UVC_EPI_BIAS_GELU_OUT) WS_CASE(UVC_EPI_BIAS_GELU_GRAD) WS_CASE(UVC_EPI_MUL_AUX)
     default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
   }
 #undef WS_CASE
@@ -787,7 +807,7 @@ static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
 #define NT_CASE(E) case E: k_gemm_nt<TA, T, TC, E><<<grid, 256, 0, st>>>(a); break;
   switch (epi) {
     NT_CASE(UVC_EPI_NONE) NT_CASE(UVC_EPI_BIAS) NT_CASE(UVC_EPI_BIAS_GELU) NT_CASE(UVC_EPI_BIAS_RESID)
-    NT_CASE(UVC_EPI_BIAS_RESID_GATE) NT_CASE(UVC_EPI_DGELU) NT_CASE(UVC_EPI_BIAS_GELU_OUT)
+    NT_CASE(UVC_EPI_BIAS_RESID_GATE) NT_CASE(UVC_EPI_DGELU) NT_CASE(UVC_EPI_BIAS_GELU_OUT) NT_CASE(UVC_EPI_BIAS_GELU_GRAD) NT_CASE(UVC_EPI_MUL_AUX)
     default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
   }
 #undef NT_CASE
@@ -801,13 +821,14 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   const int ch = (p->dtype == UVC_F32) ? 4 : 8;
   if (p->K % ch || p->lda % ch || p->ldb % ch) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: K, lda, ldb must be multiples of a 16-byte chunk");
   const int e = p->epilogue;
-  if ((e == UVC_EPI_BIAS || e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_GELU_OUT || e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && !p->bias)
+  if ((e == UVC_EPI_BIAS || e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_GELU_OUT || e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE ||
+       e == UVC_EPI_BIAS_GELU_GRAD) && !p->bias)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue needs bias");
   if ((e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && (!p->R || !p->c_is_f32))
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: residual epilogue needs R and a float32 C");
   if (e == UVC_EPI_BIAS_RESID_GATE && (!p->R2 || !p->gate)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: gate epilogue needs R2 and gate");
-  if (e == UVC_EPI_BIAS_GELU && !p->C2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: GELU epilogue needs C2");
-  if (e == UVC_EPI_DGELU && !p->aux) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dGELU epilogue needs aux");
+  if ((e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_GELU_GRAD) && !p->C2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: GELU epilogue needs C2");
+  if ((e == UVC_EPI_DGELU || e == UVC_EPI_MUL_AUX) && !p->aux) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dGELU epilogue needs aux");
   NtArgs a;
   a.A = p->A; a.B = p->B; a.C = p->C; a.C2 = p->C2; a.bias = p->bias; a.R = p->R; a.R2 = p->R2; a.aux = p->aux;
   a.dptr = p->gate; a.M = p->M; a.N = p->N; a.K = p->K; a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;

@@ -386,7 +386,8 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     }
     TRY(ln_fwd(c, b.x1, q[6], q[7], b.h2, b.mean2, b.rstd2, d.M, 1, d.D));
     if (io->training)
-      TRY(nt(c, b.h2, 0, w1, b.a, 0, d.M, Fe, d.D, UVC_EPI_BIAS_GELU, b1, nullptr, nullptr, nullptr, nullptr, b.u));
+      // b.a receives GELU'(pre-activation): that is all the backward needs of it (one multiply in the dgrad epilogue)
+      TRY(nt(c, b.h2, 0, w1, b.a, 0, d.M, Fe, d.D, UVC_EPI_BIAS_GELU_GRAD, b1, nullptr, nullptr, nullptr, nullptr, b.u));
     else   // inference (teacher / eval): the pre-activation is not needed, write GELU(a) only
       TRY(nt(c, b.h2, 0, w1, b.u, 0, d.M, Fe, d.D, UVC_EPI_BIAS_GELU_OUT, b1));
     if (io->gate_d)
@@ -451,14 +452,14 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     const uvc_mlp_compact* mc = (io->mlp_compact && io->mlp_compact[l].width > 0 && io->mlp_compact[l].width < d.F) ? &io->mlp_compact[l] : nullptr;
     TRY(guard_overwrite(c, BUF_DA));
     if (!mc) {
-      TRY(nt(c, w.gA, gf, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
+      TRY(nt(c, w.gA, gf, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
       TRY(tn(c, w.gA, gf, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1, 0, 0, BUF_GA));
       TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
       TRY(tn(c, w.dA, 0, b.h2, G + q[8], G + q[9], d.M, d.F, d.D, nullptr, 0, 0, BUF_DA));
     } else {
       const int Fe = mc->width;
       if (io->accumulate != 0.f) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit_backward: gradient accumulation with MLP compaction");
-      TRY(nt(c, w.gA, gf, mc->w2t, w.dA, 0, d.M, Fe, d.D, UVC_EPI_DGELU, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
+      TRY(nt(c, w.gA, gf, mc->w2t, w.dA, 0, d.M, Fe, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
       TRY(tn(c, w.gA, gf, b.u, mc->dw2, G + q[11], d.M, d.D, Fe, g1, 0, 0, BUF_GA, true));     // db2 goes straight to its place
       TRY(nt(c, w.dA, 0, mc->w1t, w.dH, 0, d.M, d.D, Fe, UVC_EPI_NONE));
       TRY(tn(c, w.dA, 0, b.h2, mc->dw1, mc->db1, d.M, Fe, d.D, nullptr, 0, 0, BUF_DA, true));

@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_OUT, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_NONE,
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_GRAD, EPI_BIAS_GELU_OUT, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_MUL_AUX, EPI_NONE,
                    UVC_BF16, UVC_F32)
 
 __all__ = ["EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RESID", "EPI_BIAS_RESID_GATE", "EPI_DGELU", "UVC_F32",

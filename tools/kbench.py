@@ -98,8 +98,9 @@ def main():
         dx = torch.empty(M, D, device=dev)
         part = torch.empty(ops.layernorm_bwd_blocks(M) * (2 * D + 2), device=dev)
         dg, db, dots = torch.empty(D, device=dev), torch.empty(D, device=dev), torch.empty(2, device=dev)
-        rec("ln_bwd +add1", timeit(lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx, part, dg, db, M, D, dt, add1=g32, a1=gate[1:])), M * D * 14)
-        rec("ln_bwd +add1+add2+dots", timeit(lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx, part, dg, db, M, D, dt, add1=g32, add2=dx, a2=gate[:1], dots=dots)), M * D * 18)
+        dx16, add16 = torch.empty(M, D, device=dev, dtype=bf), g16.clone()
+        rec("ln_bwd +add1 (bf16 streams)", timeit(lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx16, part, dg, db, M, D, dt, add1=g16, a1=gate[1:])), M * D * 10)
+        rec("ln_bwd +add1+add2+dots (bf16 streams)", timeit(lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx16, part, dg, db, M, D, dt, add1=g16, add2=add16, a2=gate[:1], dots=dots)), M * D * 12)
     if want("mlp_fused"):
         gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
         o32 = torch.empty(M, D, device=dev)

@@ -215,60 +215,72 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
   const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
   const int r1 = min(a.rows, r0 + LN_ROWS_PER_BLOCK);
   const float invD = 1.0f / (float)a.D;
-  for (int rb = r0 + w * 4; rb < r1; rb += 16) {
+  const TG* add1 = reinterpret_cast<const TG*>(a.add1);
+  const TG* add2 = reinterpret_cast<const TG*>(a.add2);
+  // The loads of the NEXT row group are issued before the reductions of the current one (two register sets): a workgroup
+  // keeps one group's 5 streams in flight the whole time instead of draining to zero at every reduction.
+  struct Row { f32x4 xv[NV4], dv[NV4], ad1[NV4], ad2[NV4]; float mean, rstd; size_t off; bool ok; };
+  auto load_row = [&](Row& R, int rb) {
     const int r = rb + rg;
-    const bool ok = r < r1;
-    const size_t off = ok ? row_off(r, a.rows_per_group, a.group_stride, a.D) : 0;
-    const float* x = a.x + off;
-    const TDY* dy = reinterpret_cast<const TDY*>(a.dy) + (size_t)(ok ? r : 0) * a.D;
-    const float mean = ok ? a.mean[r] : 0.f, rstd = ok ? a.rstd[r] : 0.f;
-    f32x4 xv[NV4], gy[NV4], ad1[NV4], ad2[NV4];
-    float c1 = 0.f, c2 = 0.f;
-    const TG* add1 = reinterpret_cast<const TG*>(a.add1);
-    const TG* add2 = reinterpret_cast<const TG*>(a.add2);
-    // every global load of the row is issued before the first reduction, so one HBM round trip covers them all
+    R.ok = rb < r1 && r < r1;
+    R.off = R.ok ? row_off(r, a.rows_per_group, a.group_stride, a.D) : 0;
+    const float* x = a.x + R.off;
+    const TDY* dy = reinterpret_cast<const TDY*>(a.dy) + (size_t)(R.ok ? r : 0) * a.D;
+    R.mean = R.ok ? a.mean[r] : 0.f; R.rstd = R.ok ? a.rstd[r] : 0.f;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      ad1[i] = (ok && add1) ? Ld4<TG>::ld(add1 + off + (sub + 16 * i) * 4) : z;
-      ad2[i] = (ok && add2) ? Ld4<TG>::ld(add2 + off + (sub + 16 * i) * 4) : z;
+      R.ad1[i] = (R.ok && add1) ? Ld4<TG>::ld(add1 + R.off + (sub + 16 * i) * 4) : z;
+      R.ad2[i] = (R.ok && add2) ? Ld4<TG>::ld(add2 + R.off + (sub + 16 * i) * 4) : z;
+      R.dv[i] = R.ok ? Ld4<TDY>::ld(dy + (sub + 16 * i) * 4) : z;
+      R.xv[i] = R.ok ? Ld4<float>::ld(x + (sub + 16 * i) * 4) : z;
     }
+  };
+  auto process = [&](const Row& R) {
+    f32x4 gy[NV4];
+    float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV4; ++i) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 d = ok ? Ld4<TDY>::ld(dy + (sub + 16 * i) * 4) : z;
-      xv[i] = ok ? Ld4<float>::ld(x + (sub + 16 * i) * 4) : z;
+    for (int i = 0; i < NV4; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float xh = (xv[i][e] - mean) * rstd;
-        gy[i][e] = d[e] * gam[i][e];
-        dgam[i][e] += d[e] * xh;
-        dbet[i][e] += d[e];
+        const float xh = (R.xv[i][e] - R.mean) * R.rstd;
+        gy[i][e] = R.dv[i][e] * gam[i][e];
+        dgam[i][e] += R.dv[i][e] * xh;
+        dbet[i][e] += R.dv[i][e];
         c1 += gy[i][e];
         c2 += gy[i][e] * xh;
       }
-    }
     c1 = sum16(c1) * invD;
     c2 = sum16(c2) * invD;
-    if (ok) {
-      TG* dx = reinterpret_cast<TG*>(a.dx) + off;
+    if (R.ok) {
+      TG* dx = reinterpret_cast<TG*>(a.dx) + R.off;
 #pragma unroll
       for (int i = 0; i < NV4; ++i) {
         const int c = (sub + 16 * i) * 4;
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[i][e] - c1 - ((xv[i][e] - mean) * rstd) * c2);
+        for (int e = 0; e < 4; ++e) o[e] = R.rstd * (gy[i][e] - c1 - ((R.xv[i][e] - R.mean) * R.rstd) * c2);
         if (a.add1) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += a1 * ad1[i][e]; }
+          for (int e = 0; e < 4; ++e) o[e] += a1 * R.ad1[i][e]; }
         if (a.add2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { o[e] += a2 * ad2[i][e]; dotB += ad2[i][e] * xv[i][e]; } }
+          for (int e = 0; e < 4; ++e) { o[e] += a2 * R.ad2[i][e]; dotB += R.ad2[i][e] * R.xv[i][e]; } }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dotA += o[e] * xv[i][e];
+        for (int e = 0; e < 4; ++e) dotA += o[e] * R.xv[i][e];
         Ld4<TG>::st(dx + c, o);
       }
     }
+  };
+  Row Ra, Rb;
+  int rb = r0 + w * 4;
+  load_row(Ra, rb);
+  for (; rb < r1; rb += 32) {
+    load_row(Rb, rb + 16);
+    process(Ra);
+    if (rb + 16 >= r1) break;
+    load_row(Ra, rb + 32);
+    process(Rb);
   }
   // reduce the 4 row groups of the wave, then the 4 waves (fixed order)
 #pragma unroll

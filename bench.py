@@ -127,8 +127,8 @@ def kernel_roofline(tr, args, iters=30):
     tf = flops / (ms * 1e-3) / 1e12
     mfma_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/
-    # r1_pmc_hbm_traffic_kbench.csv); only valid for the profiled configuration
-    traffic = 351281180 if (args.precision == "bf16" and args.batch == 512 and args.model_type == "deit_tiny_patch16_224") else None
+    # r1i_pmc_hbm_traffic_kbench.csv); only valid for the profiled configuration
+    traffic = 352572549 if (args.precision == "bf16" and args.batch == 512 and args.model_type == "deit_tiny_patch16_224") else None
     # intensity 2*M*D*F / bytes = 85 flop/B << the ~400 flop/B ridge: this kernel's roofline is HBM
     return {"bound": "hbm", "kernel": "k_gemm_ws<bf16,bf16,EPI_BIAS_GELU_GRAD,6> (mlp.fc1 + bias + GELU and GELU', M=%d K=%d N=%d)" % (M, D, F),
             "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),

@@ -44,7 +44,7 @@ def parse():
                    help="stage 1: 'train' = the UVC-train step the metric is quoted on; 'warmup' = the warm-up-phase step (gates fixed at .5/.5, "
                         "gate logits frozen, lr = warmup_lr), reported for reference (SURVEY 8d)")
     p.add_argument("--compact_mlp", type=int, default=1, help="stage 2: skip pruned MLP hidden units (0 = dense masked computation)")
-    p.add_argument("--serialize", type=int, default=0, help="diagnostic: 1 = teacher forward and weight gradients on the main stream (no overlap)")
+    p.add_argument("--serialize", type=int, default=0, help="diagnostic bit mask: 1 = weight gradients on the main stream, 2 = teacher forward on the main stream (3 = no overlap at all)")
     p.add_argument("--cpu_steps", type=int, default=6)
     return p.parse_args()
 
@@ -187,8 +187,9 @@ def main():
         tr = Stage1Trainer(a, device=f"cuda:{local}", distributed=world > 1)
         pruned_state(tr)
         tr.begin_epoch(a.warmup_epochs + 1 if args.phase == "train" else 1)      # UVC-train phase (post warm-up) is the metric, SURVEY.md §8d
-    if args.serialize:
+    if args.serialize & 1:
         tr.model.two_stream_backward = False
+    if args.serialize & 2:
         a.overlap_teacher = 0
     dev = torch.device("cuda", local)
     g = torch.Generator(device=dev).manual_seed(730 + rank)

@@ -105,10 +105,18 @@ typedef struct uvc_ln_args {
   int64_t group_stride;
   int32_t g_lowp;       /* backward: the gradient stream (dx, add1, add2) is stored as T (bf16) instead of float32;
                            all arithmetic and the dots stay float32 */
+  int32_t defer_reduce; /* backward: leave the per-block partials of dgamma / dbeta / dots in `partial` (one private region per
+                           call) and skip the two small reduction launches; uvc_layernorm_bwd_reduce_batch finishes many calls at once */
 } uvc_ln_args;
+/* one deferred uvc_layernorm_bwd call: its partial region and outputs (dots may be NULL) */
+typedef struct uvc_ln_reduce_item { const float* partial; float* dgamma; float* dbeta; float* dots; int32_t nblocks; int32_t reserved; } uvc_ln_reduce_item;
+/* finish up to 64 deferred LayerNorm backward calls (same D) in ONE launch; sums in a fixed order (deterministic);
+ * outputs written as beta_acc*old + sum.  `items` is a HOST array. */
+int uvc_layernorm_bwd_reduce_batch(const uvc_ln_reduce_item* items, int32_t n, int32_t D, float beta_acc, void* stream);
 int uvc_layernorm_fwd(const uvc_ln_args* args, void* stream);
 int uvc_layernorm_bwd(const uvc_ln_args* args, void* stream);
 int uvc_layernorm_bwd_blocks(int32_t rows);
+int uvc_layernorm_bwd_nblocks(int32_t rows);
 
 /* Fused inference MLP half of a block: out = x + fc2(GELU(fc1(LayerNorm(x)))) (model_distilled.py:153-166,186-189) for the
  * no-grad forwards (teacher: utils/losses.py:47-49; eval).  x, out float32 [M, D]; w1 [F, D], w2 [D, F] are the bf16

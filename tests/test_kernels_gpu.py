@@ -276,6 +276,45 @@ def test_layernorm_bwd_bf16_gradient_stream(rows, D):
         ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dg, db, rows, D, BF16, add1=add1.float())
 
 
+def test_layernorm_bwd_deferred_batched_reduction():
+    """defer_reduce leaves the per-block partials in a private region; uvc_layernorm_bwd_reduce_batch finishes several calls
+    in one launch and must give exactly the results of the immediate path (same fixed summation order is not required,
+    equality to 1e-6 is)."""
+    import ctypes as C
+    from uvc_amd import _lib as L, ops
+    rows, D = 1576, 192
+    outs = []
+    items = (L.uvc_ln_reduce_item * 2)()
+    keep = []
+    for k in range(2):
+        x, gamma = rnd(rows, D, seed=131 + k) * 2, rnd(D, seed=133 + k) * 0.2 + 1.0
+        y = torch.empty(rows, D, device=dev(), dtype=torch.bfloat16)
+        mean, rstd = torch.empty(rows, device=dev()), torch.empty(rows, device=dev())
+        ops.layernorm_fwd(x, gamma, rnd(D, seed=135), y, mean, rstd, rows, D, BF16)
+        dy = to_t(rnd(rows, D, seed=137 + k), BF16)
+        dx = torch.empty(rows, D, device=dev())
+        part = torch.empty(ops.layernorm_bwd_blocks(rows) * (2 * D + 2), device=dev())
+        dg, db, dots = torch.zeros(D, device=dev()), torch.zeros(D, device=dev()), torch.zeros(2, device=dev())
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, part, dg, db, rows, D, BF16, dots=dots)
+        dg2, db2, dots2 = torch.zeros(D, device=dev()), torch.zeros(D, device=dev()), torch.zeros(2, device=dev())
+        part2 = torch.empty_like(part)
+        a = ops._ln_args(x, gamma, None, rows, D, BF16, 1, None)
+        a.mean, a.rstd, a.dy, a.dx = L.ptr(mean), L.ptr(rstd), L.ptr(dy), L.ptr(dx)
+        a.partial, a.dgamma, a.dbeta, a.dots = L.ptr(part2), L.ptr(dg2), L.ptr(db2), L.ptr(dots2)
+        a.dy_is_f32, a.defer_reduce = 0, 1
+        L.check(L.lib().uvc_layernorm_bwd(C.byref(a), L.cur_stream()), "uvc_layernorm_bwd")
+        assert float(dg2.abs().sum()) == 0.0                       # nothing reduced yet
+        items[k].partial, items[k].dgamma, items[k].dbeta, items[k].dots = L.ptr(part2), L.ptr(dg2), L.ptr(db2), L.ptr(dots2)
+        items[k].nblocks = int(L.lib().uvc_layernorm_bwd_nblocks(rows))
+        outs.append((dg, db, dots, dg2, db2, dots2))
+        keep.append((x, gamma, y, mean, rstd, dy, dx, part, part2))
+    L.check(L.lib().uvc_layernorm_bwd_reduce_batch(items, 2, D, 0.0, L.cur_stream()), "uvc_layernorm_bwd_reduce_batch")
+    for dg, db, dots, dg2, db2, dots2 in outs:
+        torch.testing.assert_close(dg2, dg, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(db2, db, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dots2, dots, rtol=1e-5, atol=1e-3)
+
+
 def test_layernorm_class_token_rows():
     """Final norm on the class/dist-token rows only (model_distilled.py:507-508): strided rows."""
     from uvc_amd import ops

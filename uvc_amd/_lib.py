@@ -58,12 +58,16 @@ class uvc_attn_args(C.Structure):
                [(n, C.c_int32) for n in ("B", "N", "H", "head_dim", "dtype")] + [("scale", C.c_float)]
 
 
+class uvc_ln_reduce_item(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("partial", "dgamma", "dbeta", "dots")] + [("nblocks", C.c_int32), ("reserved", C.c_int32)]
+
+
 class uvc_ln_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "gamma", "beta", "y", "mean", "rstd", "dy", "dx", "add1", "a1", "add2",
                                           "a2", "partial", "dgamma", "dbeta", "dots")] + \
                [("eps", C.c_float), ("beta_acc", C.c_float)] + \
                [(n, C.c_int32) for n in ("rows", "D", "rows_per_group", "dtype", "y_is_f32", "dy_is_f32")] + \
-               [("group_stride", C.c_int64), ("g_lowp", C.c_int32)]
+               [("group_stride", C.c_int64), ("g_lowp", C.c_int32), ("defer_reduce", C.c_int32)]
 
 
 class uvc_mlp_args(C.Structure):
@@ -106,6 +110,8 @@ _SIGNATURES = {
     "uvc_layernorm_fwd": [C.POINTER(uvc_ln_args), VP],
     "uvc_layernorm_bwd": [C.POINTER(uvc_ln_args), VP],
     "uvc_layernorm_bwd_blocks": [I32],
+    "uvc_layernorm_bwd_nblocks": [I32],
+    "uvc_layernorm_bwd_reduce_batch": [C.POINTER(uvc_ln_reduce_item), I32, I32, F32, VP],
     "uvc_distill_loss": [C.POINTER(uvc_loss_args), VP],
     "uvc_grad_sqnorm": [VP, I64, VP, VP, I32, VP],
     "uvc_adamw_step": [C.POINTER(uvc_adamw_args), VP],

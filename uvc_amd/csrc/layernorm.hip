@@ -3,6 +3,7 @@
 // UVC/models/model_distilled.py:199,204,288 (eps from joint_train.py:138), biased variance.
 // Algorithmic bytes/row: fwd 4D read + sizeof(T)*D write; bwd (4 + sizeof(Tdy))*D read (+4D per
 // addend) + 4D write.
+#include <cstring>
 #include "common.h"
 #include "../../include/uvc_kernels.h"
 
@@ -324,6 +325,28 @@ __global__ __launch_bounds__(256) void k_ln_bwd_reduce2(uvc_ln_args a, const flo
   else if (a.dots) a.dots[c - 2 * a.D] = tot;
 }
 
+// batched finish of deferred calls: block (x, y) = 64 columns of item y; 1024 threads = 64 columns x 16 row slices
+struct LnBatch { uvc_ln_reduce_item it[64]; };
+__global__ __launch_bounds__(1024) void k_ln_bwd_reduce_batch(LnBatch b, int D, float beta_acc) {
+  __shared__ float red[16][64];
+  const uvc_ln_reduce_item& it = b.it[blockIdx.y];
+  const int W = 2 * D + 2;
+  const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (c < W)
+    for (int r = sl; r < it.nblocks; r += 16) s += it.partial[(size_t)r * W + c];
+  red[sl][tx] = s;
+  __syncthreads();
+  if (sl == 0 && c < W) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][tx];
+    if (c < D) it.dgamma[c] = (beta_acc != 0.f ? beta_acc * it.dgamma[c] : 0.f) + tot;
+    else if (c < 2 * D) it.dbeta[c - D] = (beta_acc != 0.f ? beta_acc * it.dbeta[c - D] : 0.f) + tot;
+    else if (it.dots) it.dots[c - 2 * D] = tot;
+  }
+}
+
 int check(const uvc_ln_args* p) {
   if (!p || !p->x || !p->gamma || !p->mean || !p->rstd) return uvc_set_error_msg(UVC_ERR_ARG, "layernorm: null pointer");
   if (p->rows <= 0 || p->D <= 0 || p->D > 1024) return uvc_set_error_msg(UVC_ERR_ARG, "layernorm: need 0 < D <= 1024");
@@ -385,6 +408,7 @@ template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
     else k_ln_bwd<T, 16><<<grid, 256, 0, st>>>(a);
   }
   UVC_CHECK_LAUNCH();
+  if (a.defer_reduce) return UVC_OK;
   const int W = 2 * a.D + 2;
   if (grid >= 4 * RED_S) {
     float* p2 = a.partial + (size_t)grid * W;            // scratch tail (uvc_layernorm_bwd_blocks reserves it)
@@ -402,6 +426,8 @@ template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
 
 // number of [2D+2]-float rows the backward scratch must hold: per-block partials + the second reduction stage
 extern "C" int uvc_layernorm_bwd_blocks(int32_t rows) { return ceil_div(rows, LN_ROWS_PER_BLOCK) + RED_S; }
+// number of partial rows a call over `rows` rows writes (the nblocks of its uvc_ln_reduce_item)
+extern "C" int uvc_layernorm_bwd_nblocks(int32_t rows) { return ceil_div(rows, LN_ROWS_PER_BLOCK); }
 
 extern "C" int uvc_layernorm_fwd(const uvc_ln_args* p, void* stream) {
   if (int e = check(p)) return e;
@@ -417,4 +443,17 @@ extern "C" int uvc_layernorm_bwd(const uvc_ln_args* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (p->dy_is_f32 || p->dtype == UVC_F32) return launch_bwd<float>(*p, st);
   return launch_bwd<bf16_t>(*p, st);
+}
+
+extern "C" int uvc_layernorm_bwd_reduce_batch(const uvc_ln_reduce_item* items, int32_t n, int32_t D, float beta_acc, void* stream) {
+  if (!items || n <= 0 || n > 64 || D <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_layernorm_bwd_reduce_batch: 1..64 items");
+  LnBatch b;
+  memset(&b, 0, sizeof(b));
+  for (int i = 0; i < n; ++i) {
+    if (!items[i].partial || !items[i].dgamma || !items[i].dbeta || items[i].nblocks <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_layernorm_bwd_reduce_batch: bad item");
+    b.it[i] = items[i];
+  }
+  k_ln_bwd_reduce_batch<<<dim3(ceil_div(2 * D + 2, 64), n), 1024, 0, (hipStream_t)stream>>>(b, D, beta_acc);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
 }

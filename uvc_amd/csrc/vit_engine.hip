@@ -53,7 +53,7 @@ struct Work {
   // backward scratch
   void* gA; void* gB;      // dL/dx streams of the backward: T (bf16 in the throughput mode: every consumer is a bf16 GEMM
                            // operand or a LayerNorm backward that accumulates in float32), float32 in the exact mode
-  void* dA; void* dH; void* dqkv; float* delta; float* ln_partial; float* cs_partial;
+  void* dA; void* dH; void* dqkv; float* delta; float* ln_partial; int64_t ln_region; float* cs_partial;
   void* tn_ws; int64_t tn_ws_bytes; float* dotsraw; void* dhc; void* dpe;
 };
 
@@ -91,7 +91,10 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
     w.gA = c.take(MD * d.tsz); w.gB = c.take(MD * d.tsz);
     w.dA = c.take(MF * d.tsz); w.dH = c.take(MD * d.tsz); w.dqkv = c.take(3 * MD * d.tsz);
     w.delta = (float*)c.take((int64_t)d.B * d.H * d.N * 4);
-    w.ln_partial = (float*)c.take((int64_t)uvc_layernorm_bwd_blocks(d.M) * (2 * d.D + 2) * 4);
+    // one private region of per-block dgamma/dbeta/dots partials per LayerNorm-backward call of a pass (2 per block + final norm):
+    // the calls leave their partials there and ONE batched launch per backward call finishes them (49 tiny launches less per step)
+    w.ln_region = (int64_t)uvc_layernorm_bwd_blocks(d.M) * (2 * d.D + 2);
+    w.ln_partial = (float*)c.take(w.ln_region * 4 * (2 * d.L + 1));
     const int maxN = d.F > 3 * d.D ? d.F : 3 * d.D;
     w.cs_partial = (float*)c.take((int64_t)uvc_colsum_blocks(d.M) * (maxN > d.NC ? maxN : d.NC) * 4);
     w.tn_ws_bytes = max_tn_ws(d);
@@ -108,6 +111,7 @@ struct Ctx {
   const uvc_vit_cfg* cfg; Dims d; uvc_vit_offsets off; uvc_vit_shadow_offsets soff; const uvc_vit_io* io; void* st; Work w;
   void* side;            // optional second stream for the weight-gradient GEMMs (backward)
   bool done_set[5];      // ev_done[k] recorded in this call
+  uvc_ln_reduce_item ln_items[64]; int n_ln = 0;   // LayerNorm-backward calls of this pass whose reductions are still pending
 };
 
 // Events for the two-stream backward.  Created once per process (host objects, no device memory).
@@ -187,12 +191,22 @@ int ln_fwd(const Ctx& c, const float* x, int64_t pw, int64_t pb, void* y, float*
   a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
   return uvc_layernorm_fwd(&a, c.st);
 }
-int ln_bwd(const Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, void* dx,
+int flush_ln(Ctx& c) {
+  if (c.n_ln == 0) return UVC_OK;
+  const int e = uvc_layernorm_bwd_reduce_batch(c.ln_items, c.n_ln, c.d.D, c.io->accumulate, c.st);
+  c.n_ln = 0;
+  return e;
+}
+int ln_bwd(Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, void* dx,
            const void* add1, const float* a1, const void* add2, const float* a2, float* dots, int rows, int rpg, int64_t gs) {
   uvc_ln_args a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.gamma = c.io->params + pw; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx; a.add1 = add1; a.a1 = a1;
-  a.add2 = add2; a.a2 = a2; a.partial = c.w.ln_partial; a.dgamma = c.io->grads + pw; a.dbeta = c.io->grads + pb; a.dots = dots;
+  if (c.n_ln >= 2 * c.d.L + 1) { if (int e = flush_ln(c)) return e; }
+  a.add2 = add2; a.a2 = a2; a.partial = c.w.ln_partial + c.w.ln_region * c.n_ln; a.dgamma = c.io->grads + pw; a.dbeta = c.io->grads + pb; a.dots = dots;
+  a.defer_reduce = 1;
+  uvc_ln_reduce_item& it = c.ln_items[c.n_ln++];
+  it.partial = a.partial; it.dgamma = a.dgamma; it.dbeta = a.dbeta; it.dots = dots; it.nblocks = uvc_layernorm_bwd_nblocks(rows); it.reserved = 0;
   a.eps = 1e-6f; a.beta_acc = c.io->accumulate; a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
   a.g_lowp = c.d.dtype == UVC_BF16;
   return uvc_layernorm_bwd(&a, c.st);
@@ -482,12 +496,14 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   }
   if (sb <= d.L + 1 && se > d.L + 1) {
     // gate logits (block_skip_gating) gradient
+    TRY(flush_ln(c));                          // the gate gradient reads the dot products of the blocks' LayerNorm backwards
     if (io->gate_d && io->gate_mode != 0)
       TRY(uvc_gate_grad(P + o.gate, io->gate_d, w.dotsraw, G + o.gate, d.L, io->gate_mode, io->gate_eps, io->accumulate, stream));
     // token assembly
     TRY(uvc_assemble_tokens_bwd(w.gA, w.pe, io->patch_mask, w.dpe, G + o.pos_embed, G + o.cls_token, d.ntok == 2 ? G + o.dist_token : nullptr,
                                 io->d_patch_mask, d.B, d.np, d.D, d.ntok, d.dtype, 0, d.dtype == UVC_BF16, io->accumulate, stream));
   }
+  TRY(flush_ln(c));
   if (se < d.L + 3) return join_side(c);
   // patch embedding (weight gradient only: the image needs no gradient)
   TRY(tn(c, w.dpe, 0, w.patches, G + o.patch_w, G + o.patch_b, d.B * d.np, d.D, d.K0));

@@ -81,6 +81,10 @@ typedef struct uvc_attn_args {
   float* delta;      /* scratch [B,H,N]    backward only */
   int32_t B, N, H, head_dim, dtype;
   float scale;
+  const int32_t* head_keep;  /* forward only, optional device [H]: heads with 0 are skipped and their slice of o is written as zeros.
+                                For inference on a pruned model whose attn.proj input columns of that head are all zero (masked),
+                                which makes the skip exact.  Not for training: the reference's clip norm includes the gradients of
+                                masked proj columns, which need the head's output. */
 } uvc_attn_args;
 int uvc_attention_fwd(const uvc_attn_args* args, void* stream);
 int uvc_attention_bwd(const uvc_attn_args* args, void* stream);

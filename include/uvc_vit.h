@@ -105,6 +105,8 @@ typedef struct uvc_vit_io {
    * `stream` waits for the side stream before the call's last stage returns. */
   void* side_stream;
   const uvc_mlp_compact* mlp_compact;  /* HOST [L] or NULL; entries with width 0 or width == hidden run dense */
+  const int32_t* head_keep;            /* device [L, H] or NULL: no-grad forwards skip the attention of heads marked 0 (their
+                                          attn.proj input columns are masked to zero, so the result is unchanged); ignored when training */
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

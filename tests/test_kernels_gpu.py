@@ -202,6 +202,23 @@ def test_attention_fwd_bwd(dtype, B, N, H):
     torch.testing.assert_close(dqkv.double(), x.grad, **tb)
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_attention_forward_head_keep(dtype):
+    """Inference-only head skipping: heads marked 0 get an all-zero output slice, the others are untouched."""
+    from uvc_amd import ops
+    B, N, H = 3, 197, 3
+    T = ops.tdtype(dtype)
+    qkv = to_t(rnd(B, N, 3 * H * 64, seed=141), dtype)
+    o_full, o_skip = torch.empty(B, N, H * 64, device=dev(), dtype=T), torch.full((B, N, H * 64), float("nan"), device=dev(), dtype=T)
+    lse = torch.empty(B, H, N, device=dev())
+    ops.attention_fwd(qkv, o_full, lse, B, N, H, dtype)
+    keep = torch.tensor([1, 0, 1], device=dev(), dtype=torch.int32)
+    ops.attention_fwd(qkv, o_skip, lse, B, N, H, dtype, head_keep=keep)
+    o_full, o_skip = o_full.view(B, N, H, 64), o_skip.view(B, N, H, 64)
+    assert torch.equal(o_skip[:, :, 0], o_full[:, :, 0]) and torch.equal(o_skip[:, :, 2], o_full[:, :, 2])
+    assert float(o_skip[:, :, 1].float().abs().sum()) == 0.0
+
+
 def test_attention_softmax_extremes_f32():
     """Rows dominated by one key (large logits) and identical keys: no NaN/inf, matches float64."""
     from uvc_amd import ops

@@ -192,3 +192,28 @@ def test_mlp_compaction_equals_the_dense_masked_computation(name, precision):
             inv = m._mlp_bufs[l]["inv"]
             assert float(m.blocks[l].mlp.fc1.weight.grad[inv < 0].abs().sum()) == 0.0
             assert float(m.blocks[l].mlp.fc2.weight.grad[:, inv < 0].abs().sum()) > 0.0      # the rank-1 columns are there
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_eval_forward_skipping_pruned_heads_and_units_is_exact(precision):
+    """valid()-style forward of the pruned model: with the masks applied, skipping the attention of fully pruned heads and the
+    pruned MLP units gives the logits of the dense masked forward (bit-identical for the heads: their outputs only meet zero
+    weights; the MLP runs other GEMM shapes, so float32 summation order may differ)."""
+    name = "stage2_tiny8"
+    r, cfg, tr = build(name, precision, compact=1)
+    m = tr.model
+    # make sure at least one head is fully pruned in some layer
+    assert tr.head_keep is not None and int((tr.head_keep == 0).sum()) > 0, tr.head_keep
+    m.apply_masks()
+    x_all, _ = SC.make_inputs(r)
+    x = torch.from_numpy(x_all[0]).cuda()
+    m.eval()
+    with torch.no_grad():
+        out_skip, _ = m(x)
+        m.set_head_skipping(False)
+        out_heads_dense, _ = m(x)
+        m.set_mlp_compaction(False)
+        out_dense, _ = m(x)
+    assert torch.equal(out_skip, out_heads_dense)
+    tol = dict(rtol=1e-5, atol=1e-5) if precision == "fp32" else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out_skip, out_dense, **tol)

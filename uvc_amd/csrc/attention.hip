@@ -176,6 +176,7 @@ struct AttnArgs {
   float* delta;      // [B, H, N]
   int B, N, H;
   float scale;
+  const int* head_keep;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -194,9 +195,14 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
   const T* kb = qb + a.H * HD;
   const T* vb = qb + 2 * a.H * HD;
+  T* ob = reinterpret_cast<T*>(a.o) + (size_t)b * a.N * a.H * HD + h * HD;
+  if (a.head_keep && a.head_keep[h] == 0) {                 // pruned head (inference): its output slice is zeros, nothing is read
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < a.N * 16; i += blockDim.x) Store4<T>::st(ob + (size_t)(i >> 4) * a.H * HD + (i & 15) * 4, z);
+    return;
+  }
   stage_rows2<T>(sK, kb, ldq, sV, vb, ldq, a.N, NP);
   __syncthreads();
-  T* ob = reinterpret_cast<T*>(a.o) + (size_t)b * a.N * a.H * HD + h * HD;
   const int nqt = (a.N + 15) / 16;
   for (int qt = w; qt < nqt; qt += nw) {
     typename MM::Frag qf[G::KS];
@@ -449,7 +455,7 @@ int check(const uvc_attn_args* p, bool bwd) {
 AttnArgs conv(const uvc_attn_args* p) {
   AttnArgs a;
   a.qkv = p->qkv; a.o = p->o; a.lse = p->lse; a.dout = p->dout; a.dqkv = p->dqkv; a.delta = p->delta;
-  a.B = p->B; a.N = p->N; a.H = p->H; a.scale = p->scale;
+  a.B = p->B; a.N = p->N; a.H = p->H; a.scale = p->scale; a.head_keep = p->head_keep;
   return a;
 }
 

@@ -211,9 +211,10 @@ int ln_bwd(Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const
   a.g_lowp = c.d.dtype == UVC_BF16;
   return uvc_layernorm_bwd(&a, c.st);
 }
-int attn(const Ctx& c, const BlockBufs& b, bool bwd) {
+int attn(const Ctx& c, const BlockBufs& b, bool bwd, int layer = -1) {
   uvc_attn_args a;
   memset(&a, 0, sizeof(a));
+  if (!bwd && layer >= 0 && !c.io->training && c.io->head_keep) a.head_keep = c.io->head_keep + (size_t)layer * c.d.H;
   a.qkv = b.qkv; a.o = b.o; a.lse = b.lse; a.dout = c.w.dH; a.dqkv = c.w.dqkv; a.delta = c.w.delta;
   a.B = c.d.B; a.N = c.d.N; a.H = c.d.H; a.head_dim = 64; a.dtype = c.d.dtype; a.scale = 0.125f;
   return bwd ? uvc_attention_bwd(&a, c.st) : uvc_attention_fwd(&a, c.st);
@@ -381,7 +382,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     const int64_t* q = o.blk[l];
     TRY(ln_fwd(c, xin, q[0], q[1], b.h1, b.mean1, b.rstd1, d.M, 1, d.D));
     TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, UVC_EPI_BIAS, P + q[3]));
-    TRY(attn(c, b, false));
+    TRY(attn(c, b, false, l));
     TRY(nt(c, b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), b.x1, 1, d.M, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xin));
     // Stage-2 compaction: pruned hidden units are skipped (compact weights gathered by the host, uvc_mlp_compact)
     const uvc_mlp_compact* mc = (io->mlp_compact && io->mlp_compact[l].width > 0 && io->mlp_compact[l].width < d.F) ? &io->mlp_compact[l] : nullptr;

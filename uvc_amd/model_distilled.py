@@ -52,7 +52,7 @@ class uvc_vit_io(C.Structure):
                 ("run_block", C.POINTER(C.c_int32)), ("patch_mask", C.c_void_p), ("d_patch_mask", C.c_void_p),
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
                 ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
-                ("mlp_compact", C.c_void_p)]
+                ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p)]
 
 
 class uvc_mlp_compact(C.Structure):
@@ -214,6 +214,7 @@ class DistilledVisionTransformer(nn.Module):
         self._flat_mask = None
         self._mlp_compact = None
         self._mlp_bufs = None
+        self._head_keep = None
         self._skip_grads_clean = False
         self.exp_source = lambda shape: torch.empty(shape, device=self._flat.device, dtype=torch.float32).exponential_()
         self.to(dev)
@@ -386,6 +387,26 @@ class DistilledVisionTransformer(nn.Module):
         self._shadow_fresh = False
         return widths
 
+    def set_head_skipping(self, keep=None):
+        """No-grad forwards (eval) skip the attention of pruned heads.  ``keep``: bool [depth, heads], or None to derive it from
+        the masks (a head is pruned when every attn.proj mask column of its 64 inputs is zero: its output then meets only
+        zero weights, so skipping it is exact once ``apply_masks()`` has run); ``False`` switches it off.  Training forwards
+        never skip heads: the reference's global-norm clip includes the gradients of the masked proj columns."""
+        if keep is False:
+            self._head_keep = None
+            return None
+        cfg = self._cfg
+        if keep is None:
+            rows = []
+            for blk in self.blocks:
+                m = getattr(blk.attn.proj, "mask", None)
+                rows.append(torch.ones(cfg.num_heads, dtype=torch.bool) if m is None else
+                            (m != 0).any(dim=0).reshape(cfg.num_heads, -1).any(dim=1).cpu())
+            keep = torch.stack(rows)
+        keep = keep.to(torch.int32).contiguous()
+        self._head_keep = None if bool(keep.all()) else keep.to(self._flat.device)
+        return keep
+
     def _gather_compact(self, stream):
         """Refresh the gathered operand copies of the compacted MLPs from the (masked) master weights."""
         dt = ops.UVC_F32 if self.precision == "fp32" else ops.UVC_BF16
@@ -434,6 +455,7 @@ class DistilledVisionTransformer(nn.Module):
         io.gate_mode, io.gate_eps = self._gate_mode(), float(self.eps)
         io.accumulate = 1.0 if self.grad_accumulate else 0.0
         io.mlp_compact = C.addressof(self._mlp_compact) if self._mlp_compact is not None else None
+        io.head_keep = L.ptr(self._head_keep) if (self._head_keep is not None and not training) else None
         return io
 
     def _ws_view(self, B, training, which):

@@ -88,8 +88,11 @@ def _attn_args(qkv, o, lse, B, N, H, dtype, dout=None, dqkv=None, delta=None):
     return a
 
 
-def attention_fwd(qkv, o, lse, B, N, H, dtype):
+def attention_fwd(qkv, o, lse, B, N, H, dtype, head_keep=None):
     a = _attn_args(qkv, o, lse, B, N, H, dtype)
+    if head_keep is not None:
+        _chk(head_keep)
+        a.head_keep = L.ptr(head_keep)
     L.check(L.lib().uvc_attention_fwd(C.byref(a), L.cur_stream()), "uvc_attention_fwd")
 
 

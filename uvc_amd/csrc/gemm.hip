@@ -317,30 +317,33 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
 // 192-column group; groups of one tile sequence are placed on one XCD so they share its L2.
 constexpr int WS_BM = 64;
 
-template <typename TA, typename TC, int EPI, int KT, int WS_NW>
-__global__ __launch_bounds__(64 * WS_NW, 2) void k_gemm_ws(NtArgs g, int ngroups, int nslots) {
+// NJ = 16-column accumulator tiles per wave: 4 (64 columns, 96 VGPRs of W at K = 192, two waves per SIMD) or 2 (32 columns, 48 VGPRs,
+// eight waves per workgroup, four per SIMD: the GELU epilogues of fc1 overlap its stores better)
+template <typename TA, typename TC, int EPI, int KT, int WS_NW, int NJ = 4>
+__global__ __launch_bounds__(64 * WS_NW, NJ == 4 ? 2 : 4) void k_gemm_ws(NtArgs g, int ngroups, int nslots) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   constexpr int ROWB = KT * 64 + 32;             // bytes per staged A row (KT*32 bf16 + pad; words = 8 or 40 mod 64, see NT_ROWB)
   constexpr int CPR = KT * 4;                    // 16-byte chunks per row
   constexpr int NLD = (WS_BM * CPR + 64 * WS_NW - 1) / (64 * WS_NW);
-  constexpr int VN = OutVec<TC>::VN, LPR = 64 / VN, RPI = 64 / LPR;
+  constexpr int CW = 16 * NJ, EPW = CW + 4;         // columns per wave; floats per staged accumulator row
+  constexpr int VN = OutVec<TC>::VN, LPR = CW / VN, RPI = 64 / LPR;
   __shared__ __attribute__((aligned(16))) char sA[2][WS_BM * ROWB];
-  __shared__ __attribute__((aligned(16))) float sStage[WS_NW][16 * EP_LD];
+  __shared__ __attribute__((aligned(16))) float sStage[WS_NW][16 * EPW];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gq = lane >> 4, li = lane & 15;
   const int L = blockIdx.x;
   const int grp = (L >> 3) % ngroups, slot = (L / (8 * ngroups)) * 8 + (L & 7);
-  const int n0 = grp * 64 * WS_NW + w * 64;
+  const int n0 = grp * CW * WS_NW + w * CW;
   const bool active = n0 < g.N;                  // N % 64 == 0: a wave is either fully inside or idle
   const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A);
   const T* __restrict__ W = reinterpret_cast<const T*>(g.B);
   TC* __restrict__ C = reinterpret_cast<TC*>(g.C);
   const int ntiles = (g.M + WS_BM - 1) / WS_BM;
 
-  typename MM::Frag bf[4][KT];
+  typename MM::Frag bf[NJ][KT];
   if (active) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int ks = 0; ks < KT; ++ks)
         bf[j][ks] = __builtin_bit_cast(typename MM::Frag, *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + j * 16 + li) * g.ldb + (ks * 4 + gq) * 8));
@@ -405,11 +408,11 @@ __global__ __launch_bounds__(64 * WS_NW, 2) void k_gemm_ws(NtArgs g, int ngroups
 #pragma unroll
       for (int ks = 0; ks < KT; ++ks) fa[ks] = lds_frag<T>(sA[buf_] + (sub_ * 16 + li) * ROWB + (ks * 4 + gq) * 16);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) c = MM::mma(bf[j][ks], fa[ks], c);
-        *reinterpret_cast<f32x4*>(stg + li * EP_LD + j * 16 + gq * 4) = c;
+        *reinterpret_cast<f32x4*>(stg + li * EPW + j * 16 + gq * 4) = c;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(64 * WS_NW, 2) void k_gemm_ws(NtArgs g, int ngroups
       const int r = it * RPI + lane / LPR;
       const int m = m0_ + sub_ * 16 + r;
       float v[VN];
-      load_vec<float, VN>(stg + r * EP_LD + cc, v);
+      load_vec<float, VN>(stg + r * EPW + cc, v);
       if (m < g.M) {
         const size_t mo = (size_t)m;
 #pragma unroll
@@ -516,8 +519,30 @@ static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }
+template <typename TA, typename TC, int KT>
+static int launch_ws_narrow(const NtArgs& a, int epi, hipStream_t st) {      // 8 waves x 32 columns
+  const int ngroups = ceil_div(a.N, 256);
+  const int ntiles = ceil_div(a.M, WS_BM);
+  int nslots = (512 / ngroups) & ~7;
+  if (nslots < 8) nslots = 8;
+  if (nslots > ((ntiles + 7) & ~7)) nslots = (ntiles + 7) & ~7;
+  const int grid = nslots * ngroups;
+#define WS_CASE(E) case E: k_gemm_ws<TA, TC, E, KT, 8, 2><<<grid, 512, 0, st>>>(a, ngroups, nslots); break;
+  switch (epi) {
+    WS_CASE(UVC_EPI_DGELU) WS_CASE(UVC_EPI_MUL_AUX)
+    default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue");
+  }
+#undef WS_CASE
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
 template <typename TA, typename TC>
 static int launch_ws(const NtArgs& a, int epi, hipStream_t st) {
+  // dL/d(fc1 out) = (g W2) * gelu'(a): measured 95 -> 83 us (stored gelu') and 118 -> 105 us (recomputed) with 32 columns per wave;
+  // the forward's GELU epilogues are VALU-bound either way and stay on the 64-column tiling
+  if constexpr (sizeof(TC) == 2 && sizeof(TA) == 2) {
+    if (a.N % 256 == 0 && a.K == 192 && (epi == UVC_EPI_DGELU || epi == UVC_EPI_MUL_AUX)) return launch_ws_narrow<TA, TC, 6>(a, epi, st);
+  }
   // 4 waves (256 columns) per workgroup when N divides: more waves per CU to overlap the GELU epilogues
   if (a.N % 256 == 0) return a.K == 192 ? launch_ws_epi<TA, TC, 6, 4>(a, epi, st) : launch_ws_epi<TA, TC, 4, 4>(a, epi, st);
   return a.K == 192 ? launch_ws_epi<TA, TC, 6, 3>(a, epi, st) : launch_ws_epi<TA, TC, 4, 3>(a, epi, st);

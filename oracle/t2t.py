@@ -138,17 +138,24 @@ def prm_exp(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return torch.exp(wtx - xd) / math.sqrt(m)
 
 
+def linear_attention(kqv: torch.Tensor, w: torch.Tensor):
+    """token_performer.py:46-50: kqv [B, T, 3*emb] split as k | q | v -> (y [B, T, emb], v)."""
+    emb = kqv.shape[-1] // 3
+    k, q, v = torch.split(kqv, emb, dim=-1)
+    kp, qp = prm_exp(k, w), prm_exp(q, w)
+    D = torch.einsum("bti,bi->bt", qp, kp.sum(dim=1)).unsqueeze(2)
+    kptv = torch.einsum("bin,bim->bnm", v.float(), kp)
+    y = torch.einsum("bti,bni->btn", qp, kptv) / (D + PRM_EPS)
+    return y, v
+
+
 def performer(sd: Dict[str, torch.Tensor], pre: str, x: torch.Tensor):
     """Token_performer.forward (token_performer.py:45-69).  Returns (tokens [B, T, emb], macs)."""
     emb = sd[pre + "proj.weight"].shape[0]
     w = sd[pre + "w"]
     xn = F.layer_norm(x, (x.shape[-1],), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], LN_EPS)
     kqv = F.linear(xn, sd[pre + "kqv.weight"], sd[pre + "kqv.bias"])
-    k, q, v = torch.split(kqv, emb, dim=-1)
-    kp, qp = prm_exp(k, w), prm_exp(q, w)
-    D = torch.einsum("bti,bi->bt", qp, kp.sum(dim=1)).unsqueeze(2)
-    kptv = torch.einsum("bin,bim->bnm", v.float(), kp)
-    y = torch.einsum("bti,bni->btn", qp, kptv) / (D + PRM_EPS)
+    y, v = linear_attention(kqv, w)
     y = v + F.linear(y, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
     B, T, dim = x.shape
     m = w.shape[0]

@@ -86,6 +86,20 @@ class uvc_adamw_args(C.Structure):
                [("step", C.c_int32), ("flags", C.c_void_p)]
 
 
+class uvc_unfold_args(C.Structure):          # include/uvc_t2t.h
+    _fields_ = [("src", C.c_void_p)] + [(n, C.c_int64) for n in ("sb", "sc", "sh", "sw")] + \
+               [(n, C.c_int32) for n in ("B", "C", "H", "W", "k", "s", "p", "ldo", "out_is_f32", "dtype")] + \
+               [("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("out", C.c_void_p), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("dy", C.c_void_p), ("dy_is_f32", C.c_int32), ("dxu", C.c_void_p), ("partial", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("beta_acc", C.c_float)]
+
+
+class uvc_performer_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("kqv", "w", "part", "kptv", "att")] + [("att_is_f32", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("datt", "dskip", "dkqv", "dkptv")] + \
+               [(n, C.c_int32) for n in ("g_is_f32", "B", "T", "dtype")]
+
+
 UVC_F32, UVC_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_BIAS_GELU_OUT, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX = range(9)
 
@@ -139,6 +153,14 @@ _SIGNATURES = {
     "uvc_cast_transpose_multi": [VP, VP, I32, VP, VP, VP, VP, VP, I32, VP],
     "uvc_gate_distrib": [VP, VP, VP, I32, I32, F32, VP],
     "uvc_gate_grad": [VP, VP, VP, VP, I32, I32, F32, F32, VP],
+    # include/uvc_t2t.h
+    "uvc_unfold_ln_fwd": [C.POINTER(uvc_unfold_args), VP],
+    "uvc_unfold_ln_bwd": [C.POINTER(uvc_unfold_args), VP],
+    "uvc_unfold_bwd_blocks": [I32],
+    "uvc_fold_tokens": [VP, I32, I32, I32, VP, I32, I32, I32, I32, I32, I32, I32, VP],
+    "uvc_performer_splits": [I32, I32],
+    "uvc_performer_fwd": [C.POINTER(uvc_performer_args), VP],
+    "uvc_performer_bwd": [C.POINTER(uvc_performer_args), VP],
 }
 
 

@@ -1,0 +1,547 @@
+// T2T-ViT tokens-to-token front end (include/uvc_t2t.h): soft split fused with the stage's LayerNorm, its adjoint (fold),
+// and the Performer's linear attention, forward and backward.  Follows UVC/T2TViT/models/t2t_vit.py:84-105 and
+// token_performer.py:31-62 of the reference.  HBM-bound token streams (3136 / 784 / 196 tokens per image, 64-wide):
+// one pass over each stream, float32 arithmetic on the VALU, LDS tiles of 64 tokens, deterministic two-level sums.
+#include "common.h"
+#include "../../include/uvc_kernels.h"
+#include "../../include/uvc_t2t.h"
+
+namespace {
+
+// ================================================================================================
+//                                  soft split (+ LayerNorm)
+// ================================================================================================
+struct UG {                       // unfold geometry + pointers, passed by value
+  const float* src; int64_t sb, sc, sh, sw;
+  int B, C, H, W, k, s, p, Ho, Wo, L, kk, dim, ldo, rows, c_fast;
+  const float* gamma; const float* beta; float eps;
+  void* out; float* mean; float* rstd;
+  const void* dy; float* dxu; float* partial;
+};
+
+// One wave gathers one unfolded row into registers in natural feature order e = lane + 64*j (e = c*kk + ki*k + kj).
+// Token-major sources (C == 64, sc == 1) are read with the channel on the lane -- 256-byte coalesced loads -- and
+// transposed to the natural order through a wave-private LDS row (stride kk is odd: conflict-free).
+template <int NV>
+__device__ __forceinline__ void gather_row(const UG& g, int row, bool valid, int lane, float* lrow, float (&v)[NV]) {
+  const int b = valid ? row / g.L : 0, l = valid ? row % g.L : 0;
+  const int ho = l / g.Wo, wo = l % g.Wo;
+  const float* sb = g.src + (int64_t)b * g.sb;
+  if (g.c_fast) {
+    for (int j = 0; j < g.kk; ++j) {
+      const int ki = j / g.k, kj = j % g.k;
+      const int hi = ho * g.s - g.p + ki, wi = wo * g.s - g.p + kj;
+      float x = 0.f;
+      if (valid && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) x = sb[(int64_t)hi * g.sh + (int64_t)wi * g.sw + lane];
+      lrow[lane * g.kk + j] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = (lane + 64 * j < g.dim) ? lrow[lane + 64 * j] : 0.f;
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int e = lane + 64 * j;
+      float x = 0.f;
+      if (valid && e < g.dim) {
+        const int c = e / g.kk, r = e % g.kk, ki = r / g.k, kj = r % g.k;
+        const int hi = ho * g.s - g.p + ki, wi = wo * g.s - g.p + kj;
+        if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) x = sb[(int64_t)c * g.sc + (int64_t)hi * g.sh + (int64_t)wi * g.sw];
+      }
+      v[j] = x;
+    }
+  }
+}
+
+template <typename TO, int NV>
+__global__ __launch_bounds__(256) void k_unfold_ln(UG g) {
+  __shared__ float lds[4][NV * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int base = blockIdx.x * 4; base < g.rows; base += gridDim.x * 4) {
+    const int row = base + wv;
+    const bool valid = row < g.rows;
+    float v[NV];
+    gather_row<NV>(g, row, valid, lane, lds[wv], v);
+    if (g.gamma) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) s += v[j];
+      const float mean = wave_sum(s) / (float)g.dim;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) { const float d = (lane + 64 * j < g.dim) ? v[j] - mean : 0.f; q += d * d; }
+      const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.dim + g.eps);
+      if (valid && lane == 0) { g.mean[row] = mean; g.rstd[row] = rstd; }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int e = lane + 64 * j;
+        if (e < g.dim) v[j] = (v[j] - mean) * rstd * g.gamma[e] + g.beta[e];
+      }
+    }
+    if (valid) {
+      TO* o = (TO*)g.out + (int64_t)row * g.ldo;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int e = lane + 64 * j;
+        if (e < g.ldo) ElemIO<TO>::store(o + e, e < g.dim ? v[j] : 0.f);
+      }
+    }
+  }
+}
+
+// LayerNorm backward of the fused kernel: recomputes the unfolded row, writes dxu (float32, natural order) and leaves the
+// per-workgroup partial sums of dgamma / dbeta in `partial` ([gridDim.x][2*dim]).
+template <typename TDY, int NV>
+__global__ __launch_bounds__(256) void k_unfold_ln_bwd(UG g) {
+  __shared__ float lds[4][NV * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float dgm[NV], dbt[NV], gam[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { dgm[j] = 0.f; dbt[j] = 0.f; gam[j] = (lane + 64 * j < g.dim) ? g.gamma[lane + 64 * j] : 0.f; }
+  const float inv = 1.0f / (float)g.dim;
+  for (int base = blockIdx.x * 4; base < g.rows; base += gridDim.x * 4) {
+    const int row = base + wv;
+    const bool valid = row < g.rows;
+    float v[NV];
+    gather_row<NV>(g, row, valid, lane, lds[wv], v);
+    const float mean = valid ? g.mean[row] : 0.f, rstd = valid ? g.rstd[row] : 0.f;
+    const TDY* dyr = (const TDY*)g.dy + (int64_t)(valid ? row : 0) * g.ldo;
+    float gy[NV], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int e = lane + 64 * j;
+      const float dy = (valid && e < g.dim) ? ElemIO<TDY>::load(dyr + e) : 0.f;
+      v[j] = (e < g.dim) ? (v[j] - mean) * rstd : 0.f;          // xhat
+      dgm[j] += dy * v[j];
+      dbt[j] += dy;
+      gy[j] = dy * gam[j];
+      s1 += gy[j];
+      s2 += gy[j] * v[j];
+    }
+    if (g.dxu) {
+      s1 = wave_sum(s1) * inv;
+      s2 = wave_sum(s2) * inv;
+      if (valid) {
+        float* o = g.dxu + (int64_t)row * g.dim;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int e = lane + 64 * j;
+          if (e < g.dim) o[e] = rstd * (gy[j] - s1 - v[j] * s2);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* red = &lds[0][0];
+  // waves 1..3 hand their sums to wave 0 through LDS, one quantity at a time (fixed order)
+  for (int pass = 0; pass < 2; ++pass) {
+    if (wv > 0) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) lds[wv][lane + 64 * j] = pass == 0 ? dgm[j] : dbt[j];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int e = lane + 64 * j;
+        const float t = (pass == 0 ? dgm[j] : dbt[j]) + lds[1][e] + lds[2][e] + lds[3][e];
+        if (e < g.dim) g.partial[(int64_t)blockIdx.x * 2 * g.dim + pass * g.dim + e] = t;
+      }
+    }
+    __syncthreads();
+  }
+  (void)red;
+}
+
+__global__ void k_unfold_bwd_reduce(const float* partial, int nblk, int dim, float* dgamma, float* dbeta, float beta_acc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * dim) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * 2 * dim + c];
+  float* o = c < dim ? dgamma + c : dbeta + (c - dim);
+  *o = (beta_acc != 0.f ? beta_acc * *o : 0.f) + t;
+}
+
+template <typename TS>
+__global__ void k_fold(const TS* src, int lds, float* dst, int B, int C, int H, int W, int k, int s, int p, int Ho, int Wo) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * H * W * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const int hw = (int)((idx / C) % (H * W));
+  const int b = (int)(idx / ((int64_t)C * H * W));
+  const int h = hw / W, w = hw % W, kk = k * k, L = Ho * Wo;
+  float acc = 0.f;
+  for (int ki = 0; ki < k; ++ki) {
+    const int hh = h + p - ki;
+    if (hh < 0 || hh % s) continue;
+    const int ho = hh / s;
+    if (ho >= Ho) continue;
+    for (int kj = 0; kj < k; ++kj) {
+      const int ww = w + p - kj;
+      if (ww < 0 || ww % s) continue;
+      const int wo = ww / s;
+      if (wo >= Wo) continue;
+      acc += ElemIO<TS>::load(src + ((int64_t)b * L + ho * Wo + wo) * lds + c * kk + ki * k + kj);
+    }
+  }
+  dst[idx] = acc;
+}
+
+int fill_geom(const uvc_unfold_args* a, UG& g) {
+  if (!a || !a->src) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold: null pointer");
+  if (a->B <= 0 || a->C <= 0 || a->k <= 0 || a->s <= 0 || a->p < 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold: geometry");
+  g.src = a->src; g.sb = a->sb; g.sc = a->sc; g.sh = a->sh; g.sw = a->sw;
+  g.B = a->B; g.C = a->C; g.H = a->H; g.W = a->W; g.k = a->k; g.s = a->s; g.p = a->p;
+  g.Ho = (a->H + 2 * a->p - a->k) / a->s + 1; g.Wo = (a->W + 2 * a->p - a->k) / a->s + 1;
+  g.L = g.Ho * g.Wo; g.kk = a->k * a->k; g.dim = a->C * g.kk; g.ldo = a->ldo; g.rows = a->B * g.L;
+  g.c_fast = (a->sc == 1 && a->C == 64) ? 1 : 0;
+  g.gamma = a->gamma; g.beta = a->beta; g.eps = a->eps; g.out = a->out; g.mean = a->mean; g.rstd = a->rstd;
+  g.dy = a->dy; g.dxu = a->dxu; g.partial = a->partial;
+  if (g.Ho <= 0 || g.Wo <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold: empty output");
+  if (g.dim > 576 || g.ldo < g.dim || g.ldo > ((g.dim + 63) / 64) * 64) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_unfold: need C*k*k <= 576 and dim <= ldo <= roundup(dim, 64)");
+  return UVC_OK;
+}
+int bwd_grid(int rows) { const int n = (rows + 3) / 4; return n < 1024 ? n : 1024; }
+
+// ================================================================================================
+//                                  Performer linear attention
+// ================================================================================================
+constexpr int PE = 64, PM = 32, PT = 64, PKV = 65 * 32;
+#define SQRT_M 5.656854249492381f
+
+__device__ __forceinline__ void load_w(const float* w, float (*sw)[65], int tid) {
+#pragma unroll
+  for (int it = 0; it < 8; ++it) { const int idx = tid + it * 256; sw[idx >> 6][idx & 63] = w[idx]; }
+}
+// [64 tokens][64] float32 tile of kqv (row stride 192) -> LDS [64][65]; rows at or beyond T are zero
+__device__ __forceinline__ void load_tile_kqv(const float* base, int t0, int T, float (*s)[65], int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t0 + r < T) v = *reinterpret_cast<const f32x4*>(base + (int64_t)(t0 + r) * 192 + c4);
+    s[r][c4] = v[0]; s[r][c4 + 1] = v[1]; s[r][c4 + 2] = v[2]; s[r][c4 + 3] = v[3];
+  }
+}
+// [64 tokens][64] tile of a dense gradient stream [B*T, 64] (float32 or bf16) -> LDS
+template <typename TG>
+__device__ __forceinline__ void load_tile_g(const TG* base, int t0, int T, float (*s)[65], int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[r][c4 + e] = (t0 + r < T) ? ElemIO<TG>::load(base + (int64_t)(t0 + r) * 64 + c4 + e) : 0.f;
+  }
+}
+__device__ __forceinline__ void load_kv(const float* kv, float (*skv)[33], int tid) {
+  for (int idx = tid; idx < PKV; idx += 256) skv[idx >> 5][idx & 31] = kv[idx];
+}
+// positive random features (token_performer.py:31-43): thread (token t, feature group mg) -> 8 of the 32 features
+__device__ __forceinline__ void prm8(const float (*sx)[65], const float (*sw)[65], int t, int mg, float (&p)[8]) {
+  float d[8], xx = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = 0.f;
+  for (int i = 0; i < PE; ++i) {
+    const float x = sx[t][i];
+    xx += x * x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] += x * sw[mg * 8 + j][i];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = expf(d[j] - 0.5f * xx) / SQRT_M;
+}
+
+// kptv / ksum partials of one (image, split): sum_t v_t kp_t^T and sum_t kp_t over the split's token tiles
+__global__ __launch_bounds__(256) void k_performer_kv(const float* kqv, const float* w, float* part, int T, int S, int tps) {
+  __shared__ float sw[PM][65], sk[PT][65], sv[PT][65], skp[PT][33];
+  const int tid = threadIdx.x, b = blockIdx.x / S, sp = blockIdx.x % S;
+  const int ntile = (T + PT - 1) / PT;
+  const int t = tid & 63, mg = tid >> 6;
+  const float* base = kqv + (int64_t)b * T * 192;
+  load_w(w, sw, tid);
+  float acc[8], ks = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int tile_end = (sp + 1) * tps < ntile ? (sp + 1) * tps : ntile;
+  for (int tile = sp * tps; tile < tile_end; ++tile) {
+    const int t0 = tile * PT;
+    __syncthreads();
+    load_tile_kqv(base, t0, T, sk, tid);
+    load_tile_kqv(base + 128, t0, T, sv, tid);
+    __syncthreads();
+    float p[8];
+    prm8(sk, sw, t, mg, p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) skp[t][mg * 8 + j] = (t0 + t < T) ? p[j] : 0.f;
+    __syncthreads();
+    for (int tt = 0; tt < PT; ++tt) {
+      const float vv = sv[tt][t];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += vv * skp[tt][mg * 8 + j];
+    }
+    if (tid < PM)
+      for (int tt = 0; tt < PT; ++tt) ks += skp[tt][tid];
+  }
+  float* o = part + (int64_t)blockIdx.x * PKV;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[t * PM + mg * 8 + j] = acc[j];
+  if (tid < PM) o[64 * PM + tid] = ks;
+}
+
+__global__ void k_part_reduce(const float* part, float* out, int S) {
+  const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (e >= PKV) return;
+  float t = 0.f;
+  for (int s = 0; s < S; ++s) t += part[((int64_t)b * S + s) * PKV + e];
+  out[(int64_t)b * PKV + e] = t;
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void k_performer_q(const float* kqv, const float* w, const float* kptv, TO* att, int T, int ntile) {
+  __shared__ float sw[PM][65], sq[PT][65], skv[65][33], sqp[PT][33], sden[4][PT];
+  const int tid = threadIdx.x, b = blockIdx.x / ntile, t0 = (blockIdx.x % ntile) * PT;
+  const int t = tid & 63, mg = tid >> 6;
+  load_w(w, sw, tid);
+  load_tile_kqv(kqv + (int64_t)b * T * 192 + 64, t0, T, sq, tid);
+  load_kv(kptv + (int64_t)b * PKV, skv, tid);
+  __syncthreads();
+  float p[8], pd = 0.f;
+  prm8(sq, sw, t, mg, p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sqp[t][mg * 8 + j] = p[j]; pd += p[j] * skv[64][mg * 8 + j]; }
+  sden[mg][t] = pd;
+  __syncthreads();
+  const int n = t;
+  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {
+    float num = 0.f;
+#pragma unroll
+    for (int m = 0; m < PM; ++m) num += sqp[tt][m] * skv[n][m];
+    const float den = ((sden[0][tt] + sden[1][tt]) + (sden[2][tt] + sden[3][tt])) + 1e-8f;
+    if (t0 + tt < T) ElemIO<TO>::store(att + ((int64_t)b * T + t0 + tt) * PE + n, num / den);
+  }
+}
+
+// q side of the backward: dq, and the (image, split) partials of dkptv / dksum
+template <typename TG>
+__global__ __launch_bounds__(256) void k_performer_bwd_q(const float* kqv, const float* w, const float* kptv, const TG* datt, TG* dkqv, float* part,
+                                                         int T, int S, int tps) {
+  __shared__ float sw[PM][65], sq[PT][65], sdy[PT][65], skv[65][33], sqp[PT][33], sden[4][PT], sdden[PT];
+  const int tid = threadIdx.x, b = blockIdx.x / S, sp = blockIdx.x % S;
+  const int ntile = (T + PT - 1) / PT;
+  const int t = tid & 63, mg = tid >> 6;
+  load_w(w, sw, tid);
+  load_kv(kptv + (int64_t)b * PKV, skv, tid);
+  float acc[8], dks = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int tile_end = (sp + 1) * tps < ntile ? (sp + 1) * tps : ntile;
+  for (int tile = sp * tps; tile < tile_end; ++tile) {
+    const int t0 = tile * PT;
+    __syncthreads();
+    load_tile_kqv(kqv + (int64_t)b * T * 192 + 64, t0, T, sq, tid);
+    load_tile_g<TG>(datt + (int64_t)b * T * 64, t0, T, sdy, tid);
+    __syncthreads();
+    {                                                                  // P1: qp and the denominator
+      float p[8], pd = 0.f;
+      prm8(sq, sw, t, mg, p);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float pj = (t0 + t < T) ? p[j] : 0.f; sqp[t][mg * 8 + j] = pj; pd += pj * skv[64][mg * 8 + j]; }
+      sden[mg][t] = pd;
+    }
+    __syncthreads();
+    for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                  // P2: dnum (in place over dy), dden; thread (n = t, 16 tokens)
+      float num = 0.f;
+#pragma unroll
+      for (int m = 0; m < PM; ++m) num += sqp[tt][m] * skv[t][m];
+      const float den = ((sden[0][tt] + sden[1][tt]) + (sden[2][tt] + sden[3][tt])) + 1e-8f;
+      const float dy = sdy[tt][t];
+      const float dot = wave_sum(dy * num);
+      sdy[tt][t] = dy / den;
+      if (t == 0) sdden[tt] = -dot / (den * den);
+    }
+    __syncthreads();
+    for (int tt = 0; tt < PT; ++tt) {                                  // P4: dkptv[n][m] += dnum[tt][n] qp[tt][m]; thread (n = t, 8 features)
+      const float dn = sdy[tt][t];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += dn * sqp[tt][mg * 8 + j];
+    }
+    if (tid < PM)
+      for (int tt = 0; tt < PT; ++tt) dks += sdden[tt] * sqp[tt][tid];
+    __syncthreads();
+    {                                                                  // P3: g = dqp * qp in place over qp; thread (token t, 8 features)
+      float dqp[8];
+      const float dd = sdden[t];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dqp[j] = dd * skv[64][mg * 8 + j];
+      for (int n = 0; n < PE; ++n) {
+        const float dn = sdy[t][n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dqp[j] += dn * skv[n][mg * 8 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sqp[t][mg * 8 + j] *= dqp[j];
+    }
+    __syncthreads();
+    for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                  // P5: dq[tt][i] = sum_m g (w[m][i] - q[tt][i]); thread (i = t, 16 tokens)
+      float a = 0.f, gs = 0.f;
+#pragma unroll
+      for (int m = 0; m < PM; ++m) { const float gm = sqp[tt][m]; a += gm * sw[m][t]; gs += gm; }
+      if (t0 + tt < T) ElemIO<TG>::store(dkqv + ((int64_t)b * T + t0 + tt) * 192 + 64 + t, a - sq[tt][t] * gs);
+    }
+  }
+  float* o = part + (int64_t)blockIdx.x * PKV;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[t * PM + mg * 8 + j] = acc[j];
+  if (tid < PM) o[64 * PM + tid] = dks;
+}
+
+// k / v side of the backward, one 64-token tile per workgroup
+template <typename TG>
+__global__ __launch_bounds__(256) void k_performer_bwd_k(const float* kqv, const float* w, const float* dkptv, const TG* dskip, TG* dkqv, int T, int ntile) {
+  __shared__ float sw[PM][65], sk[PT][65], sv[PT][65], sdk[65][33], skp[PT][33];
+  const int tid = threadIdx.x, b = blockIdx.x / ntile, t0 = (blockIdx.x % ntile) * PT;
+  const int t = tid & 63, mg = tid >> 6;
+  const float* base = kqv + (int64_t)b * T * 192;
+  load_w(w, sw, tid);
+  load_tile_kqv(base, t0, T, sk, tid);
+  load_tile_kqv(base + 128, t0, T, sv, tid);
+  load_kv(dkptv + (int64_t)b * PKV, sdk, tid);
+  __syncthreads();
+  {
+    float p[8];
+    prm8(sk, sw, t, mg, p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) skp[t][mg * 8 + j] = p[j];
+  }
+  __syncthreads();
+  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                    // dv[tt][n] = sum_m kp[tt][m] dkptv[n][m] (+ skip gradient)
+    float a = 0.f;
+#pragma unroll
+    for (int m = 0; m < PM; ++m) a += skp[tt][m] * sdk[t][m];
+    if (t0 + tt < T) {
+      const int64_t r = (int64_t)b * T + t0 + tt;
+      if (dskip) a += ElemIO<TG>::load(dskip + r * 64 + t);
+      ElemIO<TG>::store(dkqv + r * 192 + 128 + t, a);
+    }
+  }
+  __syncthreads();
+  {                                                                    // g = dkp * kp in place; thread (token t, 8 features)
+    float dkp[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dkp[j] = sdk[64][mg * 8 + j];
+    for (int n = 0; n < PE; ++n) {
+      const float vv = sv[t][n];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dkp[j] += vv * sdk[n][mg * 8 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) skp[t][mg * 8 + j] *= dkp[j];
+  }
+  __syncthreads();
+  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                    // dk[tt][i] = sum_m g (w[m][i] - k[tt][i])
+    float a = 0.f, gs = 0.f;
+#pragma unroll
+    for (int m = 0; m < PM; ++m) { const float gm = skp[tt][m]; a += gm * sw[m][t]; gs += gm; }
+    if (t0 + tt < T) ElemIO<TG>::store(dkqv + ((int64_t)b * T + t0 + tt) * 192 + t, a - sk[tt][t] * gs);
+  }
+}
+
+int splits_of(int B, int T) {
+  const int ntile = (T + PT - 1) / PT;
+  int s = 1024 / (B > 0 ? B : 1);
+  if (s < 1) s = 1;
+  if (s > ntile) s = ntile;
+  const int tps = (ntile + s - 1) / s;
+  return (ntile + tps - 1) / tps;
+}
+int check_perf(const uvc_performer_args* p) {
+  if (!p || !p->kqv || !p->w || !p->part || !p->kptv) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_performer: null pointer");
+  if (p->B <= 0 || p->T <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_performer: B, T");
+  if (p->dtype != UVC_F32 && p->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_performer: dtype");
+  return UVC_OK;
+}
+
+}  // namespace
+
+extern "C" int uvc_unfold_bwd_blocks(int32_t rows) { return bwd_grid(rows); }
+
+extern "C" int uvc_unfold_ln_fwd(const uvc_unfold_args* a, void* stream) {
+  UG g;
+  if (int e = fill_geom(a, g)) return e;
+  if (!a->out || (a->gamma && (!a->beta || !a->mean || !a->rstd))) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold_ln_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  int grid = (g.rows + 3) / 4;
+  if (grid > 16384) grid = 16384;
+  const bool f32 = a->out_is_f32 || a->dtype == UVC_F32;
+  const int nv = (g.dim + 63) / 64;
+  if (nv <= 3) { if (f32) k_unfold_ln<float, 3><<<grid, 256, 0, st>>>(g); else k_unfold_ln<bf16_t, 3><<<grid, 256, 0, st>>>(g); }
+  else { if (f32) k_unfold_ln<float, 9><<<grid, 256, 0, st>>>(g); else k_unfold_ln<bf16_t, 9><<<grid, 256, 0, st>>>(g); }
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_unfold_ln_bwd(const uvc_unfold_args* a, void* stream) {
+  UG g;
+  if (int e = fill_geom(a, g)) return e;
+  if (!a->gamma || !a->mean || !a->rstd || !a->dy || !a->partial || !a->dgamma || !a->dbeta) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold_ln_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = bwd_grid(g.rows);
+  const bool f32 = a->dy_is_f32 || a->dtype == UVC_F32;
+  const int nv = (g.dim + 63) / 64;
+  if (nv <= 3) { if (f32) k_unfold_ln_bwd<float, 3><<<grid, 256, 0, st>>>(g); else k_unfold_ln_bwd<bf16_t, 3><<<grid, 256, 0, st>>>(g); }
+  else { if (f32) k_unfold_ln_bwd<float, 9><<<grid, 256, 0, st>>>(g); else k_unfold_ln_bwd<bf16_t, 9><<<grid, 256, 0, st>>>(g); }
+  UVC_CHECK_LAUNCH();
+  k_unfold_bwd_reduce<<<ceil_div(2 * g.dim, 256), 256, 0, st>>>(g.partial, grid, g.dim, a->dgamma, a->dbeta, a->beta_acc);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_fold_tokens(const void* src, int32_t src_is_f32, int32_t dtype, int32_t lds, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                               int32_t k, int32_t s, int32_t p, void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || s <= 0 || p < 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_fold_tokens: arguments");
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  if (Ho <= 0 || Wo <= 0 || lds < C * k * k) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_fold_tokens: geometry");
+  const int64_t total = (int64_t)B * H * W * C;
+  const int grid = (int)((total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_is_f32 || dtype == UVC_F32) k_fold<float><<<grid, 256, 0, st>>>((const float*)src, lds, dst, B, C, H, W, k, s, p, Ho, Wo);
+  else k_fold<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, lds, dst, B, C, H, W, k, s, p, Ho, Wo);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_performer_splits(int32_t B, int32_t T) { return splits_of(B, T); }
+
+extern "C" int uvc_performer_fwd(const uvc_performer_args* p, void* stream) {
+  if (int e = check_perf(p)) return e;
+  if (!p->att) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_performer_fwd: null att");
+  hipStream_t st = (hipStream_t)stream;
+  const int ntile = (p->T + PT - 1) / PT, S = splits_of(p->B, p->T), tps = (ntile + S - 1) / S;
+  k_performer_kv<<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->part, p->T, S, tps);
+  UVC_CHECK_LAUNCH();
+  k_part_reduce<<<dim3(ceil_div(PKV, 256), p->B), 256, 0, st>>>(p->part, p->kptv, S);
+  UVC_CHECK_LAUNCH();
+  if (p->att_is_f32 || p->dtype == UVC_F32) k_performer_q<float><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->kptv, (float*)p->att, p->T, ntile);
+  else k_performer_q<bf16_t><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->kptv, (bf16_t*)p->att, p->T, ntile);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+extern "C" int uvc_performer_bwd(const uvc_performer_args* p, void* stream) {
+  if (int e = check_perf(p)) return e;
+  if (!p->datt || !p->dkqv || !p->dkptv) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_performer_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int ntile = (p->T + PT - 1) / PT, S = splits_of(p->B, p->T), tps = (ntile + S - 1) / S;
+  const bool f32 = p->g_is_f32 || p->dtype == UVC_F32;
+  if (f32) k_performer_bwd_q<float><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->kptv, (const float*)p->datt, (float*)p->dkqv, p->part, p->T, S, tps);
+  else k_performer_bwd_q<bf16_t><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->kptv, (const bf16_t*)p->datt, (bf16_t*)p->dkqv, p->part, p->T, S, tps);
+  UVC_CHECK_LAUNCH();
+  k_part_reduce<<<dim3(ceil_div(PKV, 256), p->B), 256, 0, st>>>(p->part, p->dkptv, S);
+  UVC_CHECK_LAUNCH();
+  if (f32) k_performer_bwd_k<float><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->dkptv, (const float*)p->dskip, (float*)p->dkqv, p->T, ntile);
+  else k_performer_bwd_k<bf16_t><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->dkptv, (const bf16_t*)p->dskip, (bf16_t*)p->dkqv, p->T, ntile);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}

@@ -34,7 +34,7 @@ def _is_f32(t) -> int:
 
 
 def gemm_nt(A, B, C_, *, dtype, epilogue=EPI_NONE, bias=None, R=None, R2=None, aux=None, gate=None, C2=None, alpha=1.0,
-            alpha_ptr=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, force_generic=False):
+            alpha_ptr=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ldr=None, ldaux=None, force_generic=False):
     """C[M,N] = epi(A[M,K] . B[N,K]^T)."""
     _chk(A, B, C_, bias, R, R2, aux, gate, C2, alpha_ptr)
     a = L.uvc_gemm_nt_args()
@@ -47,8 +47,8 @@ def gemm_nt(A, B, C_, *, dtype, epilogue=EPI_NONE, bias=None, R=None, R2=None, a
     a.lda = lda if lda is not None else a.K
     a.ldb = ldb if ldb is not None else a.K
     a.ldc = ldc if ldc is not None else a.N
-    a.ldr = a.ldc
-    a.ldaux = a.ldc
+    a.ldr = ldr if ldr is not None else a.ldc
+    a.ldaux = ldaux if ldaux is not None else a.ldc
     a.dtype, a.a_is_f32, a.c_is_f32, a.epilogue = dtype, _is_f32(A), _is_f32(C_), epilogue
     a.force_generic = int(force_generic)
     L.check(L.lib().uvc_gemm_nt(C.byref(a), L.cur_stream()), "uvc_gemm_nt")
@@ -101,18 +101,18 @@ def attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype):
     L.check(L.lib().uvc_attention_bwd(C.byref(a), L.cur_stream()), "uvc_attention_bwd")
 
 
-def _ln_args(x, gamma, beta, rows, D, dtype, rows_per_group=1, group_stride=None):
+def _ln_args(x, gamma, beta, rows, D, dtype, rows_per_group=1, group_stride=None, eps=1e-6):
     a = L.uvc_ln_args()
     a.x, a.gamma, a.beta = L.ptr(x), L.ptr(gamma), L.ptr(beta)
     a.rows, a.D, a.rows_per_group, a.dtype = rows, D, rows_per_group, dtype
     a.group_stride = group_stride if group_stride is not None else D * rows_per_group
-    a.eps = 1e-6
+    a.eps = eps
     return a
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, dtype, rows_per_group=1, group_stride=None):
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, dtype, rows_per_group=1, group_stride=None, eps=1e-6):
     _chk(x, gamma, beta, y, mean, rstd)
-    a = _ln_args(x, gamma, beta, rows, D, dtype, rows_per_group, group_stride)
+    a = _ln_args(x, gamma, beta, rows, D, dtype, rows_per_group, group_stride, eps)
     a.y, a.mean, a.rstd, a.y_is_f32 = L.ptr(y), L.ptr(mean), L.ptr(rstd), _is_f32(y)
     L.check(L.lib().uvc_layernorm_fwd(C.byref(a), L.cur_stream()), "uvc_layernorm_fwd")
 
@@ -122,9 +122,9 @@ def layernorm_bwd_blocks(rows) -> int:
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, rows, D, dtype, *, add1=None, a1=None, add2=None,
-                  a2=None, dots=None, beta_acc=0.0, rows_per_group=1, group_stride=None):
+                  a2=None, dots=None, beta_acc=0.0, rows_per_group=1, group_stride=None, eps=1e-6):
     _chk(dy, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, add1, a1, add2, a2, dots)
-    a = _ln_args(x, gamma, None, rows, D, dtype, rows_per_group, group_stride)
+    a = _ln_args(x, gamma, None, rows, D, dtype, rows_per_group, group_stride, eps)
     a.mean, a.rstd, a.dy, a.dx = L.ptr(mean), L.ptr(rstd), L.ptr(dy), L.ptr(dx)
     a.add1, a.a1, a.add2, a.a2 = L.ptr(add1), L.ptr(a1), L.ptr(add2), L.ptr(a2)
     a.partial, a.dgamma, a.dbeta, a.dots = L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dots)
@@ -259,3 +259,71 @@ def gate_grad(g, d, dots, dg, Lb, mode, eps, beta_acc=0.0):
     _chk(g, d, dots, dg)
     L.check(L.lib().uvc_gate_grad(L.ptr(g), L.ptr(d), L.ptr(dots), L.ptr(dg), Lb, mode, eps, beta_acc, L.cur_stream()),
             "uvc_gate_grad")
+
+
+# ---- T2T tokens-to-token front end (include/uvc_t2t.h) --------------------------------------------
+def _unfold_args(src, strides, B, Cc, H, W, k, s, p, ldo, dtype):
+    a = L.uvc_unfold_args()
+    a.src = L.ptr(src)
+    a.sb, a.sc, a.sh, a.sw = strides
+    a.B, a.C, a.H, a.W, a.k, a.s, a.p, a.ldo, a.dtype = B, Cc, H, W, k, s, p, ldo, dtype
+    return a
+
+
+def unfold_out_hw(H, W, k, s, p):
+    return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+
+
+def unfold_ln_fwd(src, strides, B, Cc, H, W, k, s, p, out, dtype, *, gamma=None, beta=None, mean=None, rstd=None, eps=1e-5):
+    """out[B*L, ldo] = (LayerNorm of) the soft split rows of `src` (element strides (sb, sc, sh, sw)); ldo = out.shape[1]."""
+    _chk(src, out, gamma, beta, mean, rstd)
+    a = _unfold_args(src, strides, B, Cc, H, W, k, s, p, out.shape[1], dtype)
+    a.out, a.out_is_f32 = L.ptr(out), _is_f32(out)
+    a.gamma, a.beta, a.mean, a.rstd, a.eps = L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), eps
+    L.check(L.lib().uvc_unfold_ln_fwd(C.byref(a), L.cur_stream()), "uvc_unfold_ln_fwd")
+
+
+def unfold_bwd_blocks(rows) -> int:
+    return int(L.lib().uvc_unfold_bwd_blocks(rows))
+
+
+def unfold_ln_bwd(src, strides, B, Cc, H, W, k, s, p, dy, dtype, *, gamma, mean, rstd, partial, dgamma, dbeta, dxu=None, beta_acc=0.0, eps=1e-5):
+    _chk(src, dy, gamma, mean, rstd, partial, dgamma, dbeta, dxu)
+    a = _unfold_args(src, strides, B, Cc, H, W, k, s, p, dy.shape[1], dtype)
+    a.gamma, a.mean, a.rstd, a.eps = L.ptr(gamma), L.ptr(mean), L.ptr(rstd), eps
+    a.dy, a.dy_is_f32, a.dxu, a.partial = L.ptr(dy), _is_f32(dy), L.ptr(dxu), L.ptr(partial)
+    a.dgamma, a.dbeta, a.beta_acc = L.ptr(dgamma), L.ptr(dbeta), beta_acc
+    L.check(L.lib().uvc_unfold_ln_bwd(C.byref(a), L.cur_stream()), "uvc_unfold_ln_bwd")
+
+
+def fold_tokens(src, dst, B, Cc, H, W, k, s, p, dtype, lds=None):
+    """dst[B, H*W, C] float32 = adjoint of the soft split applied to src [B*L, lds]."""
+    _chk(src, dst)
+    L.check(L.lib().uvc_fold_tokens(L.ptr(src), _is_f32(src), dtype, lds if lds is not None else src.shape[1], L.ptr(dst), B, Cc, H, W, k, s, p,
+                                    L.cur_stream()), "uvc_fold_tokens")
+
+
+def performer_splits(B, T) -> int:
+    return int(L.lib().uvc_performer_splits(B, T))
+
+
+def _perf_args(kqv, w, part, kptv, B, T, dtype):
+    a = L.uvc_performer_args()
+    a.kqv, a.w, a.part, a.kptv, a.B, a.T, a.dtype = L.ptr(kqv), L.ptr(w), L.ptr(part), L.ptr(kptv), B, T, dtype
+    return a
+
+
+def performer_fwd(kqv, w, part, kptv, att, B, T, dtype):
+    _chk(kqv, w, part, kptv, att)
+    a = _perf_args(kqv, w, part, kptv, B, T, dtype)
+    a.att, a.att_is_f32 = L.ptr(att), _is_f32(att)
+    L.check(L.lib().uvc_performer_fwd(C.byref(a), L.cur_stream()), "uvc_performer_fwd")
+
+
+def performer_bwd(kqv, w, part, kptv, datt, dkqv, dkptv, B, T, dtype, dskip=None):
+    _chk(kqv, w, part, kptv, datt, dkqv, dkptv, dskip)
+    if dkqv.dtype != datt.dtype or (dskip is not None and dskip.dtype != datt.dtype):
+        raise L.UvcHipError("performer_bwd: datt, dskip and dkqv must share one element type")
+    a = _perf_args(kqv, w, part, kptv, B, T, dtype)
+    a.datt, a.dskip, a.dkqv, a.dkptv, a.g_is_f32 = L.ptr(datt), L.ptr(dskip), L.ptr(dkqv), L.ptr(dkptv), _is_f32(datt)
+    L.check(L.lib().uvc_performer_bwd(C.byref(a), L.cur_stream()), "uvc_performer_bwd")

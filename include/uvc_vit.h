@@ -24,6 +24,8 @@ typedef struct uvc_vit_cfg {
   int32_t img_size, patch_size, in_chans, num_classes, embed_dim, depth, num_heads, hidden;
   int32_t ntok;    /* 1, or 2 with the distillation token (enable_dist) */
   int32_t dtype;   /* UVC_F32 (exact float32 MFMA) or UVC_BF16 */
+  float ln_eps;    /* LayerNorm epsilon; <= 0 selects DeiT's 1e-6 (model_distilled.py:402).  T2T-ViT uses nn.LayerNorm's 1e-5 (t2t_vit.py:111) */
+  int32_t no_qkv_bias;  /* 1: attn.qkv has no bias (T2T blocks, transformer_block.py:49); its slot in the flat buffers is never read or written */
 } uvc_vit_cfg;
 
 /* element offsets into the flat parameter / gradient buffers (every tensor 16-byte aligned) */

@@ -9,7 +9,8 @@
 namespace {
 
 struct Dims {
-  int B, S, P, C, D, L, H, F, NC, ntok, np, N, M, K0, dtype;
+  int B, S, P, C, D, L, H, F, NC, ntok, np, N, M, K0, dtype, qkv_bias;
+  float eps;
   size_t tsz;
 };
 Dims dims_of(const uvc_vit_cfg& c, int B) {
@@ -18,6 +19,8 @@ Dims dims_of(const uvc_vit_cfg& c, int B) {
   d.F = c.hidden; d.NC = c.num_classes; d.ntok = c.ntok; d.np = (c.img_size / c.patch_size) * (c.img_size / c.patch_size);
   d.N = d.np + d.ntok; d.M = B * d.N; d.K0 = c.in_chans * c.patch_size * c.patch_size; d.dtype = c.dtype;
   d.tsz = c.dtype == UVC_F32 ? 4 : 2;
+  d.eps = c.ln_eps > 0.f ? c.ln_eps : 1e-6f;
+  d.qkv_bias = c.no_qkv_bias ? 0 : 1;
   return d;
 }
 
@@ -187,7 +190,7 @@ int csum(const Ctx& c, const void* X, int x_f32, float* out, int M, int N, const
 int ln_fwd(const Ctx& c, const float* x, int64_t pw, int64_t pb, void* y, float* mean, float* rstd, int rows, int rpg, int64_t gs) {
   uvc_ln_args a;
   memset(&a, 0, sizeof(a));
-  a.x = x; a.gamma = c.io->params + pw; a.beta = c.io->params + pb; a.y = y; a.mean = mean; a.rstd = rstd; a.eps = 1e-6f;
+  a.x = x; a.gamma = c.io->params + pw; a.beta = c.io->params + pb; a.y = y; a.mean = mean; a.rstd = rstd; a.eps = c.d.eps;
   a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
   return uvc_layernorm_fwd(&a, c.st);
 }
@@ -207,7 +210,7 @@ int ln_bwd(Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const
   a.defer_reduce = 1;
   uvc_ln_reduce_item& it = c.ln_items[c.n_ln++];
   it.partial = a.partial; it.dgamma = a.dgamma; it.dbeta = a.dbeta; it.dots = dots; it.nblocks = uvc_layernorm_bwd_nblocks(rows); it.reserved = 0;
-  a.eps = 1e-6f; a.beta_acc = c.io->accumulate; a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
+  a.eps = c.d.eps; a.beta_acc = c.io->accumulate; a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
   a.g_lowp = c.d.dtype == UVC_BF16;
   return uvc_layernorm_bwd(&a, c.st);
 }
@@ -381,7 +384,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     const BlockBufs& b = w.blk[l];
     const int64_t* q = o.blk[l];
     TRY(ln_fwd(c, xin, q[0], q[1], b.h1, b.mean1, b.rstd1, d.M, 1, d.D));
-    TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, UVC_EPI_BIAS, P + q[3]));
+    TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, d.qkv_bias ? UVC_EPI_BIAS : UVC_EPI_NONE, d.qkv_bias ? P + q[3] : nullptr));
     TRY(attn(c, b, false, l));
     TRY(nt(c, b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), b.x1, 1, d.M, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xin));
     // Stage-2 compaction: pruned hidden units are skipped (compact weights gathered by the host, uvc_mlp_compact)
@@ -394,7 +397,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
       // no-grad forward (teacher / eval): LayerNorm + fc1 + GELU + fc2 + residual in one kernel, hidden activation in registers
       uvc_mlp_args m;
       m.x = b.x1; m.gamma = P + q[6]; m.beta = P + q[7]; m.w1 = w1; m.b1 = b1;
-      m.w2 = w2; m.b2 = P + q[11]; m.out = xout; m.M = d.M; m.D = d.D; m.F = Fe; m.eps = 1e-6f;
+      m.w2 = w2; m.b2 = P + q[11]; m.out = xout; m.M = d.M; m.D = d.D; m.F = Fe; m.eps = d.eps;
       TRY(uvc_mlp_fused_fwd(&m, c.st));
       xin = xout;
       continue;
@@ -490,7 +493,7 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     TRY(guard_overwrite(c, BUF_DQKV));
     TRY(attn(c, b, true));
     TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));
-    TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], G + q[3], d.M, 3 * d.D, d.D, nullptr, 0, 0, BUF_DQKV));
+    TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], d.qkv_bias ? G + q[3] : nullptr, d.M, 3 * d.D, d.D, nullptr, 0, 0, BUF_DQKV));
     // gA <- dL/dx_l = LN1'(dH) + gB + d0*gA ; dots: <new gA, x_l>, <old gA, x_l>
     TRY(guard_overwrite(c, BUF_GA));
     TRY(ln_bwd(c, w.dH, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0, w.dotsraw + 2 * l, d.M, 1, d.D));

@@ -63,7 +63,7 @@ class FlatGradReducer:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
 
 
-def bucket_plan(off, depth: int, n_extra: int, num_buckets: int = 4):
+def bucket_plan(off, depth: int, n_extra: int, num_buckets: int = 4, n_flat: Optional[int] = None):
     """Backward stage boundaries and the flat-buffer ranges that are final after each of them.
     Stages: 0 = heads + final norm, 1..L = blocks L-1..0, L+1/L+2 = embedding (uvc_vit.h).  The flat
     layout is in forward order, so a bucket is a contiguous [block k .. previous bucket) range."""
@@ -82,7 +82,8 @@ def bucket_plan(off, depth: int, n_extra: int, num_buckets: int = 4):
         hi = lo
         l = lo_blk
     # tail: blocks [0, l) + embedding + the small conditionally-active tensors (+ the dual scalar slot)
-    plan.append((depth + 3, [(0, hi), (off.n_main, off.n_total - off.n_main + n_extra)]))
+    n_flat = off.n_total if n_flat is None else n_flat      # T2T-ViT: the tokens-to-token parameters sit behind the engine's layout
+    plan.append((depth + 3, [(0, hi), (off.n_main, n_flat - off.n_main + n_extra)]))
     return plan
 
 
@@ -102,7 +103,7 @@ class DistributedDataParallel(torch.nn.Module):
             dist.broadcast(module._flat, src=0, group=process_group)       # apex DDP ctor behaviour
             module.mark_weights_changed()
         self.dual_scalar = dual_scalar
-        plan = bucket_plan(module._off, module._cfg.depth, module.N_EXTRA, 1 if delay_allreduce else num_buckets)
+        plan = bucket_plan(module._off, module._cfg.depth, module.N_EXTRA, 1 if delay_allreduce else num_buckets, module.n_flat)
         self.stage_ends = [p[0] for p in plan]
         self.reducer = FlatGradReducer(module._flat_grad, [p[1] for p in plan], process_group)
         object.__setattr__(module, "_ddp", self)      # plain attribute: registering it as a sub-module would create a module cycle
@@ -113,8 +114,8 @@ class DistributedDataParallel(torch.nn.Module):
     # called by the model's backward between stages
     def pack_dual(self):
         if self.dual_scalar is not None:
-            self.module._flat_grad[self.module._off.n_total] = self.dual_scalar.detach()
+            self.module._flat_grad[self.module.n_flat] = self.dual_scalar.detach()
 
     def unpack_dual(self):
         if self.dual_scalar is not None and self.world > 1:
-            self.dual_scalar.data.copy_(self.module._flat_grad[self.module._off.n_total])
+            self.dual_scalar.data.copy_(self.module._flat_grad[self.module.n_flat])

@@ -26,7 +26,7 @@ __all__ = ["DistilledVisionTransformer", "PatchEmbed", "Attention", "Mlp", "Bloc
 
 class uvc_vit_cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("img_size", "patch_size", "in_chans", "num_classes", "embed_dim", "depth",
-                                         "num_heads", "hidden", "ntok", "dtype")]
+                                         "num_heads", "hidden", "ntok", "dtype")] + [("ln_eps", C.c_float), ("no_qkv_bias", C.c_int32)]
 
 
 MAXD = 32
@@ -216,6 +216,7 @@ class DistilledVisionTransformer(nn.Module):
         self._mlp_bufs = None
         self._head_keep = None
         self._skip_grads_clean = False
+        self._front_state = None
         self.exp_source = lambda shape: torch.empty(shape, device=self._flat.device, dtype=torch.float32).exponential_()
         self.to(dev)
 
@@ -234,6 +235,26 @@ class DistilledVisionTransformer(nn.Module):
                 nn.init.ones_(m.weight)
 
     # -- flat storage ---------------------------------------------------------------------------------
+    @property
+    def n_flat(self):
+        """Elements of the flat parameter buffer (the engine's layout; T2T-ViT appends its tokens-to-token parameters)."""
+        return self._off.n_total
+
+    def _extra_live_segments(self):
+        """(offset, count) ranges behind the engine's layout that receive gradients every step (none for DeiT)."""
+        return []
+
+    def _frozen_ranges(self):
+        """(offset, count) ranges the optimiser must never touch (requires_grad False tensors inside the live segments)."""
+        return []
+
+    def _front_end_forward(self, x, B, training):
+        """Hook for a token embedding other than the patch convolution: write pe into the engine workspace and return True."""
+        return False
+
+    def _front_end_backward(self, st):
+        pass
+
     def _slots(self):
         """(parameter, offset) pairs of the canonical flat layout (uvc_vit_layout)."""
         o = self._off
@@ -257,7 +278,7 @@ class DistilledVisionTransformer(nn.Module):
 
     def _flatten(self, device):
         """(Re)build the flat parameter/gradient buffers and point every Parameter at its slice."""
-        n = self._off.n_total
+        n = self.n_flat
         flat = torch.zeros(n, device=device, dtype=torch.float32)
         grad = torch.zeros(n + self.N_EXTRA, device=device, dtype=torch.float32)   # + comm scratch (dual scalar)
         for p, off in self._slots():
@@ -323,7 +344,7 @@ class DistilledVisionTransformer(nn.Module):
         (joint_train.py:169-171 / post_train.py:155-157) is a view at its weight's offset, 1 elsewhere.  Mask buffers
         that were registered or moved after the fact are adopted (copied in and re-pointed) here."""
         if self._flat_mask is None or self._flat_mask.device != self._flat.device:
-            self._flat_mask = torch.ones(self._off.n_total, device=self._flat.device, dtype=torch.float32)
+            self._flat_mask = torch.ones(self.n_flat, device=self._flat.device, dtype=torch.float32)
         base = self._flat_mask.data_ptr()
         off_of = {id(p): off for p, off in self._slots()}
         for _, m in self.named_modules():
@@ -532,12 +553,16 @@ class DistilledVisionTransformer(nn.Module):
                 patch = dict(mode=2, mask=mask, ysoft=ys, psoft=ps, tau=float(tau))
             io.patch_mask = L.ptr(mask)
             io.stage_begin, io.stage_end = 1, 2
+        if self._front_end_forward(x, B, training):
+            if patch is not None:
+                raise NotImplementedError("patch gating with a custom front end")
+            io.stage_begin, io.stage_end = 1, 2
         if gate_d is not None:     # drawn after the patch-gating noise, in the reference's RNG order (:446-485)
             e = self.exp_source((cfg.depth, 2)) if mode in (1, 3) else None
             ops.gate_distrib(self.block_skip_gating.data, e, gate_d, cfg.depth, mode, float(self.eps))
         io.gate_d = L.ptr(gate_d)
         L.check(lib.uvc_vit_forward(C.byref(cfg), C.byref(io), stream), "uvc_vit_forward")
-        self._last = dict(x=x, gate_d=gate_d, patch=patch, B=B, run_block=run_block) if training else None
+        self._last = dict(x=x, gate_d=gate_d, patch=patch, B=B, run_block=run_block, front=self._front_state) if training else None
         self.last_distrib = gate_d
         self.last_patch_mask = patch["mask"] if patch else None
         return logits, logits_dist
@@ -621,10 +646,14 @@ class DistilledVisionTransformer(nn.Module):
         cuts = set(ddp.stage_ends) if ddp else {depth + 3}
         if patch:
             cuts.add(depth + 2)            # after token assembly: d(mask) is known, dpe not yet consumed
+        front = st.get("front")            # custom front end: it consumes dpe instead of the patch-embedding wgrad (stage depth+2)
         begin = 0
         for end in sorted(cuts):
-            io.stage_begin, io.stage_end = begin, end
-            L.check(_bind().uvc_vit_backward(C.byref(self._cfg), C.byref(io), L.cur_stream()), "uvc_vit_backward")
+            io.stage_begin, io.stage_end = begin, (min(end, depth + 2) if front else end)
+            if io.stage_end > io.stage_begin:
+                L.check(_bind().uvc_vit_backward(C.byref(self._cfg), C.byref(io), L.cur_stream()), "uvc_vit_backward")
+            if front and end == depth + 3:
+                self._front_end_backward(st)
             if patch and end == depth + 2:
                 self._patch_backward(st, dmask)
             if ddp and end in ddp.stage_ends:

@@ -45,15 +45,16 @@ def _clip_state(model):
 def _small_tensors(model):
     """(name, parameter, offset) of the conditionally-active tensors."""
     o = model._off
-    out = [("gate", model.block_skip_gating, o.gate), ("gumbel_w", model.gumbel.weight, o.gumbel_w),
-           ("gumbel_b", model.gumbel.bias, o.gumbel_b)]
+    out = [("gate", model.block_skip_gating, o.gate)]
+    if getattr(model, "gumbel", None) is not None:
+        out += [("gumbel_w", model.gumbel.weight, o.gumbel_w), ("gumbel_b", model.gumbel.bias, o.gumbel_b)]
     if model.patch_gating is not None:
         out.append(("patch_gating", model.patch_gating, o.patch_gating))
     return out
 
 
 def _live_segments(model):
-    segs = [(0, model._off.n_main)]
+    segs = [(0, model._off.n_main)] + list(model._extra_live_segments())
     for _, p, off in _small_tensors(model):
         if p.grad is not None:
             segs.append((off, p.numel()))
@@ -78,7 +79,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.model = model
         self.max_grad_norm = max_grad_norm
         dev = model._flat.device
-        n = model._off.n_total
+        n = model.n_flat
         self.exp_avg = torch.zeros(n, device=dev)
         self.exp_avg_sq = torch.zeros(n, device=dev)
         self.steps = {"main": 0}
@@ -89,16 +90,16 @@ class FusedAdamW(torch.optim.Optimizer):
     def _element_flags(self):
         """uint8 flag per element of the flat buffer (or None when every element decays and trains)."""
         m = self.model
-        skipped = tuple(m.skipped_block_ranges())
+        skipped = tuple(m.skipped_block_ranges()) + tuple(m._frozen_ranges())
         if not self.filter_bias_and_bn and not skipped:
             return None
         if self._flags is None or self._flags_key != skipped:
-            fl = torch.full((m._off.n_total,), DECAY, dtype=torch.uint8)
+            fl = torch.full((m.n_flat,), DECAY, dtype=torch.uint8)
             if self.filter_bias_and_bn:
                 skip = m.no_weight_decay() if hasattr(m, "no_weight_decay") else set()
                 off_of = {id(p): off for p, off in m._slots()}
                 for name, p in m.named_parameters():
-                    if p.ndim == 1 or name.endswith(".bias") or name in skip:
+                    if (p.ndim == 1 or name.endswith(".bias") or name in skip) and id(p) in off_of:
                         off = off_of[id(p)]
                         fl[off:off + p.numel()] = NO_DECAY
             for off, k in skipped:
@@ -134,6 +135,9 @@ class FusedAdamW(torch.optim.Optimizer):
         flags = self._element_flags()
         ops.adamw_step(m._flat[:n], m._flat_grad[:n], self.exp_avg[:n], self.exp_avg_sq[:n], st["sq"], step=self.steps["main"],
                        gnorm_out=st["gnorm"], flags=flags[:n] if flags is not None else None, **common)
+        for off, k in m._extra_live_segments():
+            ops.adamw_step(m._flat[off:off + k], m._flat_grad[off:off + k], self.exp_avg[off:off + k], self.exp_avg_sq[off:off + k], st["sq"],
+                           step=self.steps["main"], flags=flags[off:off + k] if flags is not None else None, **common)
         for name, p, off in _small_tensors(m):
             if p.grad is None:
                 continue

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -116,6 +116,8 @@ class Stage1:
     sched_step: int = 0                      # LambdaLR.last_epoch
     lr: float = 0.0                          # optimizer.param_groups[0]['lr']
     global_step: int = 0
+    fwd: Optional[Callable] = None           # model forward with V.forward's signature (None = DeiT; oracle/t2t.py:forward_flags for T2T-ViT)
+    frozen: Tuple[str, ...] = ()             # requires_grad False parameters (T2T: pos_embed, the Performer random features)
 
     def __post_init__(self):
         if self.opt is None:
@@ -138,16 +140,17 @@ def stage1_step(S: Stage1, x: torch.Tensor, y_soft: torch.Tensor, exp_model: Lis
                 e1: torch.Tensor, e2: Optional[torch.Tensor], out: Optional[dict] = None):
     """joint_train.py:395-450 after mixup.  exp_model: Exp(1) draws consumed by the student forward;
     e1/e2: draws of the two resource evaluations inside uvc_optimizer."""
-    for p in S.params.values():
-        p.requires_grad_(True)
+    fwd = S.fwd if S.fwd is not None else V.forward
+    for k, p in S.params.items():
+        p.requires_grad_(k not in S.frozen)
         p.grad = None
     gate_trainable = not S.flags.enable_warmup          # joint_train.py:349,358
     S.params["block_skip_gating"].requires_grad_(bool(gate_trainable))
     rec: dict = {}
-    (o, od), _ = V.forward(S.params, S.cfg, S.flags, x, tau=S.th.patch_tau, ratio=S.th.patch_ratio,
-                           exp_draws=exp_model, record=rec)
+    (o, od), _ = fwd(S.params, S.cfg, S.flags, x, tau=S.th.patch_tau, ratio=S.th.patch_ratio,
+                     exp_draws=exp_model, record=rec)
     with torch.no_grad():
-        tl, _ = V.forward(S.teacher, S.cfg, teacher_flags(), x)
+        tl, _ = fwd(S.teacher, S.cfg, teacher_flags(), x)
     loss = distillation_loss(o, od, y_soft, tl, S.th.distillation_type, S.th.distillation_alpha,
                              S.th.distillation_tau)
     loss.backward()

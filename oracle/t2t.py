@@ -47,6 +47,10 @@ class T2TConfig:
         return int(self.embed_dim * self.mlp_ratio)
 
     @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+    @property
     def m(self) -> int:
         return int(self.token_dim * self.kernel_ratio)         # token_performer.py:27
 
@@ -232,3 +236,26 @@ def forward(sd: Dict[str, torch.Tensor], cfg: T2TConfig, x: torch.Tensor, gate_d
     x = F.layer_norm(x, (cfg.embed_dim,), sd["norm.weight"], sd["norm.bias"], LN_EPS)
     logits = F.linear(x[:, 0], sd["head.weight"], sd["head.bias"])
     return logits, (macs_embed, macs_list)
+
+
+def forward_flags(params: Dict[str, torch.Tensor], cfg: T2TConfig, flags, x: torch.Tensor, tau: float = -1.0, ratio: float = 0.9,
+                  exp_draws: Optional[list] = None, record: Optional[dict] = None):
+    """``forward`` behind the call signature of oracle/vit.py:forward (what oracle/step.py:stage1_step drives): the per-block
+    gate distributions come from oracle/vit.py:block_distrib (model_distilled.py:480-488 == t2t_vit.py:181-185) with one
+    Exp(1) draw [2] per block; ``tau`` / ``ratio`` are accepted and unused (T2T's forward has no patch gating).
+    Training returns ((logits, logits), macs) (t2t_vit.py:205-206), eval (logits, macs).  UNPINNED for the gated case."""
+    from . import vit as V
+    gate_d = None
+    if flags.enable_block_gating:
+        draws = list(exp_draws) if exp_draws is not None else []
+        rows = []
+        for i in range(cfg.depth):
+            e = draws.pop(0) if (flags.use_gumbel == 1 and not flags.enable_warmup) else None
+            rows.append(V.block_distrib(params["block_skip_gating"][i], flags, e))
+        gate_d = torch.stack(rows)
+        if record is not None:
+            record["distribs"] = gate_d.detach()
+    logits, macs = forward(params, cfg, x, gate_d=gate_d)
+    if flags.training:
+        return (logits, logits), macs
+    return logits, macs

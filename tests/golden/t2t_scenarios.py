@@ -29,3 +29,44 @@ def make_input(r):
     m = r["model_cfg"]
     rs = np.random.RandomState(r["seed"] + 1000)
     return rs.standard_normal((r["batch"], 3, m["img_size"], m["img_size"])).astype(np.float32)
+
+
+# Stage-1 steps on T2T-ViT.  The reference cannot run these: oracle (oracle/step.py with oracle/t2t.py's forward)
+# against the HIP path, no reference fixture.
+STAGE1 = {
+    "t2t_micro_train": dict(model="micro", batch=4, steps=3, warmup=0, state="pruned", seed=51, gating_interval=2, warmup_steps=1, weight_gain=3.0),
+    "t2t_micro_warmup": dict(model="micro", batch=4, steps=2, warmup=1, state="zero", seed=52, weight_gain=3.0),
+    "t2t_micro_softl0": dict(model="micro", batch=4, steps=2, warmup=0, state="pruned", seed=53, use_gumbel=0, gating_interval=2, weight_gain=3.0),
+}
+
+
+def stage1_recipe(name):
+    import scenarios as SC
+    r = dict(SC.DEFAULTS)
+    r.update(STAGE1[name])
+    r["name"] = name
+    r["model_cfg"] = dict(MODELS[r["model"]])
+    return r
+
+
+def stage1_inputs(r):
+    m = r["model_cfg"]
+    rs = np.random.RandomState(r["seed"] + 1000)
+    x = rs.standard_normal((r["steps"], r["batch"], 3, m["img_size"], m["img_size"])).astype(np.float32)
+    z = 2.0 * rs.standard_normal((r["steps"], r["batch"], m["num_classes"]))
+    e = np.exp(z - z.max(-1, keepdims=True))
+    y = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    return x, y
+
+
+def stage1_draws(r, depth):
+    """Exp(1) draws per step: `depth` block-gate draws [2] for the student forward, then e1 / e2 [depth, 2] of the two resource
+    evaluations inside uvc_optimizer (SURVEY 8c note 3)."""
+    rs = np.random.RandomState(r["seed"] + 2000)
+    out = []
+    for _ in range(r["steps"]):
+        md = [rs.exponential(size=2).astype(np.float32) for _ in range(depth)]
+        e1 = rs.exponential(size=(depth, 2)).astype(np.float32)
+        e2 = rs.exponential(size=(depth, 2)).astype(np.float32)
+        out.append((md, e1, e2))
+    return out

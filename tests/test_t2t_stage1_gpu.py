@@ -1,0 +1,161 @@
+"""GPU: Stage-1 UVC steps on T2T-ViT (BASELINE config 5's model family at micro size) -- the product's Stage1Trainer with
+the HIP T2T_ViT against the oracle step (oracle/step.py) driven with oracle/t2t.py's forward on CPU, same weights, inputs
+and Exp(1) draws.  The reference cannot run this path, so the parity here is to the oracle's restatement of
+the lines as written (gated T2T forward UNPINNED); the ungated forward underneath is pinned by test_t2t_model_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+import scenarios as SC
+import t2t_scenarios as TS
+from helpers import train_hyper, uvc_hyper, student_flags
+from oracle import step as OS
+from oracle import t2t as OT
+from oracle import uvc as OU
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol, atol, what):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b); tol = atol + rtol * np.abs(b)
+    assert np.all(err <= tol), f"{what}: max err {err.max():.3e} vs tol {tol.flat[err.argmax()]:.3e} (ref {b.flat[err.argmax()]:.4e})"
+
+
+def build(name, precision):
+    from uvc_amd.stage1 import Stage1Trainer, default_args
+    from uvc_amd.uvc_utils import prune_w_mask
+    r = TS.stage1_recipe(name)
+    m = r["model_cfg"]
+    cfg = OT.T2TConfig(**m)
+    params = OT.init_params_numpy(cfg, r["seed"], weight_gain=r["weight_gain"])
+    teacher = OT.init_params_numpy(cfg, r["seed"] + 500, weight_gain=r["weight_gain"])
+    # ---- oracle
+    with torch.no_grad():
+        _, (embed, macs) = OT.forward(params, cfg, torch.ones(1, 3, cfg.img_size, cfg.img_size))
+    st = OU.UvcState.create(cfg.depth, cfg.num_heads, cfg.head_dim, cfg.hidden, embed, macs, eps=r["eps"])
+    s0, r0, y0, p0, z0 = SC.initial_state(r, cfg.depth, cfg.num_heads, cfg.head_dim, cfg.hidden)
+    st.s, st.r = torch.from_numpy(s0.copy()), torch.from_numpy(r0.copy())
+    st.y, st.p, st.z = torch.from_numpy(y0.copy()), torch.from_numpy(p0.copy()), torch.tensor(float(z0))
+    frozen = ("pos_embed", "tokens_to_token.attention1.w", "tokens_to_token.attention2.w") + \
+        tuple(f"blocks.{i}.{k}" for i in range(cfg.depth) for k in ("attn_skip_gating", "mlp_skip_gating"))
+    S = OS.Stage1(cfg=cfg, flags=student_flags(r), params={k: v.clone() for k, v in params.items()}, teacher=teacher, st=st, hp=uvc_hyper(r),
+                  th=train_hyper(r), fwd=OT.forward_flags, frozen=frozen)
+    if r["warmup"]:
+        S.lr = r["warmup_lr"]
+    # ---- product
+    a = default_args(
+        model_type="t2t_scenario", model_cfg=dict(embed_dim=m["embed_dim"], depth=m["depth"], num_heads=m["num_heads"], mlp_ratio=m["mlp_ratio"]),
+        img_size=m["img_size"], num_classes=m["num_classes"], enable_deit=0, precision=precision, learning_rate=r["learning_rate"],
+        weight_decay=r["weight_decay"], max_grad_norm=r["max_grad_norm"], warmup_steps=r["warmup_steps"], steps_per_epoch=r["t_total"], num_epochs=1,
+        warmup_lr=r["warmup_lr"], distillation_alpha=r["distillation_alpha"], distillation_tau=r["distillation_tau"], enable_patch_gating=0,
+        patch_ratio=r["patch_ratio"], budget=r["budget"], slr=r["slr"], rlr=r["rlr"], glr=r["glr"], ylr=r["ylr"], plr=r["plr"],
+        zlr_schedule_list=str(int(r["zlr"])), sl2wd=r["sl2wd"], z_grad_clip=r["z_grad_clip"], gating_interval=r["gating_interval"],
+        gating_weight=r["gating_weight"], use_gumbel=r["use_gumbel"], enable_block_gating=r["enable_block_gating"], eps=r["eps"],
+        eps_decay=r["eps_decay"], enable_warmup=r["warmup"], warmup_epochs=1 if r["warmup"] else 0)
+    tr = Stage1Trainer(a, student_state=params, teacher_state=teacher)
+    mm = tr.minimax
+    mm.s.data.copy_(torch.from_numpy(s0)); mm.r.data.copy_(torch.from_numpy(r0))
+    mm.y.data.copy_(torch.from_numpy(y0)); mm.p.data.copy_(torch.from_numpy(p0)); mm.z.data.fill_(float(z0))
+    tr.gating_grad_list = []
+    if r["warmup"]:
+        tr.model.enable_warmup = 1
+        tr.model.block_skip_gating.requires_grad = False
+        for g in tr.optimizer.param_groups:
+            g["lr"] = r["warmup_lr"]
+    else:
+        tr.model.enable_warmup = 0
+        tr.model.block_skip_gating.requires_grad = True
+    prune_w_mask(mm, tr.optimizer)
+    return r, cfg, S, tr
+
+
+def run(name, precision):
+    r, cfg, S, tr = build(name, precision)
+    f32 = precision == "fp32"
+    rt = 1e-3 if f32 else 3e-2
+    x_all, y_all = TS.stage1_inputs(r)
+    draws = TS.stage1_draws(r, cfg.depth)
+    gum = r["enable_block_gating"] and r["use_gumbel"]
+    for step in range(r["steps"]):
+        md, e1, e2 = draws[step]
+        md_t = [torch.from_numpy(d) for d in md] if (gum and not r["warmup"]) else []
+        e1_t = torch.from_numpy(e1) if gum else None
+        e2_t = torch.from_numpy(e2) if (gum and not r["warmup"]) else None
+        x, y = torch.from_numpy(x_all[step]), torch.from_numpy(y_all[step])
+        ref = {}
+        OS.stage1_step(S, x, y, list(md_t), e1_t, e2_t, out=ref)
+        if md_t:
+            gd = torch.stack(md_t).cuda()
+            tr.model.exp_source = lambda shape, t=gd: t
+        q = [t.cuda() for t in (e1_t, e2_t) if t is not None]
+        tr.minimax.exp_source = lambda shape, q=q: q.pop(0)
+        out = tr.step(x.cuda(), y.cuda(), zero_grad=False)
+        pre = f"step{step} "
+        close(float(out["loss"]), float(ref["loss"]), rt, 1e-6, pre + "loss")
+        close(out["outputs"][0].detach().cpu().numpy(), ref["logits"].numpy(), rt, 3e-4 if f32 else 5e-2, pre + "logits")
+        close(float(out["gnorm"]), float(ref["grad_norm"]), rt if f32 else 5e-2, 0, pre + "grad_norm")
+        close(float(out["cur"]), float(ref["cur_resource"]), 1e-4, 0, pre + "cur_resource")
+        stt = 1e-3 if f32 else 2e-2
+        close(out["s"].numpy(), S.st.s.numpy(), stt, 1e-6, pre + "s")
+        close(out["r"].numpy(), S.st.r.numpy(), stt, 1e-6, pre + "r")
+        close(tr.minimax.y.data.cpu().numpy(), S.st.y.numpy(), stt, 1e-7, pre + "y")
+        close(tr.minimax.p.data.cpu().numpy(), S.st.p.numpy(), stt, 1e-7, pre + "p")
+        close(float(tr.minimax.z), float(S.st.z), 1e-4, 0, pre + "z")
+        close(out["g"].numpy(), S.params["block_skip_gating"].detach().numpy(), stt, 1e-6, pre + "gating")
+        named = dict(tr.model.named_parameters())
+        # the oracle's clip scaled its gradients in place; the product arms the clip and applies it inside the fused AdamW
+        coef = min(1.0, r["max_grad_norm"] / (float(out["gnorm"]) + 1e-6))
+        for k, gref in ref["grads"].items():
+            got = named[k].grad
+            if gref is None:
+                assert got is None, k
+                continue
+            assert got is not None, k
+            if k == "block_skip_gating":
+                continue
+            sc = float(gref.abs().max()) + 1e-12
+            err = float((got.cpu() * coef - gref).abs().max()) / sc
+            assert err < (3e-3 if f32 else 8e-2), (pre, k, err)
+        for k, v in S.params.items():                       # weights after clip + AdamW + prox
+            a_, b_ = float(named[k].data.double().abs().sum()), float(v.detach().double().abs().sum())
+            assert abs(a_ - b_) <= (1e-4 if f32 else 2e-3) * abs(b_) + 1e-6, (pre, k, a_, b_)
+        tr.optimizer.zero_grad()
+    return r, cfg, S, tr
+
+
+@pytest.mark.parametrize("name", list(TS.STAGE1))
+def test_t2t_stage1_fp32_matches_oracle(name):
+    run(name, "fp32")
+
+
+@pytest.mark.parametrize("name", ["t2t_micro_train"])
+def test_t2t_stage1_bf16_matches_oracle(name):
+    run(name, "bf16")
+
+
+def test_t2t_stage1_masks_bit_exact_vs_oracle():
+    """Mask index sets after the steps: bit-exact with the oracle's (least-k on the same scores)."""
+    from uvc_amd.uvc_utils import prune_w_mask
+    r, cfg, S, tr = run("t2t_micro_train", "fp32")
+    prune_w_mask(tr.minimax, tr.optimizer)
+    masks = OU.prune_masks(S.st, S.w1(), S.w3())
+    for l in range(cfg.depth):
+        assert torch.equal(tr.uvc_layers["W1"][l].mask[0].cpu().bool(), masks[l][3])
+        assert torch.equal(tr.uvc_layers["W3"][l].mask[0].cpu().bool(), masks[l][4])
+        assert torch.equal(tr.uvc_layers["W2"][l].mask[:, 0].cpu().bool(), masks[l][4])
+
+
+def test_t2t_14_stage1_step_runs():
+    """BASELINE config 5's model: one post-warm-up Stage-1 step of t2t_vit_14 at batch 4 (bf16)."""
+    from uvc_amd.stage1 import Stage1Trainer, default_args
+    a = default_args(model_type="t2t_vit_14", precision="bf16", train_batch_size=4)
+    tr = Stage1Trainer(a)
+    tr.begin_epoch(a.warmup_epochs + 1)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(4, 3, 224, 224, device="cuda", generator=g)
+    y = torch.softmax(torch.randn(4, 1000, device="cuda", generator=g), -1)
+    out = tr.step(x, y)
+    assert np.isfinite(float(out["loss"])) and np.isfinite(float(out["gnorm"])) and 0 < float(out["cur"]) <= 1.0 + 1e-6
+    assert abs(float(tr.flops_list[0]) - 256647680) < 1 and tr.flops_list[1][0] == [87146496, 14902656, 14902656, 29048832, 87146496, 87146496]

@@ -28,6 +28,10 @@ CONFIGS = {
 }
 
 
+# T2TViT/models/t2t_vit.py:244-249 (models/configs.py:159-165); BASELINE config 5
+T2T_CONFIGS = {"t2t_vit_14": dict(embed_dim=384, depth=14, num_heads=6, mlp_ratio=3.0)}
+
+
 def default_args(**over) -> Namespace:
     """The argparse defaults of joint_train.py:684-879 overlaid with the README command
     (run_uvc_train.sh:4-38); keyword arguments override."""
@@ -49,22 +53,40 @@ class Stage1Trainer:
         if not args.enable_pruning:
             raise TypeError("enable_pruning=0 raises in the reference (uvc_optimizer_gating signature, SURVEY.md Q7)")
         self.args = args
-        cfg = dict(CONFIGS[args.model_type]) if args.model_type in CONFIGS else dict(args.model_cfg)
+        t2t = "t2t" in args.model_type                                      # joint_train.py:143-145
+        if t2t:
+            cfg = dict(T2T_CONFIGS[args.model_type]) if args.model_type in T2T_CONFIGS else dict(args.model_cfg)
+        else:
+            cfg = dict(CONFIGS[args.model_type]) if args.model_type in CONFIGS else dict(args.model_cfg)
         args.head_size = cfg["embed_dim"] // cfg["num_heads"]              # joint_train.py:883-885
         args.num_heads = cfg["num_heads"]
         args.budget = float(args.budget)
-        kw = dict(patch_size=cfg["patch_size"], embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"],
-                  mlp_ratio=cfg.get("mlp_ratio", 4), qkv_bias=True, drop_rate=0, img_size=args.img_size,
-                  num_classes=args.num_classes, precision=args.precision, device=device)
-        model = DistilledVisionTransformer(enable_dist=args.enable_deit, gumbel_hard=False,
-                                           enable_patch_gating=args.enable_patch_gating, **kw)      # :135-140
+        if t2t:
+            # The reference builds `t2t_vit_14()` with default flags and then calls it as model(x, tau, ratio), which raises
+            # (SURVEY Q8).  Defined here: the same model with DeiT's gate flags (block gating as written at t2t_vit.py:181-189).
+            from .t2t_vit import T2T_ViT
+            if args.enable_deit or args.enable_patch_gating:
+                raise NotImplementedError("T2T-ViT has no distillation token and its forward has no patch gating (t2t_vit.py:168-200)")
+            kw = dict(embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"], mlp_ratio=cfg.get("mlp_ratio", 3.0),
+                      img_size=args.img_size, num_classes=args.num_classes, precision=args.precision, device=device)
+            model = T2T_ViT(gumbel_hard=False, **kw)
+        else:
+            kw = dict(patch_size=cfg["patch_size"], embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"],
+                      mlp_ratio=cfg.get("mlp_ratio", 4), qkv_bias=True, drop_rate=0, img_size=args.img_size,
+                      num_classes=args.num_classes, precision=args.precision, device=device)
+            model = DistilledVisionTransformer(enable_dist=args.enable_deit, gumbel_hard=False,
+                                               enable_patch_gating=args.enable_patch_gating, **kw)      # :135-140
         if student_state is not None:
             model.load_state_dict(student_state, strict=False)
         register_masks(model)                                                                       # :169-171
         args.total_param = count_mask(model)
         teacher = None
         if args.distillation_type != "none":                                                        # :948-981
-            teacher = DistilledVisionTransformer(enable_dist=args.enable_deit, **kw)
+            if t2t:
+                from .t2t_vit import T2T_ViT
+                teacher = T2T_ViT(**kw)                                                             # :963-964
+            else:
+                teacher = DistilledVisionTransformer(enable_dist=args.enable_deit, **kw)
             src = teacher_state if teacher_state is not None else {k: v for k, v in model.state_dict().items()
                                                                    if not k.endswith(".mask") and k != "patch_gating"}
             teacher.load_state_dict(src, strict=False)

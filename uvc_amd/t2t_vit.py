@@ -431,7 +431,8 @@ class T2T_ViT(DistilledVisionTransformer):
         blk = [B * 3 * D * N * D, N * B * H * N * 64, N * B * H * N * 64, B * N * D * D, Fh * B * N * D, D * B * N * Fh]
         return embed, [list(blk) for _ in range(c.depth)]
 
-    def forward(self, x):
+    def forward(self, x, tau=-1, number=0.9):
+        """``tau`` / ``number`` are what joint_train.py:410,1012 pass; T2T's forward_features has no patch gating, they are ignored."""
         if self.enable_jumping:
             raise NotImplementedError("enable_jumping is off on the UVC hot path")
         macs = self.macs(x.shape[0])

@@ -24,7 +24,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 # algorithmic FLOPs per image per step = 2*(3E + 4*L*Bk + 4*C)
-GFLOP_PER_IMG = {"deit_tiny_patch16_224": 9.972, "deit_small_patch16_224": 36.675, "deit_base_patch16_224": 140.28}
+GFLOP_PER_IMG = {"deit_tiny_patch16_224": 9.972, "deit_small_patch16_224": 36.675, "deit_base_patch16_224": 140.28,
+                 "t2t_vit_14": 37.42}      # T2T: 2*(3E + 4*L*Bk + 4*C) with E = 256,647,680; the tokens-to-token dgrad (<= 0.51) not counted
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -130,7 +131,8 @@ def kernel_roofline(tr, args, iters=30):
     # r1i_pmc_hbm_traffic_kbench.csv); only valid for the profiled configuration
     traffic = 352572549 if (args.precision == "bf16" and args.batch == 512 and args.model_type == "deit_tiny_patch16_224") else None
     # intensity 2*M*D*F / bytes = 85 flop/B << the ~400 flop/B ridge: this kernel's roofline is HBM
-    return {"bound": "hbm", "kernel": "k_gemm_ws<bf16,bf16,EPI_BIAS_GELU_GRAD,6> (mlp.fc1 + bias + GELU and GELU', M=%d K=%d N=%d)" % (M, D, F),
+    kname = "k_gemm_ws<bf16,bf16,EPI_BIAS_GELU_GRAD,6>" if D == 192 else "uvc_gemm_nt"
+    return {"bound": "hbm", "kernel": kname + " (mlp.fc1 + bias + GELU and GELU', M=%d K=%d N=%d)" % (M, D, F),
             "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
             "traffic": traffic, "algorithmic_bytes": bytes_alg, "launch_ms": round(ms, 4),
             "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / mfma_peak, 4)}

@@ -201,14 +201,22 @@ __global__ __launch_bounds__(256) void k_ln_fwd_v(uvc_ln_args a) {
 }
 
 // TG: element type of the gradient stream (dx, add1, add2): float32, or bf16 when uvc_ln_args.g_lowp is set.
-template <typename TDY, typename TG, int NV4>
+// LPR lanes share a row (D = 4 * LPR * NV4): 16 for D <= 192, 32 for 384, 64 for 768, so that NV4 stays <= 3 and the two
+// row register sets fit (with 16 lanes per row D = 384 took all 256 VGPRs and D = 768 spilled ~750 registers to scratch).
+template <int LPR> __device__ __forceinline__ float sum_lpr(float v) {
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename TDY, typename TG, int NV4, int LPR>
 __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
-  __shared__ float red[4][2 * 64 * NV4 + 2];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane & 15, rg = lane >> 4;
+  constexpr int DD = 4 * LPR * NV4, RPW = 64 / LPR;        // row length; rows a wave handles at a time
+  __shared__ float red[4][2 * DD + 2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane & (LPR - 1), rg = lane / LPR;
   f32x4 gam[NV4], dgam[NV4], dbet[NV4];
 #pragma unroll
   for (int i = 0; i < NV4; ++i) {
-    gam[i] = Ld4<float>::ld(a.gamma + (sub + 16 * i) * 4);
+    gam[i] = Ld4<float>::ld(a.gamma + (sub + LPR * i) * 4);
     dgam[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbet[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float a1 = a.a1 ? *a.a1 : 1.f, a2 = a.a2 ? *a.a2 : 1.f;
@@ -231,10 +239,10 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
-      R.ad1[i] = (R.ok && add1) ? Ld4<TG>::ld(add1 + R.off + (sub + 16 * i) * 4) : z;
-      R.ad2[i] = (R.ok && add2) ? Ld4<TG>::ld(add2 + R.off + (sub + 16 * i) * 4) : z;
-      R.dv[i] = R.ok ? Ld4<TDY>::ld(dy + (sub + 16 * i) * 4) : z;
-      R.xv[i] = R.ok ? Ld4<float>::ld(x + (sub + 16 * i) * 4) : z;
+      R.ad1[i] = (R.ok && add1) ? Ld4<TG>::ld(add1 + R.off + (sub + LPR * i) * 4) : z;
+      R.ad2[i] = (R.ok && add2) ? Ld4<TG>::ld(add2 + R.off + (sub + LPR * i) * 4) : z;
+      R.dv[i] = R.ok ? Ld4<TDY>::ld(dy + (sub + LPR * i) * 4) : z;
+      R.xv[i] = R.ok ? Ld4<float>::ld(x + (sub + LPR * i) * 4) : z;
     }
   };
   auto process = [&](const Row& R) {
@@ -251,13 +259,13 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
         c1 += gy[i][e];
         c2 += gy[i][e] * xh;
       }
-    c1 = sum16(c1) * invD;
-    c2 = sum16(c2) * invD;
+    c1 = sum_lpr<LPR>(c1) * invD;
+    c2 = sum_lpr<LPR>(c2) * invD;
     if (R.ok) {
       TG* dx = reinterpret_cast<TG*>(a.dx) + R.off;
 #pragma unroll
       for (int i = 0; i < NV4; ++i) {
-        const int c = (sub + 16 * i) * 4;
+        const int c = (sub + LPR * i) * 4;
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = R.rstd * (gy[i][e] - c1 - ((R.xv[i][e] - R.mean) * R.rstd) * c2);
@@ -274,13 +282,13 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
     }
   };
   Row Ra, Rb;
-  int rb = r0 + w * 4;
+  int rb = r0 + w * RPW;
   load_row(Ra, rb);
-  for (; rb < r1; rb += 32) {
-    load_row(Rb, rb + 16);
+  for (; rb < r1; rb += 8 * RPW) {
+    load_row(Rb, rb + 4 * RPW);
     process(Ra);
-    if (rb + 16 >= r1) break;
-    load_row(Ra, rb + 32);
+    if (rb + 4 * RPW >= r1) break;
+    load_row(Ra, rb + 8 * RPW);
     process(Rb);
   }
   // reduce the 4 row groups of the wave, then the 4 waves (fixed order)
@@ -289,15 +297,15 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float g = dgam[i][e], b = dbet[i][e];
-      g += __shfl_xor(g, 16, 64); g += __shfl_xor(g, 32, 64);
-      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-      if (rg == 0) { red[w][(sub + 16 * i) * 4 + e] = g; red[w][64 * NV4 + (sub + 16 * i) * 4 + e] = b; }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { g += __shfl_xor(g, o, 64); b += __shfl_xor(b, o, 64); }
+      if (rg == 0) { red[w][(sub + LPR * i) * 4 + e] = g; red[w][DD + (sub + LPR * i) * 4 + e] = b; }
     }
   dotA = wave_sum(dotA); dotB = wave_sum(dotB);
-  if (lane == 0) { red[w][2 * 64 * NV4] = dotA; red[w][2 * 64 * NV4 + 1] = dotB; }
+  if (lane == 0) { red[w][2 * DD] = dotA; red[w][2 * DD + 1] = dotB; }
   __syncthreads();
   float* P = a.partial + (size_t)blockIdx.x * (2 * a.D + 2);
-  for (int c = threadIdx.x; c < 2 * 64 * NV4 + 2; c += 256) P[c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+  for (int c = threadIdx.x; c < 2 * DD + 2; c += 256) P[c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
 // two-stage reduction of the per-block partials: [nblocks, W] -> [RED_S, W] -> [W]
@@ -382,22 +390,13 @@ template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
   const int grid = ceil_div(a.rows, LN_ROWS_PER_BLOCK);
   const int nv = ceil_div(a.D, 64);
   bool vec = a.D % 64 == 0 && (a.group_stride % 4) == 0;
-  if (vec && a.g_lowp) {
-    switch (a.D / 64) {
-      case 2: k_ln_bwd_v<T, bf16_t, 2><<<grid, 256, 0, st>>>(a); break;
-      case 3: k_ln_bwd_v<T, bf16_t, 3><<<grid, 256, 0, st>>>(a); break;
-      case 6: k_ln_bwd_v<T, bf16_t, 6><<<grid, 256, 0, st>>>(a); break;
-      case 12: k_ln_bwd_v<T, bf16_t, 12><<<grid, 256, 0, st>>>(a); break;
+  if (vec) {
+#define LNB_CASE(DV, NV4, LPR) case DV: if (a.g_lowp) k_ln_bwd_v<T, bf16_t, NV4, LPR><<<grid, 256, 0, st>>>(a); else k_ln_bwd_v<T, float, NV4, LPR><<<grid, 256, 0, st>>>(a); break;
+    switch (a.D) {
+      LNB_CASE(128, 2, 16) LNB_CASE(192, 3, 16) LNB_CASE(256, 2, 32) LNB_CASE(384, 3, 32) LNB_CASE(512, 2, 64) LNB_CASE(768, 3, 64)
       default: vec = false;
     }
-  } else if (vec) {
-    switch (a.D / 64) {
-      case 2: k_ln_bwd_v<T, float, 2><<<grid, 256, 0, st>>>(a); break;
-      case 3: k_ln_bwd_v<T, float, 3><<<grid, 256, 0, st>>>(a); break;
-      case 6: k_ln_bwd_v<T, float, 6><<<grid, 256, 0, st>>>(a); break;
-      case 12: k_ln_bwd_v<T, float, 12><<<grid, 256, 0, st>>>(a); break;
-      default: vec = false;
-    }
+#undef LNB_CASE
   }
   if (!vec && a.g_lowp) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "layernorm_bwd: a bf16 gradient stream needs D % 64 == 0");
   if (!vec) {

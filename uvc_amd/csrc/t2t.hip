@@ -154,13 +154,19 @@ __global__ __launch_bounds__(256) void k_unfold_ln_bwd(UG g) {
   (void)red;
 }
 
-__global__ void k_unfold_bwd_reduce(const float* partial, int nblk, int dim, float* dgamma, float* dbeta, float beta_acc) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * dim) return;
+__global__ __launch_bounds__(256) void k_unfold_bwd_reduce(const float* partial, int nblk, int dim, float* dgamma, float* dbeta, float beta_acc) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * 2 * dim + c];
-  float* o = c < dim ? dgamma + c : dbeta + (c - dim);
-  *o = (beta_acc != 0.f ? beta_acc * *o : 0.f) + t;
+  if (c < 2 * dim)
+    for (int b = q; b < nblk; b += 4) t += partial[(int64_t)b * 2 * dim + c];
+  red[q][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (q == 0 && c < 2 * dim) {
+    t = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    float* o = c < dim ? dgamma + c : dbeta + (c - dim);
+    *o = (beta_acc != 0.f ? beta_acc * *o : 0.f) + t;
+  }
 }
 
 template <typename TS>
@@ -203,7 +209,7 @@ int fill_geom(const uvc_unfold_args* a, UG& g) {
   if (g.dim > 576 || g.ldo < g.dim || g.ldo > ((g.dim + 63) / 64) * 64) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_unfold: need C*k*k <= 576 and dim <= ldo <= roundup(dim, 64)");
   return UVC_OK;
 }
-int bwd_grid(int rows) { const int n = (rows + 3) / 4; return n < 1024 ? n : 1024; }
+int bwd_grid(int rows) { const int n = (rows + 3) / 4; return n < 512 ? n : 512; }
 
 // ================================================================================================
 //                                  Performer linear attention
@@ -493,7 +499,7 @@ extern "C" int uvc_unfold_ln_bwd(const uvc_unfold_args* a, void* stream) {
   if (nv <= 3) { if (f32) k_unfold_ln_bwd<float, 3><<<grid, 256, 0, st>>>(g); else k_unfold_ln_bwd<bf16_t, 3><<<grid, 256, 0, st>>>(g); }
   else { if (f32) k_unfold_ln_bwd<float, 9><<<grid, 256, 0, st>>>(g); else k_unfold_ln_bwd<bf16_t, 9><<<grid, 256, 0, st>>>(g); }
   UVC_CHECK_LAUNCH();
-  k_unfold_bwd_reduce<<<ceil_div(2 * g.dim, 256), 256, 0, st>>>(g.partial, grid, g.dim, a->dgamma, a->dbeta, a->beta_acc);
+  k_unfold_bwd_reduce<<<ceil_div(2 * g.dim, 64), 256, 0, st>>>(g.partial, grid, g.dim, a->dgamma, a->dbeta, a->beta_acc);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

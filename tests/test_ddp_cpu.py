@@ -20,15 +20,19 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, depth, nb, out):
+def _worker(rank, world, port, depth, nb, out, front=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from uvc_amd.ddp import FlatGradReducer, bucket_plan
     off = _Off(depth, per_block=1000, embed=300, head=500, small=40)
     n_extra = 4
-    plan = bucket_plan(off, depth, n_extra, nb)
-    # coverage: every index of [0, n_total + n_extra) in exactly one bucket
+    # front > 0: a model whose flat buffer carries extra parameters behind the engine's layout (T2T-ViT's tokens-to-token
+    # module, uvc_amd/t2t_vit.py); they and the dual-scalar slot behind them ride in the tail bucket
+    n_flat = off.n_total + front
+    plan = bucket_plan(off, depth, n_extra, nb, n_flat)
+    off.n_total = n_flat                          # the rest of the check addresses the whole buffer
+    # coverage: every index of [0, n_flat + n_extra) in exactly one bucket
     cover = torch.zeros(off.n_total + n_extra, dtype=torch.int32)
     for _, ranges in plan:
         for o, n in ranges:
@@ -59,3 +63,11 @@ def test_bucketed_mean_allreduce_gloo_world2():
         out = mgr.dict()
         mp.spawn(_worker, args=(2, port, depth, nb, out), nprocs=2, join=True)
         assert out[0] and out[1], (depth, nb)
+
+
+def test_bucketed_allreduce_with_front_end_segment_gloo_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, 14, 4, out, 7777), nprocs=2, join=True)
+    assert out[0] and out[1]

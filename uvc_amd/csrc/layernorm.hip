@@ -3,13 +3,20 @@
 // UVC/models/model_distilled.py:199,204,288 (eps from joint_train.py:138), biased variance.
 // Algorithmic bytes/row: fwd 4D read + sizeof(T)*D write; bwd (4 + sizeof(Tdy))*D read (+4D per
 // addend) + 4D write.
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 #include "../../include/uvc_kernels.h"
 
 namespace {
 
-constexpr int LN_ROWS_PER_BLOCK = 128;   // backward: rows per block (32 per wave); smaller blocks only inflate the partial reduction
+// backward: rows per workgroup.  128 keeps the partial reduction small when there are rows to spare; with fewer rows the
+// grid would not fill 256 CUs at one workgroup per CU (the kernels take ~200 VGPRs), so the blocks shrink.
+static int ln_rows_per_block(int rows) {
+  static const int forced = [] { const char* v = getenv("UVC_LN_RPB"); return v ? atoi(v) : 0; }();
+  if (forced == 32 || forced == 64 || forced == 128) return forced;
+  return rows >= 96 * 1024 ? 128 : rows >= 48 * 1024 ? 64 : 32;     // measured: T2T-14 batch 128 (25 k rows) +4 % step rate at 32, DeiT-Small batch 256 +1 % at 64
+}
 
 __device__ __forceinline__ size_t row_off(int r, int rpg, int64_t gs, int D) {
   return (size_t)(r / rpg) * gs + (size_t)(r % rpg) * D;
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(uvc_ln_args a) {
 }
 
 template <typename TDY, int NV>
-__global__ __launch_bounds__(256) void k_ln_bwd(uvc_ln_args a) {
+__global__ __launch_bounds__(256) void k_ln_bwd(uvc_ln_args a, int rpb) {
   __shared__ float red[4][2 * 64 * NV + 2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float gam[NV], dgam[NV], dbet[NV];
@@ -60,8 +67,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(uvc_ln_args a) {
   }
   const float a1 = a.a1 ? *a.a1 : 1.f, a2 = a.a2 ? *a.a2 : 1.f;
   float dotA = 0.f, dotB = 0.f;
-  const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
-  const int r1 = min(a.rows, r0 + LN_ROWS_PER_BLOCK);
+  const int r0 = blockIdx.x * rpb;
+  const int r1 = min(a.rows, r0 + rpb);
   const float invD = 1.0f / (float)a.D;
   for (int r = r0 + w; r < r1; r += 4) {
     const size_t off = row_off(r, a.rows_per_group, a.group_stride, a.D);
@@ -209,7 +216,7 @@ template <int LPR> __device__ __forceinline__ float sum_lpr(float v) {
   return v;
 }
 template <typename TDY, typename TG, int NV4, int LPR>
-__global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
+__global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a, int rpb) {
   constexpr int DD = 4 * LPR * NV4, RPW = 64 / LPR;        // row length; rows a wave handles at a time
   __shared__ float red[4][2 * DD + 2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane & (LPR - 1), rg = lane / LPR;
@@ -221,8 +228,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a) {
   }
   const float a1 = a.a1 ? *a.a1 : 1.f, a2 = a.a2 ? *a.a2 : 1.f;
   float dotA = 0.f, dotB = 0.f;
-  const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
-  const int r1 = min(a.rows, r0 + LN_ROWS_PER_BLOCK);
+  const int r0 = blockIdx.x * rpb;
+  const int r1 = min(a.rows, r0 + rpb);
   const float invD = 1.0f / (float)a.D;
   const TG* add1 = reinterpret_cast<const TG*>(a.add1);
   const TG* add2 = reinterpret_cast<const TG*>(a.add2);
@@ -387,11 +394,12 @@ generic:
   return UVC_OK;
 }
 template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
-  const int grid = ceil_div(a.rows, LN_ROWS_PER_BLOCK);
+  const int rpb = ln_rows_per_block(a.rows);
+  const int grid = ceil_div(a.rows, rpb);
   const int nv = ceil_div(a.D, 64);
   bool vec = a.D % 64 == 0 && (a.group_stride % 4) == 0;
   if (vec) {
-#define LNB_CASE(DV, NV4, LPR) case DV: if (a.g_lowp) k_ln_bwd_v<T, bf16_t, NV4, LPR><<<grid, 256, 0, st>>>(a); else k_ln_bwd_v<T, float, NV4, LPR><<<grid, 256, 0, st>>>(a); break;
+#define LNB_CASE(DV, NV4, LPR) case DV: if (a.g_lowp) k_ln_bwd_v<T, bf16_t, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); else k_ln_bwd_v<T, float, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); break;
     switch (a.D) {
       LNB_CASE(128, 2, 16) LNB_CASE(192, 3, 16) LNB_CASE(256, 2, 32) LNB_CASE(384, 3, 32) LNB_CASE(512, 2, 64) LNB_CASE(768, 3, 64)
       default: vec = false;
@@ -400,11 +408,11 @@ template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
   }
   if (!vec && a.g_lowp) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "layernorm_bwd: a bf16 gradient stream needs D % 64 == 0");
   if (!vec) {
-    if (nv <= 2) k_ln_bwd<T, 2><<<grid, 256, 0, st>>>(a);
-    else if (nv <= 3) k_ln_bwd<T, 3><<<grid, 256, 0, st>>>(a);
-    else if (nv <= 6) k_ln_bwd<T, 6><<<grid, 256, 0, st>>>(a);
-    else if (nv <= 12) k_ln_bwd<T, 12><<<grid, 256, 0, st>>>(a);
-    else k_ln_bwd<T, 16><<<grid, 256, 0, st>>>(a);
+    if (nv <= 2) k_ln_bwd<T, 2><<<grid, 256, 0, st>>>(a, rpb);
+    else if (nv <= 3) k_ln_bwd<T, 3><<<grid, 256, 0, st>>>(a, rpb);
+    else if (nv <= 6) k_ln_bwd<T, 6><<<grid, 256, 0, st>>>(a, rpb);
+    else if (nv <= 12) k_ln_bwd<T, 12><<<grid, 256, 0, st>>>(a, rpb);
+    else k_ln_bwd<T, 16><<<grid, 256, 0, st>>>(a, rpb);
   }
   UVC_CHECK_LAUNCH();
   if (a.defer_reduce) return UVC_OK;
@@ -424,9 +432,9 @@ template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
 }  // namespace
 
 // number of [2D+2]-float rows the backward scratch must hold: per-block partials + the second reduction stage
-extern "C" int uvc_layernorm_bwd_blocks(int32_t rows) { return ceil_div(rows, LN_ROWS_PER_BLOCK) + RED_S; }
+extern "C" int uvc_layernorm_bwd_blocks(int32_t rows) { return ceil_div(rows, ln_rows_per_block(rows)) + RED_S; }
 // number of partial rows a call over `rows` rows writes (the nblocks of its uvc_ln_reduce_item)
-extern "C" int uvc_layernorm_bwd_nblocks(int32_t rows) { return ceil_div(rows, LN_ROWS_PER_BLOCK); }
+extern "C" int uvc_layernorm_bwd_nblocks(int32_t rows) { return ceil_div(rows, ln_rows_per_block(rows)); }
 
 extern "C" int uvc_layernorm_fwd(const uvc_ln_args* p, void* stream) {
   if (int e = check(p)) return e;

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Dict, Optional
+from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
@@ -25,9 +25,10 @@ from . import vit as V
 NO_DECAY_NAMES = ("pos_embed", "cls_token", "dist_token")          # model_distilled.py:330-331
 
 
-def weight_decay_groups(params: Dict[str, torch.Tensor], weight_decay: float) -> Dict[str, float]:
-    """timm.optim.optim_factory.add_weight_decay (0.3.2) as a name -> decay table."""
-    return {n: (0.0 if (p.ndim == 1 or n.endswith(".bias") or n in NO_DECAY_NAMES) else weight_decay)
+def weight_decay_groups(params: Dict[str, torch.Tensor], weight_decay: float, no_decay_names=NO_DECAY_NAMES) -> Dict[str, float]:
+    """timm.optim.optim_factory.add_weight_decay (0.3.2) as a name -> decay table (``no_decay_names`` = model.no_weight_decay():
+    DeiT's by default; T2T-ViT's is {cls_token}, t2t_vit.py:153-155)."""
+    return {n: (0.0 if (p.ndim == 1 or n.endswith(".bias") or n in no_decay_names) else weight_decay)
             for n, p in params.items()}
 
 
@@ -79,11 +80,14 @@ class Stage2:
     wd_of: Dict[str, float] = field(default_factory=dict)
     cur_lr: float = 0.0
     global_step: int = 0
+    fwd: Optional[Callable] = None            # None = DeiT (oracle/vit.py:forward); oracle/t2t.py:forward_flags for T2T-ViT
+    frozen: Tuple[str, ...] = ()              # requires_grad False parameters (T2T: pos_embed, the Performer random features)
+    no_decay_names: Tuple[str, ...] = NO_DECAY_NAMES
 
     def __post_init__(self):
         if self.opt is None:
             self.opt = S1.AdamWState(lr0=self.hp.lr, wd=self.hp.weight_decay, eps=self.hp.opt_eps)
-        self.wd_of = weight_decay_groups(self.params, self.hp.weight_decay)
+        self.wd_of = weight_decay_groups(self.params, self.hp.weight_decay, self.no_decay_names)
         self.cur_lr = self.hp.warmup_lr if self.hp.warmup_epochs else self.hp.lr
 
     def begin_epoch(self, epoch: int):                            # scheduler.step(epoch), :339
@@ -101,15 +105,16 @@ def stage2_step(S: Stage2, x: torch.Tensor, y_soft: torch.Tensor, out: Optional[
     with torch.no_grad():
         for n, m in S.masks.items():                              # :343-346
             S.params[n].mul_(m)
-    for p in S.params.values():
-        p.requires_grad_(True)
+    fwd = S.fwd if S.fwd is not None else V.forward
+    for k, p in S.params.items():
+        p.requires_grad_(k not in S.frozen)
         p.grad = None
     S.params["block_skip_gating"].requires_grad_(False)           # :313,331
-    (o, od), _ = V.forward(S.params, S.cfg, student_flags(), x)   # :363
+    (o, od), _ = fwd(S.params, S.cfg, student_flags(), x)         # :363
     tl = None
     if S.hp.distillation_type != "none":
         with torch.no_grad():
-            tl, _ = V.forward(S.teacher, S.cfg, S1.teacher_flags(), x)
+            tl, _ = fwd(S.teacher, S.cfg, S1.teacher_flags(), x)
     loss = S1.distillation_loss(o, od, y_soft, tl, S.hp.distillation_type, S.hp.distillation_alpha, S.hp.distillation_tau)
     loss.backward()
     grads = {k: p.grad for k, p in S.params.items()}

@@ -6,7 +6,8 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Follows the reference's
 (Mlp :25-40, Attention :54-77, Block :100-112, get_sinusoid_encoding :115-125); backward is torch autograd on CPU.
 
 Pinning: the UNGATED forward (token-to-token module output, logits, the MAC table) is pinned to the reference's own
-modules run in the build container (tests/golden/make_t2t_golden.py -> tests/golden/t2t_*.npz).  The reference's GATED
+modules run in the build container (tests/golden/make_t2t_golden.py -> tests/golden/t2t_*.npz), and its backward by the
+Stage-2 step fixture (make_t2t_stage2_golden.py -> t2t_stage2_micro.npz: the reference's autograd, Performer dropout p = 0).  The reference's GATED
 T2T forward raises as shipped (``F`` never imported, ``self.gumbel_hard`` never assigned), so the gated
 branch below restates the lines as written (:181-189, identical to model_distilled.py:480-500) and its parity is UNPINNED.
 """

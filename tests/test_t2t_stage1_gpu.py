@@ -159,3 +159,70 @@ def test_t2t_14_stage1_step_runs():
     out = tr.step(x, y)
     assert np.isfinite(float(out["loss"])) and np.isfinite(float(out["gnorm"])) and 0 < float(out["cur"]) <= 1.0 + 1e-6
     assert abs(float(tr.flops_list[0]) - 256647680) < 1 and tr.flops_list[1][0] == [87146496, 14902656, 14902656, 29048832, 87146496, 87146496]
+
+
+# ---- Stage-2 masked fine-tune step on T2T-ViT against the fixture from the REFERENCE's own T2T_ViT + autograd
+# (tests/golden/make_t2t_stage2_golden.py; Performer dropout p = 0): pins the HIP backward of the tokens-to-token module
+def build_stage2(name, precision):
+    import os
+    from uvc_amd.post_train import Stage2Trainer, default_args, setup
+    from test_oracle_t2t import build_stage2_oracle
+    r, cfg, S, masks, teacher = build_stage2_oracle(name)
+    m = r["model_cfg"]
+    args = default_args(model_type="t2t_scenario", model_cfg=dict(embed_dim=m["embed_dim"], depth=m["depth"], num_heads=m["num_heads"], mlp_ratio=m["mlp_ratio"]),
+                        img_size=m["img_size"], num_classes=m["num_classes"], enable_deit=0, precision=precision, train_batch_size=r["batch"],
+                        learning_rate=r["learning_rate"], weight_decay=r["weight_decay"], max_grad_norm=r["max_grad_norm"], epochs=r["epochs"],
+                        warmup_epochs=r["warmup_epochs"], warmup_lr=r["warmup_lr"], min_lr=r["min_lr"], decay_rate=r["decay_rate"], opt_eps=r["opt_eps"],
+                        distillation_type=r["distillation_type"], distillation_alpha=r["distillation_alpha"], distillation_tau=r["distillation_tau"],
+                        compact_mlp=1, compact_multiple=64)
+    _, probe, _ = setup(default_args(**vars(args)), device="cuda")
+    state = {k: v.detach().cpu().clone() for k, v in probe.state_dict().items()}
+    for k, v in S.params.items():
+        state[k] = v.clone()
+    for k, v in masks.items():
+        state[k[:-len("weight")] + "mask"] = v.clone()
+    del probe
+    tr = Stage2Trainer(args, checkpoint=state, teacher_state=teacher)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    return r, cfg, tr, g
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_t2t_stage2_matches_reference_golden(precision):
+    name = "t2t_stage2_micro"
+    r, cfg, tr, g = build_stage2(name, precision)
+    f32 = precision == "fp32"
+    rt = 1e-3 if f32 else 3e-2
+    model = tr.model
+    names = [str(n) for n in g["param_names"]]
+    pmap = dict(model.named_parameters())
+    assert list(pmap.keys()) == names, "named_parameters order differs from the reference"
+    assert list(model.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    x_all, y_all = TS.stage1_inputs(r)
+    t2t = model.tokens_to_token
+    for step in range(r["steps"]):
+        tr.begin_epoch(r["epoch_of_step"][step])
+        out = tr.step(torch.from_numpy(x_all[step]).cuda(), torch.from_numpy(y_all[step]).cuda(), zero_grad=False)
+        pre = f"step{step}."
+        close(tr.optimizer.param_groups[0]["lr"], g[pre + "lr"], 1e-12, 0, pre + "lr")
+        close(float(out["loss"]), g[pre + "loss"], rt, 1e-6, pre + "loss")
+        close(out["outputs"][0].detach().cpu().numpy(), g[pre + "logits"], rt, 3e-4 if f32 else 5e-2, pre + "logits")
+        gn = float(out["gnorm"])
+        close(gn, g[pre + "grad_norm"], rt if f32 else 5e-2, 0, pre + "grad_norm")
+        coef = min(1.0, r["max_grad_norm"] / (gn + 1e-6))
+        ref = g[pre + "grad_abs_sum"]
+        got = np.array([np.nan if pmap[n].grad is None else float(pmap[n].grad.double().abs().sum()) * coef for n in names])
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), [n for n, a, b in zip(names, got, ref) if np.isnan(a) != np.isnan(b)]
+        ok = ~np.isnan(ref)
+        close(got[ok], ref[ok], 3e-3 if f32 else 8e-2, 1e-6, pre + "grad_abs_sum")
+        ga = 1e-6 if f32 else 2e-3
+        gr = 3e-3 if f32 else 8e-2
+        close(t2t.attention1.kqv.weight.grad[:8].cpu().numpy() * coef, g[pre + "g_kqv1"], gr, ga, pre + "d kqv1")
+        close(t2t.attention1.norm1.weight.grad.cpu().numpy() * coef, g[pre + "g_norm1_1"], gr, ga, pre + "d norm1")
+        close(t2t.attention2.proj.weight.grad.cpu().numpy() * coef, g[pre + "g_proj2"], gr, ga, pre + "d proj2")
+        close(t2t.project.bias.grad.cpu().numpy() * coef, g[pre + "g_project_b"], gr, ga, pre + "d project.bias")
+        if f32:
+            psum = np.array([float(pmap[n].data.double().abs().sum()) for n in names])
+            close(psum, g[pre + "param_abs_sum"], 1e-4, 0, pre + "param_abs_sum")
+            close(t2t.attention1.kqv.weight.data[0].cpu().numpy(), g[pre + "kqv1_row0"], 1e-3, 2e-6, pre + "kqv1 row")
+        tr.optimizer.zero_grad()

@@ -31,7 +31,7 @@ def build_parser():
     a = p.add_argument
     a("--name", default="debug"); a("--dataset", choices=["cifar10", "cifar100", "imagenet"], default="imagenet")
     a("--data_dir", default="/ssd1/shixing/imagenet2012"); a("--num_workers", default=4, type=int)
-    a("--model_type", choices=list(CONFIGS), default="deit_tiny_patch16_224")
+    a("--model_type", choices=list(CONFIGS) + ["t2t_vit_14"], default="deit_tiny_patch16_224")
     a("--model_path", default=None); a("--pretrained_dir", type=str, default="../ViT-pytorch/pretrain/ViT-B_16.npz"); a("--pretrained", type=int, default=1)
     a("--output_dir", default="../result/output/uvc_train", type=str); a("--img_size", default=224, type=int)
     a("--train_batch_size", default=1024, type=int); a("--eval_batch_size", default=64, type=int)

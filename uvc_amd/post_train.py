@@ -52,6 +52,17 @@ def register_masks(model):
 def setup(args, device="cuda", model_cfg=None):
     """post_train.py:135-186 for the DeiT family: the student as Stage-2 builds it (default gate flags, i.e. hard
     block skip; ``gumbel_hard=True``) with mask buffers registered."""
+    if "t2t" in args.model_type:                                    # post_train.py:165-167: t2t_vit_14() with the default flags
+        from .stage1 import T2T_CONFIGS
+        from .t2t_vit import T2T_ViT
+        cfg = dict(T2T_CONFIGS[args.model_type]) if args.model_type in T2T_CONFIGS else dict(model_cfg or args.model_cfg)
+        if args.enable_deit:
+            raise NotImplementedError("T2T-ViT has no distillation token")
+        kw = dict(embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"], mlp_ratio=cfg.get("mlp_ratio", 3.0),
+                  img_size=args.img_size, num_classes=args.num_classes, precision=args.precision, device=device)
+        model = T2T_ViT(**kw)
+        register_masks(model)
+        return args, model, kw
     cfg = dict(CONFIGS[args.model_type]) if args.model_type in CONFIGS else dict(model_cfg or args.model_cfg)
     kw = dict(patch_size=cfg["patch_size"], embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"],
               mlp_ratio=cfg.get("mlp_ratio", 4), qkv_bias=True, drop_rate=0, img_size=args.img_size,
@@ -67,7 +78,11 @@ class Stage2Trainer:
         args, model, kw = setup(args, device)
         teacher = None
         if args.distillation_type != "none":                                                        # :636-666
-            teacher = DistilledVisionTransformer(enable_dist=args.enable_deit, **kw)
+            if "t2t" in args.model_type:                                                            # :659-660
+                from .t2t_vit import T2T_ViT
+                teacher = T2T_ViT(**kw)
+            else:
+                teacher = DistilledVisionTransformer(enable_dist=args.enable_deit, **kw)
             if teacher_state is not None:
                 teacher.load_state_dict(teacher_state, strict=False)
             teacher.eval()

@@ -35,3 +35,26 @@ def test_bench_contract_under_torchrun_single_rank():
               "config", "roofline"):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0
+
+
+@pytest.mark.parametrize("model", ["deit", "t2t"])
+def test_two_ranks_match_single_process(model):
+    """Two ranks (gloo, both on the box's one GPU), half a batch each, against the single-process full-batch step."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547" if model == "deit" else "29549",
+                   RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", UVC_DDP_MODEL=model)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "ddp_two_rank_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    assert all(rc == 0 for rc, _, _ in outs), "\n".join(o[-1500:] + e[-3000:] for _, o, e in outs)
+    assert "DDP_TWO_RANK_OK" in outs[0][1]

@@ -10,12 +10,12 @@
 
 namespace {
 
-// backward: rows per workgroup.  128 keeps the partial reduction small when there are rows to spare; with fewer rows the
-// grid would not fill 256 CUs at one workgroup per CU (the kernels take ~200 VGPRs), so the blocks shrink.
+// backward: rows per workgroup (three workgroups fit a CU): enough workgroups to fill the chip several times over without
+// inflating the partial reduction.
 static int ln_rows_per_block(int rows) {
   static const int forced = [] { const char* v = getenv("UVC_LN_RPB"); return v ? atoi(v) : 0; }();
   if (forced == 32 || forced == 64 || forced == 128) return forced;
-  return rows >= 96 * 1024 ? 128 : rows >= 48 * 1024 ? 64 : 32;     // measured: T2T-14 batch 128 (25 k rows) +4 % step rate at 32, DeiT-Small batch 256 +1 % at 64
+  return rows >= 48 * 1024 ? 64 : 32;     // stand-alone at 100 k rows: 56 / 67 us at 64 against 60 / 77 at 128 and 62 / 72 at 32; T2T-14 (25 k rows) +4 % step rate at 32
 }
 
 __device__ __forceinline__ size_t row_off(int r, int rpg, int64_t gs, int D) {
@@ -233,8 +233,6 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a, int rpb) {
   const float invD = 1.0f / (float)a.D;
   const TG* add1 = reinterpret_cast<const TG*>(a.add1);
   const TG* add2 = reinterpret_cast<const TG*>(a.add2);
-  // The loads of the NEXT row group are issued before the reductions of the current one (two register sets): a workgroup
-  // keeps one group's 5 streams in flight the whole time instead of draining to zero at every reduction.
   struct Row { f32x4 xv[NV4], dv[NV4], ad1[NV4], ad2[NV4]; float mean, rstd; size_t off; bool ok; };
   auto load_row = [&](Row& R, int rb) {
     const int r = rb + rg;
@@ -288,15 +286,14 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a, int rpb) {
       }
     }
   };
-  Row Ra, Rb;
-  int rb = r0 + w * RPW;
-  load_row(Ra, rb);
-  for (; rb < r1; rb += 8 * RPW) {
-    load_row(Rb, rb + 4 * RPW);
+  // One row set per wave (~140 VGPRs, three workgroups per CU).  A second set that kept the next rows' loads in flight
+  // during the reductions (205 VGPRs, one workgroup per CU) was 10 % faster alone with both addends, but the kernel runs
+  // next to the weight-gradient stream and could then not share a CU with it: in the step the single set is 3 % faster
+  // end to end (DeiT-Tiny 16.40 -> 15.89 ms) and ~1 % on Small / Base / T2T.
+  Row Ra;
+  for (int rb = r0 + w * RPW; rb < r1; rb += 4 * RPW) {
+    load_row(Ra, rb);
     process(Ra);
-    if (rb + 4 * RPW >= r1) break;
-    load_row(Ra, rb + 8 * RPW);
-    process(Rb);
   }
   // reduce the 4 row groups of the wave, then the 4 waves (fixed order)
 #pragma unroll

@@ -39,9 +39,9 @@ int uvc_unfold_bwd_blocks(int32_t rows);
 
 /* Fold = adjoint of the soft split onto a token-major map: dst[b, h*W + w, c] = sum over the windows (ho, wo) and taps
  * (ki, kj) that cover (h, w) of src[b*L + ho*Wo + wo, c*k*k + ki*k + kj].  A gather (deterministic, no atomics).
- * src is float32 or T (`src_is_f32`), rows `lds` apart; dst is float32 [B, H*W, C]. */
-int uvc_fold_tokens(const void* src, int32_t src_is_f32, int32_t dtype, int32_t lds, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
-                    int32_t k, int32_t s, int32_t p, void* stream);
+ * src is float32 or T (`src_is_f32`), rows `lds` apart; dst [B, H*W, C] is float32 or T (`dst_is_f32`; sums in float32). */
+int uvc_fold_tokens(const void* src, int32_t src_is_f32, int32_t dtype, int32_t lds, void* dst, int32_t dst_is_f32, int32_t B, int32_t C, int32_t H,
+                    int32_t W, int32_t k, int32_t s, int32_t p, void* stream);
 
 /* Performer linear attention (token_performer.py:31-62) for emb = 64, m = 32 random features.
  * kqv [B*T, 192] float32 = Linear(norm1(x)) split as k | q | v (:46); w [32, 64] float32 (the fixed random features).

@@ -157,7 +157,7 @@ _SIGNATURES = {
     "uvc_unfold_ln_fwd": [C.POINTER(uvc_unfold_args), VP],
     "uvc_unfold_ln_bwd": [C.POINTER(uvc_unfold_args), VP],
     "uvc_unfold_bwd_blocks": [I32],
-    "uvc_fold_tokens": [VP, I32, I32, I32, VP, I32, I32, I32, I32, I32, I32, I32, VP],
+    "uvc_fold_tokens": [VP, I32, I32, I32, VP, I32, I32, I32, I32, I32, I32, I32, I32, VP],
     "uvc_performer_splits": [I32, I32],
     "uvc_performer_fwd": [C.POINTER(uvc_performer_args), VP],
     "uvc_performer_bwd": [C.POINTER(uvc_performer_args), VP],

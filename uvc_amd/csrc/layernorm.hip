@@ -370,6 +370,7 @@ template <typename T> int launch_fwd(const uvc_ln_args& a, hipStream_t st) {
   if (a.D % 64 == 0 && (a.group_stride % 4) == 0) {
     const int grid = ceil_div(a.rows, LNV_FWD_ROWS);
     switch (a.D / 64) {
+      case 1: k_ln_fwd_v<T, 1><<<grid, 256, 0, st>>>(a); break;
       case 2: k_ln_fwd_v<T, 2><<<grid, 256, 0, st>>>(a); break;
       case 3: k_ln_fwd_v<T, 3><<<grid, 256, 0, st>>>(a); break;
       case 6: k_ln_fwd_v<T, 6><<<grid, 256, 0, st>>>(a); break;
@@ -398,7 +399,7 @@ template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
   if (vec) {
 #define LNB_CASE(DV, NV4, LPR) case DV: if (a.g_lowp) k_ln_bwd_v<T, bf16_t, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); else k_ln_bwd_v<T, float, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); break;
     switch (a.D) {
-      LNB_CASE(128, 2, 16) LNB_CASE(192, 3, 16) LNB_CASE(256, 2, 32) LNB_CASE(384, 3, 32) LNB_CASE(512, 2, 64) LNB_CASE(768, 3, 64)
+      LNB_CASE(64, 1, 16) LNB_CASE(128, 2, 16) LNB_CASE(192, 3, 16) LNB_CASE(256, 2, 32) LNB_CASE(384, 3, 32) LNB_CASE(512, 2, 64) LNB_CASE(768, 3, 64)
       default: vec = false;
     }
 #undef LNB_CASE

@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void k_unfold_bwd_reduce(const float* partial,
   }
 }
 
-template <typename TS>
-__global__ void k_fold(const TS* src, int lds, float* dst, int B, int C, int H, int W, int k, int s, int p, int Ho, int Wo) {
+template <typename TS, typename TD>
+__global__ void k_fold(const TS* src, int lds, TD* dst, int B, int C, int H, int W, int k, int s, int p, int Ho, int Wo) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)B * H * W * C;
   if (idx >= total) return;
@@ -192,7 +192,7 @@ __global__ void k_fold(const TS* src, int lds, float* dst, int B, int C, int H, 
       acc += ElemIO<TS>::load(src + ((int64_t)b * L + ho * Wo + wo) * lds + c * kk + ki * k + kj);
     }
   }
-  dst[idx] = acc;
+  ElemIO<TD>::store(dst + idx, acc);
 }
 
 int fill_geom(const uvc_unfold_args* a, UG& g) {
@@ -209,7 +209,7 @@ int fill_geom(const uvc_unfold_args* a, UG& g) {
   if (g.dim > 576 || g.ldo < g.dim || g.ldo > ((g.dim + 63) / 64) * 64) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_unfold: need C*k*k <= 576 and dim <= ldo <= roundup(dim, 64)");
   return UVC_OK;
 }
-int bwd_grid(int rows) { const int n = (rows + 3) / 4; return n < 512 ? n : 512; }
+int bwd_grid(int rows) { const int n = (rows + 3) / 4; return n < 2048 ? n : 2048; }
 
 // ================================================================================================
 //                                  Performer linear attention
@@ -504,16 +504,19 @@ extern "C" int uvc_unfold_ln_bwd(const uvc_unfold_args* a, void* stream) {
   return UVC_OK;
 }
 
-extern "C" int uvc_fold_tokens(const void* src, int32_t src_is_f32, int32_t dtype, int32_t lds, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
-                               int32_t k, int32_t s, int32_t p, void* stream) {
+extern "C" int uvc_fold_tokens(const void* src, int32_t src_is_f32, int32_t dtype, int32_t lds, void* dst, int32_t dst_is_f32, int32_t B, int32_t C, int32_t H,
+                               int32_t W, int32_t k, int32_t s, int32_t p, void* stream) {
   if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || s <= 0 || p < 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_fold_tokens: arguments");
   const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
   if (Ho <= 0 || Wo <= 0 || lds < C * k * k) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_fold_tokens: geometry");
   const int64_t total = (int64_t)B * H * W * C;
   const int grid = (int)((total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
-  if (src_is_f32 || dtype == UVC_F32) k_fold<float><<<grid, 256, 0, st>>>((const float*)src, lds, dst, B, C, H, W, k, s, p, Ho, Wo);
-  else k_fold<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, lds, dst, B, C, H, W, k, s, p, Ho, Wo);
+  const bool sf = src_is_f32 || dtype == UVC_F32, df = dst_is_f32 || dtype == UVC_F32;
+  if (sf && df) k_fold<float, float><<<grid, 256, 0, st>>>((const float*)src, lds, (float*)dst, B, C, H, W, k, s, p, Ho, Wo);
+  else if (sf) k_fold<float, bf16_t><<<grid, 256, 0, st>>>((const float*)src, lds, (bf16_t*)dst, B, C, H, W, k, s, p, Ho, Wo);
+  else if (df) k_fold<bf16_t, float><<<grid, 256, 0, st>>>((const bf16_t*)src, lds, (float*)dst, B, C, H, W, k, s, p, Ho, Wo);
+  else k_fold<bf16_t, bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, lds, (bf16_t*)dst, B, C, H, W, k, s, p, Ho, Wo);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

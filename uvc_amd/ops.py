@@ -297,10 +297,10 @@ def unfold_ln_bwd(src, strides, B, Cc, H, W, k, s, p, dy, dtype, *, gamma, mean,
 
 
 def fold_tokens(src, dst, B, Cc, H, W, k, s, p, dtype, lds=None):
-    """dst[B, H*W, C] float32 = adjoint of the soft split applied to src [B*L, lds]."""
+    """dst[B, H*W, C] (float32 or T) = adjoint of the soft split applied to src [B*L, lds]."""
     _chk(src, dst)
-    L.check(L.lib().uvc_fold_tokens(L.ptr(src), _is_f32(src), dtype, lds if lds is not None else src.shape[1], L.ptr(dst), B, Cc, H, W, k, s, p,
-                                    L.cur_stream()), "uvc_fold_tokens")
+    L.check(L.lib().uvc_fold_tokens(L.ptr(src), _is_f32(src), dtype, lds if lds is not None else src.shape[1], L.ptr(dst), _is_f32(dst), B, Cc, H, W,
+                                    k, s, p, L.cur_stream()), "uvc_fold_tokens")
 
 
 def performer_splits(B, T) -> int:

@@ -311,9 +311,10 @@ class T2T_ViT(DistilledVisionTransformer):
                      mean2=torch.empty(M, device=dev), rstd2=torch.empty(M, device=dev), u=torch.empty(M, 64, device=dev, dtype=tdt),
                      out=torch.empty(M, 64, device=dev))
             if training:
-                b.update(gp=torch.empty(M, 64, device=dev, dtype=tdt), dout=torch.empty(M, 64, device=dev), da=torch.empty(M, 64, device=dev, dtype=tdt),
-                         dh=torch.empty(M, 64, device=dev), dx1=torch.empty(M, 64, device=dev), datt=torch.empty(M, 64, device=dev),
-                         dkqv=torch.empty(M, 192, device=dev), dkptv=torch.empty(B, 65, 32, device=dev), dxn=torch.empty(M, f["dimp"], device=dev),
+                # gradient streams in the operand type T (bf16 in the throughput mode, like the engine's dL/dx streams); sums are float32
+                b.update(gp=torch.empty(M, 64, device=dev, dtype=tdt), dout=torch.empty(M, 64, device=dev, dtype=tdt), da=torch.empty(M, 64, device=dev, dtype=tdt),
+                         dh=torch.empty(M, 64, device=dev, dtype=tdt), dx1=torch.empty(M, 64, device=dev, dtype=tdt), datt=torch.empty(M, 64, device=dev, dtype=tdt),
+                         dkqv=torch.empty(M, 192, device=dev, dtype=tdt), dkptv=torch.empty(B, 65, 32, device=dev), dxn=torch.empty(M, f["dimp"], device=dev, dtype=tdt),
                          ln2_partial=torch.empty(ops.layernorm_bwd_blocks(M) * (2 * 64 + 2), device=dev),
                          ln1_partial=torch.empty(ops.unfold_bwd_blocks(M) * 2 * f["dim"], device=dev),
                          dxu=torch.empty(M, f["dim"], device=dev) if i == 1 else None)
@@ -323,7 +324,7 @@ class T2T_ViT(DistilledVisionTransformer):
         M3 = B * side[2] * side[2]
         bufs["tok_u"] = torch.empty(M3, 576, device=dev, dtype=tdt)
         if training:
-            bufs["dxu3"] = torch.empty(M3, 576, device=dev)
+            bufs["dxu3"] = torch.empty(M3, 576, device=dev, dtype=tdt)
             tn_bytes = max(tn_bytes, ops.gemm_tn_workspace_bytes(M3, self.embed_dim, 576))
             bufs["tn_ws"] = torch.empty(tn_bytes, device=dev, dtype=torch.uint8)
             bufs["cs_partial"] = torch.empty(ops.colsum_blocks(M3) * self.embed_dim, device=dev)

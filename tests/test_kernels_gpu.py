@@ -88,9 +88,9 @@ def test_gemm_nt_f32_source_and_epilogues(dtype):
     torch.testing.assert_close(Cm.double(), 0.6 * (Aeff.double() @ Bt.double().t()) * aux.double(), **tol(dtype))
 
 
-@pytest.mark.parametrize("K,N", [(192, 192), (192, 576), (192, 768), (128, 128), (128, 512)])
+@pytest.mark.parametrize("K,N", [(192, 192), (192, 576), (192, 768), (128, 128), (128, 512), (384, 384), (384, 1152), (384, 1536)])
 def test_gemm_nt_streaming_kernel_matches_generic(K, N):
-    """The weights-stationary streaming kernel (M >= 4096, K in {128,192}, N % 64 == 0) must agree with the
+    """The weights-stationary streaming kernel (M >= 4096, K in {128,192}, N % 64 == 0; K = 384 with N % 192 == 0 and bf16 A) must agree with the
     generic tiled kernel bit-for-bit up to fp32 summation order, on every epilogue, incl. a ragged last M tile."""
     from uvc_amd import ops
     M = 4096 + 37

@@ -319,8 +319,10 @@ constexpr int WS_BM = 64;
 
 // NJ = 16-column accumulator tiles per wave: 4 (64 columns, 96 VGPRs of W at K = 192, two waves per SIMD) or 2 (32 columns, 48 VGPRs,
 // eight waves per workgroup, four per SIMD: the GELU epilogues of fc1 overlap its stores better)
+// KT = 12 (K = 384: DeiT-Small / T2T-ViT widths) runs as 6 waves x 32 columns: the wave's W slice is 96 VGPRs again, the two A images
+// (64 rows x 800 B) and the transpose buffers take 116 KB of dynamic LDS, one workgroup per CU.
 template <typename TA, typename TC, int EPI, int KT, int WS_NW, int NJ = 4>
-__global__ __launch_bounds__(64 * WS_NW, NJ == 4 ? 2 : 4) void k_gemm_ws(NtArgs g, int ngroups, int nslots) {
+__global__ __launch_bounds__(64 * WS_NW, (NJ == 4 || KT > 6) ? 2 : 4) void k_gemm_ws(NtArgs g, int ngroups, int nslots) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   constexpr int ROWB = KT * 64 + 32;             // bytes per staged A row (KT*32 bf16 + pad; words = 8 or 40 mod 64, see NT_ROWB)
@@ -328,8 +330,13 @@ __global__ __launch_bounds__(64 * WS_NW, NJ == 4 ? 2 : 4) void k_gemm_ws(NtArgs 
   constexpr int NLD = (WS_BM * CPR + 64 * WS_NW - 1) / (64 * WS_NW);
   constexpr int CW = 16 * NJ, EPW = CW + 4;         // columns per wave; floats per staged accumulator row
   constexpr int VN = OutVec<TC>::VN, LPR = CW / VN, RPI = 64 / LPR;
-  __shared__ __attribute__((aligned(16))) char sA[2][WS_BM * ROWB];
-  __shared__ __attribute__((aligned(16))) float sStage[WS_NW][16 * EPW];
+  constexpr bool DYN = KT > 6;
+  constexpr int IMGB = WS_BM * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char ws_dyn[];
+  __shared__ __attribute__((aligned(16))) char sA_st[DYN ? 16 : 2 * IMGB];
+  __shared__ __attribute__((aligned(16))) float sStage_st[DYN ? 4 : WS_NW * 16 * EPW];
+  char* const sAb = DYN ? ws_dyn : sA_st;
+  float* const sStg = DYN ? reinterpret_cast<float*>(ws_dyn + 2 * IMGB) : sStage_st;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gq = lane >> 4, li = lane & 15;
   const int L = blockIdx.x;
   const int grp = (L >> 3) % ngroups, slot = (L / (8 * ngroups)) * 8 + (L & 7);
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(64 * WS_NW, NJ == 4 ? 2 : 4) void k_gemm_ws(NtArgs 
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int id = tid + 64 * WS_NW * i, row = id / CPR, c = id % CPR;
-      if (row < WS_BM) *reinterpret_cast<u32x4*>(sA[buf] + row * ROWB + c * 16) = ra[i];
+      if (row < WS_BM) *reinterpret_cast<u32x4*>(sAb + buf * IMGB + row * ROWB + c * 16) = ra[i];
     }
   };
 
@@ -402,11 +409,11 @@ __global__ __launch_bounds__(64 * WS_NW, NJ == 4 ? 2 : 4) void k_gemm_ws(NtArgs 
   };
   auto subtile = [&](int buf_, int m0_, int sub_, const Epi& E) {
     if (!active) return;
-    float* stg = sStage[w];
+    float* stg = sStg + w * (16 * EPW);
     {
       typename MM::Frag fa[KT];
 #pragma unroll
-      for (int ks = 0; ks < KT; ++ks) fa[ks] = lds_frag<T>(sA[buf_] + (sub_ * 16 + li) * ROWB + (ks * 4 + gq) * 16);
+      for (int ks = 0; ks < KT; ++ks) fa[ks] = lds_frag<T>(sAb + buf_ * IMGB + (sub_ * 16 + li) * ROWB + (ks * 4 + gq) * 16);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
@@ -519,6 +526,37 @@ static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }
+// K = 384, N a multiple of 192 (DeiT-Small / T2T-ViT: qkv, proj, fc1 and the dgrads with K = D)
+// Measured at M = 50 k rows against the generic tiled kernel: qkv 102 -> 72 us, fc1 (+GELU, GELU') 178 -> 148, proj 47 -> 43, fc2 dgrad x GELU'
+// 133 -> 128; the plain and the recomputing-dGELU epilogues were slower (26 -> 28, 149 -> 162) and stay on the generic kernel.
+static bool ws384_ok(const NtArgs& a, int epi, int vn, bool a_f32) {
+  if (epi == UVC_EPI_NONE || epi == UVC_EPI_DGELU) return false;
+  return !a_f32 && a.K == 384 && a.N % 192 == 0 && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % vn == 0 && a.ldr % vn == 0 && a.ldaux % vn == 0 && a.M >= 4096;
+}
+template <typename TC>
+static int launch_ws384(const NtArgs& a, int epi, hipStream_t st) {
+  constexpr int KT = 12, NW = 6, NJ = 2;
+  const int ngroups = a.N / 192;
+  const int ntiles = ceil_div(a.M, WS_BM);
+  int nslots = (256 / ngroups) & ~7;                       // one workgroup per CU
+  if (nslots < 8) nslots = 8;
+  if (nslots > ((ntiles + 7) & ~7)) nslots = (ntiles + 7) & ~7;
+  const int grid = nslots * ngroups;
+  const int sh = 2 * WS_BM * (KT * 64 + 32) + NW * 16 * (16 * NJ + 4) * 4;
+#define WS_CASE(E) case E: { \
+    static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_ws<bf16_t, TC, E, KT, NW, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, sh); \
+    if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__); \
+    k_gemm_ws<bf16_t, TC, E, KT, NW, NJ><<<grid, 64 * NW, sh, st>>>(a, ngroups, nslots); } break;
+  switch (epi) {
+    WS_CASE(UVC_EPI_BIAS) WS_CASE(UVC_EPI_BIAS_GELU) WS_CASE(UVC_EPI_BIAS_RESID)
+    WS_CASE(UVC_EPI_BIAS_RESID_GATE) WS_CASE(UVC_EPI_BIAS_GELU_OUT) WS_CASE(UVC_EPI_BIAS_GELU_GRAD) WS_CASE(UVC_EPI_MUL_AUX)
+    default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
+  }
+#undef WS_CASE
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
 template <typename TA, typename TC, int KT>
 static int launch_ws_narrow(const NtArgs& a, int epi, hipStream_t st) {      // 8 waves x 32 columns
   const int ngroups = ceil_div(a.N, 256);
@@ -865,6 +903,8 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   }
   if (p->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dtype must be UVC_F32 or UVC_BF16");
   const bool ws = !p->force_generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
+  if (!p->force_generic && ws384_ok(a, e, p->c_is_f32 ? 4 : 8, p->a_is_f32 != 0))
+    return p->c_is_f32 ? launch_ws384<float>(a, e, st) : launch_ws384<bf16_t>(a, e, st);
   if (!p->force_generic && wsn_ok(a, e, p->a_is_f32 != 0))
     return p->c_is_f32 ? launch_wsn<float>(a, e, st) : launch_wsn<bf16_t>(a, e, st);
   if (p->a_is_f32) {

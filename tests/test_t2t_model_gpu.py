@@ -128,3 +128,27 @@ def test_training_forward_is_deterministic_and_optimizer_steps():
     pad = after[f["kqv_w"]:f["kqv_w"] + 192 * 160].view(192, 160)[:, 147:]
     assert float(pad.abs().max()) == 0.0                                    # K padding of attention1.kqv.weight stays zero
     assert not torch.equal(m.tokens_to_token.attention1.kqv.weight.data, sd["tokens_to_token.attention1.kqv.weight"].cuda())
+
+
+def test_t2t_14_forward_is_batch_independent_and_deterministic():
+    """Size-independent property at BASELINE config 5's model size: an image's logits are bit-identical whether it is
+    processed in a batch of 2 or of 16 (fixed-order sums everywhere, token-tile splits independent of the batch), and
+    two training forward/backward passes give bit-identical gradients."""
+    from uvc_amd.t2t_vit import t2t_vit_14
+    torch.manual_seed(3)
+    m = t2t_vit_14(precision="bf16")
+    m.eval()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(16, 3, 224, 224, device="cuda", generator=g)
+    with torch.no_grad():
+        big, _ = m(x)
+        small, _ = m(x[:2].contiguous())
+    assert torch.equal(big[:2], small)
+    m.train()
+    outs = []
+    for _ in range(2):
+        (o, _), _ = m(x[:4].contiguous())
+        o.backward(torch.ones_like(o) * 0.01)
+        outs.append((o.detach().clone(), m._flat_grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert bool(torch.isfinite(outs[0][1]).all())

@@ -454,13 +454,13 @@ __global__ __launch_bounds__(256) void k_performer_bwd_k(const float* kqv, const
   }
 }
 
+// Token tiles per split are a constant, so the order in which an image's kptv / dkptv sums are formed does not depend on the batch
+// size: an image's result is bit-identical whether it is processed alone or in a batch of 512.
+constexpr int PTPS = 8;
 int splits_of(int B, int T) {
+  (void)B;
   const int ntile = (T + PT - 1) / PT;
-  int s = 1024 / (B > 0 ? B : 1);
-  if (s < 1) s = 1;
-  if (s > ntile) s = ntile;
-  const int tps = (ntile + s - 1) / s;
-  return (ntile + tps - 1) / tps;
+  return (ntile + PTPS - 1) / PTPS;
 }
 int check_perf(const uvc_performer_args* p) {
   if (!p || !p->kqv || !p->w || !p->part || !p->kptv) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_performer: null pointer");
@@ -527,7 +527,7 @@ extern "C" int uvc_performer_fwd(const uvc_performer_args* p, void* stream) {
   if (int e = check_perf(p)) return e;
   if (!p->att) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_performer_fwd: null att");
   hipStream_t st = (hipStream_t)stream;
-  const int ntile = (p->T + PT - 1) / PT, S = splits_of(p->B, p->T), tps = (ntile + S - 1) / S;
+  const int ntile = (p->T + PT - 1) / PT, S = splits_of(p->B, p->T), tps = PTPS;
   k_performer_kv<<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->part, p->T, S, tps);
   UVC_CHECK_LAUNCH();
   k_part_reduce<<<dim3(ceil_div(PKV, 256), p->B), 256, 0, st>>>(p->part, p->kptv, S);
@@ -542,7 +542,7 @@ extern "C" int uvc_performer_bwd(const uvc_performer_args* p, void* stream) {
   if (int e = check_perf(p)) return e;
   if (!p->datt || !p->dkqv || !p->dkptv) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_performer_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  const int ntile = (p->T + PT - 1) / PT, S = splits_of(p->B, p->T), tps = (ntile + S - 1) / S;
+  const int ntile = (p->T + PT - 1) / PT, S = splits_of(p->B, p->T), tps = PTPS;
   const bool f32 = p->g_is_f32 || p->dtype == UVC_F32;
   if (f32) k_performer_bwd_q<float><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->kptv, (const float*)p->datt, (float*)p->dkqv, p->part, p->T, S, tps);
   else k_performer_bwd_q<bf16_t><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->kptv, (const bf16_t*)p->datt, (bf16_t*)p->dkqv, p->part, p->T, S, tps);

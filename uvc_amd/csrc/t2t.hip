@@ -209,59 +209,88 @@ int fill_geom(const uvc_unfold_args* a, UG& g) {
   if (g.dim > 576 || g.ldo < g.dim || g.ldo > ((g.dim + 63) / 64) * 64) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_unfold: need C*k*k <= 576 and dim <= ldo <= roundup(dim, 64)");
   return UVC_OK;
 }
-int bwd_grid(int rows) { const int n = (rows + 3) / 4; return n < 2048 ? n : 2048; }
+int bwd_grid(int rows) { const int n = (rows + 3) / 4; return n < 1024 ? n : 1024; }
 
 // ================================================================================================
 //                                  Performer linear attention
 // ================================================================================================
 constexpr int PE = 64, PM = 32, PT = 64, PKV = 65 * 32;
+// LDS row strides in floats: 64-wide tiles 68, 32-wide tiles 36 -- rows stay 16-byte aligned, so the inner products read four
+// consecutive elements per ds_read_b128 (the scalar-read form was LDS-bound: 9 reads for 8 FMAs), and both strides are 4 x odd:
+// a wave's lanes reading 16 bytes each from consecutive rows cover all 64 banks exactly once.
+constexpr int S64 = 68, S32 = 36;
 #define SQRT_M 5.656854249492381f
 
-__device__ __forceinline__ void load_w(const float* w, float (*sw)[65], int tid) {
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float c) { c += a[0] * b[0]; c += a[1] * b[1]; c += a[2] * b[2]; c += a[3] * b[3]; return c; }
+
+__device__ __forceinline__ void load_w(const float* w, float (*sw)[S64], int tid) {
 #pragma unroll
-  for (int it = 0; it < 8; ++it) { const int idx = tid + it * 256; sw[idx >> 6][idx & 63] = w[idx]; }
+  for (int it = 0; it < 2; ++it) { const int idx = (tid + it * 256) * 4; *reinterpret_cast<f32x4*>(&sw[idx >> 6][idx & 63]) = ld4(w + idx); }
 }
-// [64 tokens][64] float32 tile of kqv (row stride 192) -> LDS [64][65]; rows at or beyond T are zero
-__device__ __forceinline__ void load_tile_kqv(const float* base, int t0, int T, float (*s)[65], int tid) {
+// [64 tokens][64] float32 tile of kqv (row stride 192) -> LDS; rows at or beyond T are zero
+__device__ __forceinline__ void load_tile_kqv(const float* base, int t0, int T, float (*s)[S64], int tid) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t0 + r < T) v = *reinterpret_cast<const f32x4*>(base + (int64_t)(t0 + r) * 192 + c4);
-    s[r][c4] = v[0]; s[r][c4 + 1] = v[1]; s[r][c4 + 2] = v[2]; s[r][c4 + 3] = v[3];
+    if (t0 + r < T) v = ld4(base + (int64_t)(t0 + r) * 192 + c4);
+    *reinterpret_cast<f32x4*>(&s[r][c4]) = v;
   }
 }
 // [64 tokens][64] tile of a dense gradient stream [B*T, 64] (float32 or bf16) -> LDS
 template <typename TG>
-__device__ __forceinline__ void load_tile_g(const TG* base, int t0, int T, float (*s)[65], int tid) {
+__device__ __forceinline__ void load_tile_g(const TG* base, int t0, int T, float (*s)[S64], int tid) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t0 + r < T) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[r][c4 + e] = (t0 + r < T) ? ElemIO<TG>::load(base + (int64_t)(t0 + r) * 64 + c4 + e) : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = ElemIO<TG>::load(base + (int64_t)(t0 + r) * 64 + c4 + e);
+    }
+    *reinterpret_cast<f32x4*>(&s[r][c4]) = v;
   }
 }
-__device__ __forceinline__ void load_kv(const float* kv, float (*skv)[33], int tid) {
-  for (int idx = tid; idx < PKV; idx += 256) skv[idx >> 5][idx & 31] = kv[idx];
+__device__ __forceinline__ void load_kv(const float* kv, float (*skv)[S32], int tid) {
+  for (int idx = tid * 4; idx < PKV; idx += 1024) *reinterpret_cast<f32x4*>(&skv[idx >> 5][idx & 31]) = ld4(kv + idx);
 }
 // positive random features (token_performer.py:31-43): thread (token t, feature group mg) -> 8 of the 32 features
-__device__ __forceinline__ void prm8(const float (*sx)[65], const float (*sw)[65], int t, int mg, float (&p)[8]) {
+__device__ __forceinline__ void prm8(const float (*sx)[S64], const float (*sw)[S64], int t, int mg, float (&p)[8]) {
   float d[8], xx = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) d[j] = 0.f;
-  for (int i = 0; i < PE; ++i) {
-    const float x = sx[t][i];
-    xx += x * x;
+#pragma unroll 4
+  for (int i = 0; i < PE; i += 4) {
+    const f32x4 x = ld4(&sx[t][i]);
+    xx = dot4(x, x, xx);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] += x * sw[mg * 8 + j][i];
+    for (int j = 0; j < 8; ++j) d[j] = dot4(x, ld4(&sw[mg * 8 + j][i]), d[j]);
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) p[j] = expf(d[j] - 0.5f * xx) / SQRT_M;
 }
+// acc[j] += x * row[j], j < 8, row = 8 consecutive floats (two 16-byte broadcast reads)
+__device__ __forceinline__ void axpy8(float x, const float* row, float (&acc)[8]) {
+  const f32x4 a = ld4(row), b = ld4(row + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { acc[j] += x * a[j]; acc[4 + j] += x * b[j]; }
+}
+__device__ __forceinline__ void st8(float* row, const float (&v)[8]) {
+  *reinterpret_cast<f32x4*>(row) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(row + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+// sum_m a[m] * b[m] over the 32 features of two 36-stride rows
+__device__ __forceinline__ float dot32(const float* a, const float* b) {
+  float c = 0.f;
+#pragma unroll
+  for (int m = 0; m < PM; m += 4) c = dot4(ld4(a + m), ld4(b + m), c);
+  return c;
+}
 
 // kptv / ksum partials of one (image, split): sum_t v_t kp_t^T and sum_t kp_t over the split's token tiles
 __global__ __launch_bounds__(256) void k_performer_kv(const float* kqv, const float* w, float* part, int T, int S, int tps) {
-  __shared__ float sw[PM][65], sk[PT][65], sv[PT][65], skp[PT][33];
+  __shared__ __attribute__((aligned(16))) float sw[PM][S64], sk[PT][S64], sv[PT][S64], skp[PT][S32];
   const int tid = threadIdx.x, b = blockIdx.x / S, sp = blockIdx.x % S;
   const int ntile = (T + PT - 1) / PT;
   const int t = tid & 63, mg = tid >> 6;
@@ -279,15 +308,16 @@ __global__ __launch_bounds__(256) void k_performer_kv(const float* kqv, const fl
     __syncthreads();
     float p[8];
     prm8(sk, sw, t, mg, p);
+    if (t0 + t >= T) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) skp[t][mg * 8 + j] = (t0 + t < T) ? p[j] : 0.f;
-    __syncthreads();
-    for (int tt = 0; tt < PT; ++tt) {
-      const float vv = sv[tt][t];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += vv * skp[tt][mg * 8 + j];
+      for (int j = 0; j < 8; ++j) p[j] = 0.f;
     }
+    st8(&skp[t][mg * 8], p);
+    __syncthreads();
+#pragma unroll 16
+    for (int tt = 0; tt < PT; ++tt) axpy8(sv[tt][t], &skp[tt][mg * 8], acc);
     if (tid < PM)
+#pragma unroll 8
       for (int tt = 0; tt < PT; ++tt) ks += skp[tt][tid];
   }
   float* o = part + (int64_t)blockIdx.x * PKV;
@@ -306,7 +336,7 @@ __global__ void k_part_reduce(const float* part, float* out, int S) {
 
 template <typename TO>
 __global__ __launch_bounds__(256) void k_performer_q(const float* kqv, const float* w, const float* kptv, TO* att, int T, int ntile) {
-  __shared__ float sw[PM][65], sq[PT][65], skv[65][33], sqp[PT][33], sden[4][PT];
+  __shared__ __attribute__((aligned(16))) float sw[PM][S64], sq[PT][S64], skv[65][S32], sqp[PT][S32], sden[4][PT];
   const int tid = threadIdx.x, b = blockIdx.x / ntile, t0 = (blockIdx.x % ntile) * PT;
   const int t = tid & 63, mg = tid >> 6;
   load_w(w, sw, tid);
@@ -315,15 +345,15 @@ __global__ __launch_bounds__(256) void k_performer_q(const float* kqv, const flo
   __syncthreads();
   float p[8], pd = 0.f;
   prm8(sq, sw, t, mg, p);
+  st8(&sqp[t][mg * 8], p);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sqp[t][mg * 8 + j] = p[j]; pd += p[j] * skv[64][mg * 8 + j]; }
+  for (int j = 0; j < 8; ++j) pd += p[j] * skv[64][mg * 8 + j];
   sden[mg][t] = pd;
   __syncthreads();
   const int n = t;
+#pragma unroll 2
   for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {
-    float num = 0.f;
-#pragma unroll
-    for (int m = 0; m < PM; ++m) num += sqp[tt][m] * skv[n][m];
+    const float num = dot32(sqp[tt], skv[n]);
     const float den = ((sden[0][tt] + sden[1][tt]) + (sden[2][tt] + sden[3][tt])) + 1e-8f;
     if (t0 + tt < T) ElemIO<TO>::store(att + ((int64_t)b * T + t0 + tt) * PE + n, num / den);
   }
@@ -333,12 +363,16 @@ __global__ __launch_bounds__(256) void k_performer_q(const float* kqv, const flo
 template <typename TG>
 __global__ __launch_bounds__(256) void k_performer_bwd_q(const float* kqv, const float* w, const float* kptv, const TG* datt, TG* dkqv, float* part,
                                                          int T, int S, int tps) {
-  __shared__ float sw[PM][65], sq[PT][65], sdy[PT][65], skv[65][33], sqp[PT][33], sden[4][PT], sdden[PT];
+  __shared__ __attribute__((aligned(16))) float sw[PM][S64], sq[PT][S64], sdy[PT][S64], skv[65][S32], sqp[PT][S32], sden[4][PT], sdden[PT];
   const int tid = threadIdx.x, b = blockIdx.x / S, sp = blockIdx.x % S;
   const int ntile = (T + PT - 1) / PT;
   const int t = tid & 63, mg = tid >> 6;
   load_w(w, sw, tid);
   load_kv(kptv + (int64_t)b * PKV, skv, tid);
+  __syncthreads();
+  float wc[PM];                                                         // column t of w: dq[.][t] = sum_m g[.][m] * w[m][t]
+#pragma unroll
+  for (int m = 0; m < PM; ++m) wc[m] = sw[m][t];
   float acc[8], dks = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -353,14 +387,14 @@ __global__ __launch_bounds__(256) void k_performer_bwd_q(const float* kqv, const
       float p[8], pd = 0.f;
       prm8(sq, sw, t, mg, p);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float pj = (t0 + t < T) ? p[j] : 0.f; sqp[t][mg * 8 + j] = pj; pd += pj * skv[64][mg * 8 + j]; }
+      for (int j = 0; j < 8; ++j) { if (t0 + t >= T) p[j] = 0.f; pd += p[j] * skv[64][mg * 8 + j]; }
+      st8(&sqp[t][mg * 8], p);
       sden[mg][t] = pd;
     }
     __syncthreads();
-    for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                  // P2: dnum (in place over dy), dden; thread (n = t, 16 tokens)
-      float num = 0.f;
-#pragma unroll
-      for (int m = 0; m < PM; ++m) num += sqp[tt][m] * skv[t][m];
+#pragma unroll 2
+  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                  // P2: dnum (in place over dy), dden; thread (n = t, 16 tokens)
+      const float num = dot32(sqp[tt], skv[t]);
       const float den = ((sden[0][tt] + sden[1][tt]) + (sden[2][tt] + sden[3][tt])) + 1e-8f;
       const float dy = sdy[tt][t];
       const float dot = wave_sum(dy * num);
@@ -368,12 +402,10 @@ __global__ __launch_bounds__(256) void k_performer_bwd_q(const float* kqv, const
       if (t == 0) sdden[tt] = -dot / (den * den);
     }
     __syncthreads();
-    for (int tt = 0; tt < PT; ++tt) {                                  // P4: dkptv[n][m] += dnum[tt][n] qp[tt][m]; thread (n = t, 8 features)
-      const float dn = sdy[tt][t];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += dn * sqp[tt][mg * 8 + j];
-    }
+#pragma unroll 8
+    for (int tt = 0; tt < PT; ++tt) axpy8(sdy[tt][t], &sqp[tt][mg * 8], acc);     // P4: dkptv[n][m] += dnum[tt][n] qp[tt][m]
     if (tid < PM)
+#pragma unroll 8
       for (int tt = 0; tt < PT; ++tt) dks += sdden[tt] * sqp[tt][tid];
     __syncthreads();
     {                                                                  // P3: g = dqp * qp in place over qp; thread (token t, 8 features)
@@ -381,19 +413,28 @@ __global__ __launch_bounds__(256) void k_performer_bwd_q(const float* kqv, const
       const float dd = sdden[t];
 #pragma unroll
       for (int j = 0; j < 8; ++j) dqp[j] = dd * skv[64][mg * 8 + j];
-      for (int n = 0; n < PE; ++n) {
-        const float dn = sdy[t][n];
+#pragma unroll 2
+      for (int n = 0; n < PE; n += 4) {
+        const f32x4 dn = ld4(&sdy[t][n]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dqp[j] += dn * skv[n][mg * 8 + j];
+        for (int e = 0; e < 4; ++e) axpy8(dn[e], &skv[n + e][mg * 8], dqp);
       }
+      const f32x4 q0 = ld4(&sqp[t][mg * 8]), q1 = ld4(&sqp[t][mg * 8 + 4]);
+      float gq[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sqp[t][mg * 8 + j] *= dqp[j];
+      for (int j = 0; j < 4; ++j) { gq[j] = q0[j] * dqp[j]; gq[4 + j] = q1[j] * dqp[4 + j]; }
+      st8(&sqp[t][mg * 8], gq);
     }
     __syncthreads();
-    for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                  // P5: dq[tt][i] = sum_m g (w[m][i] - q[tt][i]); thread (i = t, 16 tokens)
+#pragma unroll 2
+  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                  // P5: dq[tt][i] = sum_m g (w[m][i] - q[tt][i]); thread (i = t, 16 tokens)
       float a = 0.f, gs = 0.f;
 #pragma unroll
-      for (int m = 0; m < PM; ++m) { const float gm = sqp[tt][m]; a += gm * sw[m][t]; gs += gm; }
+      for (int m = 0; m < PM; m += 4) {
+        const f32x4 gm = ld4(&sqp[tt][m]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a += gm[e] * wc[m + e]; gs += gm[e]; }
+      }
       if (t0 + tt < T) ElemIO<TG>::store(dkqv + ((int64_t)b * T + t0 + tt) * 192 + 64 + t, a - sq[tt][t] * gs);
     }
   }
@@ -406,7 +447,7 @@ __global__ __launch_bounds__(256) void k_performer_bwd_q(const float* kqv, const
 // k / v side of the backward, one 64-token tile per workgroup
 template <typename TG>
 __global__ __launch_bounds__(256) void k_performer_bwd_k(const float* kqv, const float* w, const float* dkptv, const TG* dskip, TG* dkqv, int T, int ntile) {
-  __shared__ float sw[PM][65], sk[PT][65], sv[PT][65], sdk[65][33], skp[PT][33];
+  __shared__ __attribute__((aligned(16))) float sw[PM][S64], sk[PT][S64], sv[PT][S64], sdk[65][S32], skp[PT][S32];
   const int tid = threadIdx.x, b = blockIdx.x / ntile, t0 = (blockIdx.x % ntile) * PT;
   const int t = tid & 63, mg = tid >> 6;
   const float* base = kqv + (int64_t)b * T * 192;
@@ -418,14 +459,12 @@ __global__ __launch_bounds__(256) void k_performer_bwd_k(const float* kqv, const
   {
     float p[8];
     prm8(sk, sw, t, mg, p);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) skp[t][mg * 8 + j] = p[j];
+    st8(&skp[t][mg * 8], p);
   }
   __syncthreads();
+#pragma unroll 2
   for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                    // dv[tt][n] = sum_m kp[tt][m] dkptv[n][m] (+ skip gradient)
-    float a = 0.f;
-#pragma unroll
-    for (int m = 0; m < PM; ++m) a += skp[tt][m] * sdk[t][m];
+    float a = dot32(skp[tt], sdk[t]);
     if (t0 + tt < T) {
       const int64_t r = (int64_t)b * T + t0 + tt;
       if (dskip) a += ElemIO<TG>::load(dskip + r * 64 + t);
@@ -437,26 +476,38 @@ __global__ __launch_bounds__(256) void k_performer_bwd_k(const float* kqv, const
     float dkp[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) dkp[j] = sdk[64][mg * 8 + j];
-    for (int n = 0; n < PE; ++n) {
-      const float vv = sv[t][n];
+#pragma unroll 2
+    for (int n = 0; n < PE; n += 4) {
+      const f32x4 vv = ld4(&sv[t][n]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dkp[j] += vv * sdk[n][mg * 8 + j];
+      for (int e = 0; e < 4; ++e) axpy8(vv[e], &sdk[n + e][mg * 8], dkp);
     }
+    const f32x4 k0 = ld4(&skp[t][mg * 8]), k1 = ld4(&skp[t][mg * 8 + 4]);
+    float gk[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) skp[t][mg * 8 + j] *= dkp[j];
+    for (int j = 0; j < 4; ++j) { gk[j] = k0[j] * dkp[j]; gk[4 + j] = k1[j] * dkp[4 + j]; }
+    st8(&skp[t][mg * 8], gk);
   }
   __syncthreads();
+  float wc[PM];
+#pragma unroll
+  for (int m = 0; m < PM; ++m) wc[m] = sw[m][t];
+#pragma unroll 2
   for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                    // dk[tt][i] = sum_m g (w[m][i] - k[tt][i])
     float a = 0.f, gs = 0.f;
 #pragma unroll
-    for (int m = 0; m < PM; ++m) { const float gm = skp[tt][m]; a += gm * sw[m][t]; gs += gm; }
+    for (int m = 0; m < PM; m += 4) {
+      const f32x4 gm = ld4(&skp[tt][m]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a += gm[e] * wc[m + e]; gs += gm[e]; }
+    }
     if (t0 + tt < T) ElemIO<TG>::store(dkqv + ((int64_t)b * T + t0 + tt) * 192 + t, a - sk[tt][t] * gs);
   }
 }
 
 // Token tiles per split are a constant, so the order in which an image's kptv / dkptv sums are formed does not depend on the batch
 // size: an image's result is bit-identical whether it is processed alone or in a batch of 512.
-constexpr int PTPS = 8;
+constexpr int PTPS = 7;     // 49 tiles (56 x 56 tokens) = 7 even splits
 int splits_of(int B, int T) {
   (void)B;
   const int ntile = (T + PT - 1) / PT;

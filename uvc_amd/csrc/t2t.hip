@@ -20,120 +20,167 @@ struct UG {                       // unfold geometry + pointers, passed by value
 };
 
 // One wave gathers one unfolded row into registers in natural feature order e = lane + 64*j (e = c*kk + ki*k + kj).
-// Token-major sources (C == 64, sc == 1) are read with the channel on the lane -- 256-byte coalesced loads -- and
+// CF: token-major sources (C == 64, sc == 1) are read with the channel on the lane -- 256-byte coalesced loads -- and
 // transposed to the natural order through a wave-private LDS row (stride kk is odd: conflict-free).
+// Integer divisions stay out of the row loop (with runtime k / kk / L they were ~2000 VALU cycles per row, more than the loads):
+// workgroups walk (image, output row) pairs and their waves the output columns, the taps of the token-major path advance
+// incrementally, and the generic path decomposes its features once per lane (LaneTaps).
+template <int NV> struct LaneTaps { int off[NV], ki[NV], kj[NV]; };
 template <int NV>
-__device__ __forceinline__ void gather_row(const UG& g, int row, bool valid, int lane, float* lrow, float (&v)[NV]) {
-  const int b = valid ? row / g.L : 0, l = valid ? row % g.L : 0;
-  const int ho = l / g.Wo, wo = l % g.Wo;
-  const float* sb = g.src + (int64_t)b * g.sb;
-  if (g.c_fast) {
+__device__ __forceinline__ LaneTaps<NV> lane_taps(const UG& g, int lane) {
+  LaneTaps<NV> t;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int e = lane + 64 * j;
+    const int c = e / g.kk, r = e % g.kk;
+    t.ki[j] = r / g.k; t.kj[j] = r % g.k;
+    t.off[j] = e < g.dim ? (int)(c * g.sc + t.ki[j] * g.sh + t.kj[j] * g.sw) : -1;
+  }
+  return t;
+}
+template <int NV, bool CF>
+__device__ __forceinline__ void gather_row(const UG& g, const LaneTaps<NV>& tp, int b, int ho, int wo, bool valid, int lane, float* lrow, float (&v)[NV]) {
+  const int h0 = ho * g.s - g.p, w0 = wo * g.s - g.p;
+  if (CF) {
+    const float* sb = g.src + (int64_t)b * g.sb + lane;
+    int ki = 0, kj = 0;
     for (int j = 0; j < g.kk; ++j) {
-      const int ki = j / g.k, kj = j % g.k;
-      const int hi = ho * g.s - g.p + ki, wi = wo * g.s - g.p + kj;
+      const int hi = h0 + ki, wi = w0 + kj;
       float x = 0.f;
-      if (valid && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) x = sb[(int64_t)hi * g.sh + (int64_t)wi * g.sw + lane];
+      if (valid && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) x = sb[(int64_t)hi * g.sh + (int64_t)wi * g.sw];
       lrow[lane * g.kk + j] = x;
+      if (++kj == g.k) { kj = 0; ++ki; }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = (lane + 64 * j < g.dim) ? lrow[lane + 64 * j] : 0.f;
     __syncthreads();
   } else {
+    const float* sb = g.src + (int64_t)b * g.sb + (int64_t)h0 * g.sh + (int64_t)w0 * g.sw;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int e = lane + 64 * j;
+      const int hi = h0 + tp.ki[j], wi = w0 + tp.kj[j];
       float x = 0.f;
-      if (valid && e < g.dim) {
-        const int c = e / g.kk, r = e % g.kk, ki = r / g.k, kj = r % g.k;
-        const int hi = ho * g.s - g.p + ki, wi = wo * g.s - g.p + kj;
-        if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) x = sb[(int64_t)c * g.sc + (int64_t)hi * g.sh + (int64_t)wi * g.sw];
-      }
+      if (valid && tp.off[j] >= 0 && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) x = sb[tp.off[j]];
       v[j] = x;
     }
   }
 }
-
+// One output row leaves as 16 bytes per lane: the wave parks its NV values per lane in its LDS row (natural order) and
+// reads them back as contiguous chunks -- one or two full-width store instructions instead of NV two-byte ones per lane.
+// DS operations of one wave execute in order; the wave barrier only keeps the compiler from reordering them.
 template <typename TO, int NV>
-__global__ __launch_bounds__(256) void k_unfold_ln(UG g) {
-  __shared__ float lds[4][NV * 64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int base = blockIdx.x * 4; base < g.rows; base += gridDim.x * 4) {
-    const int row = base + wv;
-    const bool valid = row < g.rows;
-    float v[NV];
-    gather_row<NV>(g, row, valid, lane, lds[wv], v);
-    if (g.gamma) {
-      float s = 0.f;
+__device__ __forceinline__ void store_row(float* lrow, const float (&v)[NV], TO* o, int ldo, int lane, bool valid) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) s += v[j];
-      const float mean = wave_sum(s) / (float)g.dim;
-      float q = 0.f;
+  for (int j = 0; j < NV; ++j) lrow[lane + 64 * j] = v[j];
+  __builtin_amdgcn_wave_barrier();
+  constexpr int VN = sizeof(TO) == 2 ? 8 : 4;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) { const float d = (lane + 64 * j < g.dim) ? v[j] - mean : 0.f; q += d * d; }
-      const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.dim + g.eps);
-      if (valid && lane == 0) { g.mean[row] = mean; g.rstd[row] = rstd; }
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int e = lane + 64 * j;
-        if (e < g.dim) v[j] = (v[j] - mean) * rstd * g.gamma[e] + g.beta[e];
+  for (int i = 0; i < (NV * 64 / VN + 63) / 64; ++i) {
+    const int c = (lane + 64 * i) * VN;
+    if (valid && c < ldo) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(lrow + c);
+      if (sizeof(TO) == 2) {
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(lrow + c + 4);
+        u32x4 r;
+        r[0] = pack_bf16x2(lo[0], lo[1]); r[1] = pack_bf16x2(lo[2], lo[3]); r[2] = pack_bf16x2(hi[0], hi[1]); r[3] = pack_bf16x2(hi[2], hi[3]);
+        *reinterpret_cast<u32x4*>(o + c) = r;
+      } else {
+        *reinterpret_cast<f32x4*>(o + c) = lo;
       }
     }
-    if (valid) {
-      TO* o = (TO*)g.out + (int64_t)row * g.ldo;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename TO, int NV, bool CF>
+__global__ __launch_bounds__(256) void k_unfold_ln(UG g) {
+  __shared__ __attribute__((aligned(16))) float lds[4][NV * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  LaneTaps<NV> tp;
+  if (!CF) tp = lane_taps<NV>(g, lane);
+  float gam[NV], bet[NV];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int e = lane + 64 * j;
-        if (e < g.ldo) ElemIO<TO>::store(o + e, e < g.dim ? v[j] : 0.f);
+  for (int j = 0; j < NV; ++j) {
+    const int e = lane + 64 * j;
+    gam[j] = (g.gamma && e < g.dim) ? g.gamma[e] : 0.f;
+    bet[j] = (g.gamma && e < g.dim) ? g.beta[e] : 0.f;
+  }
+  for (int bh = blockIdx.x; bh < g.B * g.Ho; bh += gridDim.x) {
+    const int b = bh / g.Ho, ho = bh - b * g.Ho;
+    for (int wo0 = 0; wo0 < g.Wo; wo0 += 4) {
+      const int wo = wo0 + wv;
+      const bool valid = wo < g.Wo;
+      const int row = bh * g.Wo + wo;
+      float v[NV];
+      gather_row<NV, CF>(g, tp, b, ho, wo, valid, lane, lds[wv], v);
+      if (g.gamma) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += v[j];
+        const float mean = wave_sum(s) / (float)g.dim;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { const float d = (lane + 64 * j < g.dim) ? v[j] - mean : 0.f; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.dim + g.eps);
+        if (valid && lane == 0) { g.mean[row] = mean; g.rstd[row] = rstd; }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = (lane + 64 * j < g.dim) ? (v[j] - mean) * rstd * gam[j] + bet[j] : 0.f;
       }
+      store_row<TO, NV>(lds[wv], v, (TO*)g.out + (int64_t)(valid ? row : 0) * g.ldo, g.ldo, lane, valid);
     }
   }
 }
 
 // LayerNorm backward of the fused kernel: recomputes the unfolded row, writes dxu (float32, natural order) and leaves the
 // per-workgroup partial sums of dgamma / dbeta in `partial` ([gridDim.x][2*dim]).
-template <typename TDY, int NV>
+template <typename TDY, int NV, bool CF>
 __global__ __launch_bounds__(256) void k_unfold_ln_bwd(UG g) {
-  __shared__ float lds[4][NV * 64];
+  __shared__ __attribute__((aligned(16))) float lds[4][NV * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float dgm[NV], dbt[NV], gam[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) { dgm[j] = 0.f; dbt[j] = 0.f; gam[j] = (lane + 64 * j < g.dim) ? g.gamma[lane + 64 * j] : 0.f; }
   const float inv = 1.0f / (float)g.dim;
-  for (int base = blockIdx.x * 4; base < g.rows; base += gridDim.x * 4) {
-    const int row = base + wv;
-    const bool valid = row < g.rows;
-    float v[NV];
-    gather_row<NV>(g, row, valid, lane, lds[wv], v);
-    const float mean = valid ? g.mean[row] : 0.f, rstd = valid ? g.rstd[row] : 0.f;
-    const TDY* dyr = (const TDY*)g.dy + (int64_t)(valid ? row : 0) * g.ldo;
-    float gy[NV], s1 = 0.f, s2 = 0.f;
+  LaneTaps<NV> tp;
+  if (!CF) tp = lane_taps<NV>(g, lane);
+  for (int bh = blockIdx.x; bh < g.B * g.Ho; bh += gridDim.x) {
+    const int b = bh / g.Ho, ho = bh - b * g.Ho;
+    for (int wo0 = 0; wo0 < g.Wo; wo0 += 4) {
+      const int wo = wo0 + wv;
+      const bool valid = wo < g.Wo;
+      const int row = bh * g.Wo + wo;
+      float v[NV];
+      gather_row<NV, CF>(g, tp, b, ho, wo, valid, lane, lds[wv], v);
+      const float mean = valid ? g.mean[row] : 0.f, rstd = valid ? g.rstd[row] : 0.f;
+      const TDY* dyr = (const TDY*)g.dy + (int64_t)(valid ? row : 0) * g.ldo;
+      float gy[NV], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int e = lane + 64 * j;
-      const float dy = (valid && e < g.dim) ? ElemIO<TDY>::load(dyr + e) : 0.f;
-      v[j] = (e < g.dim) ? (v[j] - mean) * rstd : 0.f;          // xhat
-      dgm[j] += dy * v[j];
-      dbt[j] += dy;
-      gy[j] = dy * gam[j];
-      s1 += gy[j];
-      s2 += gy[j] * v[j];
-    }
-    if (g.dxu) {
-      s1 = wave_sum(s1) * inv;
-      s2 = wave_sum(s2) * inv;
-      if (valid) {
-        float* o = g.dxu + (int64_t)row * g.dim;
+      for (int j = 0; j < NV; ++j) {
+        const int e = lane + 64 * j;
+        const float dy = (valid && e < g.dim) ? ElemIO<TDY>::load(dyr + e) : 0.f;
+        v[j] = (e < g.dim) ? (v[j] - mean) * rstd : 0.f;          // xhat
+        dgm[j] += dy * v[j];
+        dbt[j] += dy;
+        gy[j] = dy * gam[j];
+        s1 += gy[j];
+        s2 += gy[j] * v[j];
+      }
+      if (g.dxu) {
+        s1 = wave_sum(s1) * inv;
+        s2 = wave_sum(s2) * inv;
+        if (valid) {
+          float* o = g.dxu + (int64_t)row * g.dim;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const int e = lane + 64 * j;
-          if (e < g.dim) o[e] = rstd * (gy[j] - s1 - v[j] * s2);
+          for (int j = 0; j < NV; ++j) {
+            const int e = lane + 64 * j;
+            if (e < g.dim) o[e] = rstd * (gy[j] - s1 - v[j] * s2);
+          }
         }
       }
     }
   }
   __syncthreads();
-  float* red = &lds[0][0];
   // waves 1..3 hand their sums to wave 0 through LDS, one quantity at a time (fixed order)
   for (int pass = 0; pass < 2; ++pass) {
     if (wv > 0) {
@@ -151,7 +198,6 @@ __global__ __launch_bounds__(256) void k_unfold_ln_bwd(UG g) {
     }
     __syncthreads();
   }
-  (void)red;
 }
 
 __global__ __launch_bounds__(256) void k_unfold_bwd_reduce(const float* partial, int nblk, int dim, float* dgamma, float* dbeta, float beta_acc) {
@@ -528,13 +574,16 @@ extern "C" int uvc_unfold_ln_fwd(const uvc_unfold_args* a, void* stream) {
   UG g;
   if (int e = fill_geom(a, g)) return e;
   if (!a->out || (a->gamma && (!a->beta || !a->mean || !a->rstd))) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold_ln_fwd: null pointer");
+  if (g.ldo % 8) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold_ln_fwd: ldo must be a multiple of 8 (16-byte row stores)");
   hipStream_t st = (hipStream_t)stream;
-  int grid = (g.rows + 3) / 4;
+  int grid = g.B * g.Ho;
   if (grid > 16384) grid = 16384;
   const bool f32 = a->out_is_f32 || a->dtype == UVC_F32;
   const int nv = (g.dim + 63) / 64;
-  if (nv <= 3) { if (f32) k_unfold_ln<float, 3><<<grid, 256, 0, st>>>(g); else k_unfold_ln<bf16_t, 3><<<grid, 256, 0, st>>>(g); }
-  else { if (f32) k_unfold_ln<float, 9><<<grid, 256, 0, st>>>(g); else k_unfold_ln<bf16_t, 9><<<grid, 256, 0, st>>>(g); }
+#define UF_LAUNCH(NVV, CFF) do { if (f32) k_unfold_ln<float, NVV, CFF><<<grid, 256, 0, st>>>(g); else k_unfold_ln<bf16_t, NVV, CFF><<<grid, 256, 0, st>>>(g); } while (0)
+  if (nv <= 3) { if (g.c_fast) UF_LAUNCH(3, true); else UF_LAUNCH(3, false); }
+  else { if (g.c_fast) UF_LAUNCH(9, true); else UF_LAUNCH(9, false); }
+#undef UF_LAUNCH
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }
@@ -544,11 +593,14 @@ extern "C" int uvc_unfold_ln_bwd(const uvc_unfold_args* a, void* stream) {
   if (int e = fill_geom(a, g)) return e;
   if (!a->gamma || !a->mean || !a->rstd || !a->dy || !a->partial || !a->dgamma || !a->dbeta) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold_ln_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = bwd_grid(g.rows);
+  int grid = g.B * g.Ho;
+  if (grid > bwd_grid(g.rows)) grid = bwd_grid(g.rows);
   const bool f32 = a->dy_is_f32 || a->dtype == UVC_F32;
   const int nv = (g.dim + 63) / 64;
-  if (nv <= 3) { if (f32) k_unfold_ln_bwd<float, 3><<<grid, 256, 0, st>>>(g); else k_unfold_ln_bwd<bf16_t, 3><<<grid, 256, 0, st>>>(g); }
-  else { if (f32) k_unfold_ln_bwd<float, 9><<<grid, 256, 0, st>>>(g); else k_unfold_ln_bwd<bf16_t, 9><<<grid, 256, 0, st>>>(g); }
+#define UB_LAUNCH(NVV, CFF) do { if (f32) k_unfold_ln_bwd<float, NVV, CFF><<<grid, 256, 0, st>>>(g); else k_unfold_ln_bwd<bf16_t, NVV, CFF><<<grid, 256, 0, st>>>(g); } while (0)
+  if (nv <= 3) { if (g.c_fast) UB_LAUNCH(3, true); else UB_LAUNCH(3, false); }
+  else { if (g.c_fast) UB_LAUNCH(9, true); else UB_LAUNCH(9, false); }
+#undef UB_LAUNCH
   UVC_CHECK_LAUNCH();
   k_unfold_bwd_reduce<<<ceil_div(2 * g.dim, 64), 256, 0, st>>>(g.partial, grid, g.dim, a->dgamma, a->dbeta, a->beta_acc);
   UVC_CHECK_LAUNCH();

@@ -182,7 +182,8 @@ def test_mlp_compaction_equals_the_dense_masked_computation(name, precision):
     assert abs(g0 - g1) <= tol * g0
     scale = f0.abs().max().item()
     # bf16: other GEMM kernels are selected for the compact widths, so bf16-rounded intermediates (dA, dH) differ in the last bit
-    assert (f0 - f1).abs().max().item() <= (tol if precision == "fp32" else 1e-2) * scale
+    # (2^-8 each, and a few of them stack along the backward chain): 2 % of the largest gradient
+    assert (f0 - f1).abs().max().item() <= (tol if precision == "fp32" else 2e-2) * scale
     # one AdamW step moves an element by up to lr in the direction m/sqrt(v), which is ill-conditioned where |g| ~ eps
     assert (p0 - p1).abs().max().item() <= (0.1 if precision == "fp32" else 2.0) * comp.args.lr
     # rows of pruned units in dW1 / db1 are exact zeros

@@ -181,79 +181,159 @@ struct AttnArgs {
 
 // ------------------------------------------------------------------------------------------------
 // forward.  NT16 = number of 16-key tiles (multiple of TPS).
-template <typename T, int NT16>
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+// The keys are taken in blocks of at most 8 tiles with a running maximum / sum (two blocks at N = 197): the scores of one
+// block (32 VGPRs) instead of all 56 stay live, the kernel fits 128 VGPRs and runs 8 waves per workgroup, two workgroups per CU
+// (the K / V image in LDS is the limit) = 4 waves per SIMD to hide its MFMA -> max -> exp -> MFMA chain.
+template <typename T, int T0, int NTB>
+__device__ __forceinline__ void attn_key_block(const char* sK, const char* sV, const typename Mma<T>::Frag (&qf)[Geom<T>::KS], int N, float c2, int lane, int g, int li,
+                                               float& m_run, float& l_run, f32x4 (&ot)[4]) {
+  typedef Mma<T> MM;
+  typedef Geom<T> G;
+  __builtin_amdgcn_sched_barrier(0);              // keep the next block's fragment reads from being hoisted over this one (VGPRs)
+  f32x4 st[NTB];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NTB; ++t) {
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) c = MM::mma(row_frag_lds<T>(sK, (T0 + t) * 16 + li, ks * 4 + g), qf[ks], c);
+    if ((T0 + t) * 16 + 16 > N) {                   // only the last tile(s) hold padded keys (wave-uniform branch)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if ((T0 + t) * 16 + g * 4 + e >= N) c[e] = -INFINITY;
+    }
+    mx = fmaxf(mx, fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
+    st[t] = c;
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m_new = fmaxf(m_run, mx);
+  // p = exp(scale*(s - max)) = exp2(s*c2 - max*c2): one FMA + one v_exp_f32 per score (scale > 0)
+  const float mb = m_new * c2;
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTB; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float p = __builtin_amdgcn_exp2f(st[t][e] * c2 - mb); st[t][e] = p; sum += p; }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  if (T0 > 0) {                                     // rescale what the earlier blocks accumulated
+    const float alpha = __builtin_amdgcn_exp2f(m_run * c2 - mb);
+    l_run = l_run * alpha + sum;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ot[dt][e] *= alpha;
+  } else {
+    l_run = sum;
+  }
+  m_run = m_new;
+#pragma unroll
+  for (int s = 0; s < NTB / G::TPS; ++s) {
+    const typename MM::Frag pf = MM::pack(st[s * G::TPS], st[s * G::TPS + G::TPS - 1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt] = MM::mma(TrFrag<T>::ld(sV, G::ROWB, (T0 / G::TPS + s) * MM::KSTEP, dt * 16, lane), pf, ot[dt]);
+  }
+}
+
+template <typename T, int T0, int NT16, int ATT_BT>
+__device__ __forceinline__ void attn_key_blocks(const char* sK, const char* sV, const typename Mma<T>::Frag (&qf)[Geom<T>::KS], int N, float c2, int lane, int g, int li,
+                                                float& m_run, float& l_run, f32x4 (&ot)[4]) {
+  if constexpr (T0 < NT16) {
+    constexpr int NTB = (NT16 - T0) < ATT_BT ? (NT16 - T0) : ATT_BT;
+    attn_key_block<T, T0, NTB>(sK, sV, qf, N, c2, lane, g, li, m_run, l_run, ot);
+    attn_key_blocks<T, T0 + NTB, NT16, ATT_BT>(sK, sV, qf, N, c2, lane, g, li, m_run, l_run, ot);
+  }
+}
+
+// bf16: persistent workgroups (two per CU) walk (image, head) pairs; the K / V rows of the NEXT pair are fetched into registers
+// (4 + 4 chunks per thread) before the tiles of the current one are computed and written to LDS after them, so the HBM latency
+// of the staging -- a third of a head's time when it ran ahead of the tile loop -- hides under the MFMA / exp work.
+template <typename T, int NT16, int ATT_BT = 8>
+__global__ __launch_bounds__(sizeof(T) == 2 ? 512 : 256, sizeof(T) == 2 ? 4 : 1) void k_attn_fwd(AttnArgs a) {
   typedef Mma<T> MM;
   typedef Geom<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = NT16 * 16;
+  constexpr bool PF = sizeof(T) == 2;                    // register prefetch of the next head (512 threads)
+  constexpr int CPR = HD / MM::CH;
+  constexpr int NCH = PF ? (NP * CPR + 511) / 512 : 1;
   char* sK = smem;
   char* sV = smem + NP * G::ROWB;
-  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, g = lane >> 4, li = lane & 15;
   const size_t ldq = (size_t)3 * a.H * HD;
-  const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
-  const T* kb = qb + a.H * HD;
-  const T* vb = qb + 2 * a.H * HD;
-  T* ob = reinterpret_cast<T*>(a.o) + (size_t)b * a.N * a.H * HD + h * HD;
-  if (a.head_keep && a.head_keep[h] == 0) {                 // pruned head (inference): its output slice is zeros, nothing is read
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < a.N * 16; i += blockDim.x) Store4<T>::st(ob + (size_t)(i >> 4) * a.H * HD + (i & 15) * 4, z);
-    return;
-  }
-  stage_rows2<T>(sK, kb, ldq, sV, vb, ldq, a.N, NP);
-  __syncthreads();
+  const int nbh = a.B * a.H;
   const int nqt = (a.N + 15) / 16;
-  for (int qt = w; qt < nqt; qt += nw) {
-    typename MM::Frag qf[G::KS];
+  const float c2 = a.scale * 1.44269504088896340736f;
+  u32x4 pk[NCH], pv[NCH];
+  auto pf_load = [&](int bh2) {
+    const T* kb2 = reinterpret_cast<const T*>(a.qkv) + (size_t)(bh2 / a.H) * a.N * ldq + (bh2 % a.H) * HD + a.H * HD;
+    const T* vb2 = kb2 + a.H * HD;
+    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) qf[ks] = row_frag_global<T>(qb, ldq, qt * 16 + li, a.N, ks * 4 + g);
-    f32x4 st[NT16];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NT16; ++t) {
-      f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < G::KS; ++ks) c = MM::mma(row_frag_lds<T>(sK, t * 16 + li, ks * 4 + g), qf[ks], c);
-      if (t * 16 + 16 > a.N) {                       // only the last tile(s) hold padded keys (wave-uniform branch)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (t * 16 + g * 4 + e >= a.N) c[e] = -INFINITY;
-      }
-      mx = fmaxf(mx, fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
-      st[t] = c;
+    for (int i = 0; i < NCH; ++i) {
+      const int id = i * 512 + (int)threadIdx.x, row = id / CPR, c = id % CPR;
+      const bool ok = id < NP * CPR && row < a.N;
+      pk[i] = ok ? *reinterpret_cast<const u32x4*>(kb2 + (size_t)row * ldq + c * MM::CH) : z;
+      pv[i] = ok ? *reinterpret_cast<const u32x4*>(vb2 + (size_t)row * ldq + c * MM::CH) : z;
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // p = exp(scale*(s - max)) = exp2(s*c2 - max*c2): one FMA + one v_exp_f32 per score (scale > 0)
-    const float c2 = a.scale * 1.44269504088896340736f;
-    const float mb = mx * c2;
-    float sum = 0.f;
+  };
+  auto pf_store = [&]() {
 #pragma unroll
-    for (int t = 0; t < NT16; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float p = __builtin_amdgcn_exp2f(st[t][e] * c2 - mb); st[t][e] = p; sum += p; }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    f32x4 ot[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NT16 / G::TPS; ++s) {
-      const typename MM::Frag pf = MM::pack(st[s * G::TPS], st[s * G::TPS + G::TPS - 1]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) ot[dt] = MM::mma(TrFrag<T>::ld(sV, G::ROWB, s * MM::KSTEP, dt * 16, lane), pf, ot[dt]);
-    }
-    const int q = qt * 16 + li;
-    if (q < a.N) {
-      const float inv = 1.0f / sum;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        f32x4 v = ot[dt];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= inv;
-        Store4<T>::st(ob + (size_t)q * a.H * HD + dt * 16 + g * 4, v);
+    for (int i = 0; i < NCH; ++i) {
+      const int id = i * 512 + (int)threadIdx.x;
+      if (id < NP * CPR) {
+        *reinterpret_cast<u32x4*>(sK + (id / CPR) * G::ROWB + (id % CPR) * 16) = pk[i];
+        *reinterpret_cast<u32x4*>(sV + (id / CPR) * G::ROWB + (id % CPR) * 16) = pv[i];
       }
-      if (g == 0 && a.lse) a.lse[((size_t)b * a.H + h) * a.N + q] = mx * a.scale + __logf(sum);
+    }
+  };
+  int bh = blockIdx.x;
+  if (bh >= nbh) return;
+  if (PF) {
+    pf_load(bh);
+    pf_store();
+  } else {
+    const T* kb = reinterpret_cast<const T*>(a.qkv) + (size_t)(bh / a.H) * a.N * ldq + (bh % a.H) * HD + a.H * HD;
+    stage_rows2<T>(sK, kb, ldq, sV, kb + a.H * HD, ldq, a.N, NP);
+  }
+  __syncthreads();
+  for (; bh < nbh; bh += gridDim.x) {
+    const int b = bh / a.H, h = bh % a.H;
+    const int nxt = bh + (int)gridDim.x;
+    if (PF && nxt < nbh) pf_load(nxt);
+    const T* qb = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ldq + h * HD;
+    T* ob = reinterpret_cast<T*>(a.o) + (size_t)b * a.N * a.H * HD + h * HD;
+    if (a.head_keep && a.head_keep[h] == 0) {               // pruned head (inference): its output slice is zeros
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      for (int i = threadIdx.x; i < a.N * 16; i += blockDim.x) Store4<T>::st(ob + (size_t)(i >> 4) * a.H * HD + (i & 15) * 4, z);
+    } else {
+      for (int qt = w; qt < nqt; qt += nw) {
+        typename MM::Frag qf[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) qf[ks] = row_frag_global<T>(qb, ldq, qt * 16 + li, a.N, ks * 4 + g);
+        f32x4 ot[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+        attn_key_blocks<T, 0, NT16, ATT_BT>(sK, sV, qf, a.N, c2, lane, g, li, m_run, l_run, ot);
+        const int q = qt * 16 + li;
+        if (q < a.N) {
+          const float inv = 1.0f / l_run;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            f32x4 v = ot[dt];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= inv;
+            Store4<T>::st(ob + (size_t)q * a.H * HD + dt * 16 + g * 4, v);
+          }
+          if (g == 0 && a.lse) a.lse[((size_t)b * a.H + h) * a.N + q] = m_run * a.scale + __logf(l_run);
+        }
+      }
+    }
+    if (PF && nxt < nbh) {
+      __syncthreads();
+      pf_store();
+      __syncthreads();
     }
   }
 }
@@ -413,12 +493,13 @@ template <typename T, int NT16> int launch(const AttnArgs& a, int which, hipStre
   const int grid = a.B * a.H;
   // forward: 4 waves per (image, head); backward: 8 (two workgroups per CU either way -- the LDS image is the limit --
   // so backward runs 4 waves per SIMD, which hides its longer dependent MFMA -> exp -> MFMA chains: 153 -> 135 us)
-  const int threads = which == 0 ? 256 : 512;
+  const int threads = which == 0 ? (sizeof(T) == 2 ? 512 : 256) : 512;
   hipError_t e = hipSuccess;
   if (which == 0) {
+    const int fgrid = (sizeof(T) == 2 && grid > 512) ? 512 : grid;      // bf16: two persistent workgroups per CU
     if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-    k_attn_fwd<T, NT16><<<grid, threads, sh, st>>>(a);
+    k_attn_fwd<T, NT16><<<fgrid, sizeof(T) == 2 ? 512 : 256, sh, st>>>(a);
   } else if (which == 1) {
     if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_bwd_dq<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);

@@ -23,6 +23,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+_real_stdout = sys.stdout
+
 # algorithmic FLOPs per image per step = 2*(3E + 4*L*Bk + 4*C)
 GFLOP_PER_IMG = {"deit_tiny_patch16_224": 9.972, "deit_small_patch16_224": 36.675, "deit_base_patch16_224": 140.28,
                  "t2t_vit_14": 37.42}      # T2T: 2*(3E + 4*L*Bk + 4*C) with E = 256,647,680; the tokens-to-token dgrad (<= 0.51) not counted
@@ -244,11 +246,16 @@ def main():
         line["roofline"] = kernel_roofline(tr, args)
         if world == 1 and not args.no_cpu_baseline and args.stage == 1:
             line["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=_real_stdout, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    # stdout carries exactly ONE line, the JSON record: the library's progress prints (FLOP size, eps updates, gating banners)
+    # are the reference's own messages and go to stderr here
+    import contextlib
+    _real_stdout = sys.stdout
+    with contextlib.redirect_stdout(sys.stderr):
+        main()

@@ -132,14 +132,14 @@ def test_training_forward_is_deterministic_and_optimizer_steps():
 
 def test_t2t_14_forward_is_batch_independent_and_deterministic():
     """Size-independent property at BASELINE config 5's model size: an image's logits are bit-identical whether it is
-    processed in a batch of 2 or of 16 (fixed-order sums everywhere, token-tile splits independent of the batch), and
+    processed in a batch of 2 or of 24 (fixed-order sums everywhere, token-tile splits independent of the batch), and
     two training forward/backward passes give bit-identical gradients."""
     from uvc_amd.t2t_vit import t2t_vit_14
     torch.manual_seed(3)
     m = t2t_vit_14(precision="bf16")
     m.eval()
     g = torch.Generator(device="cuda").manual_seed(5)
-    x = torch.randn(16, 3, 224, 224, device="cuda", generator=g)
+    x = torch.randn(24, 3, 224, 224, device="cuda", generator=g)      # 24 images: the streaming K = 384 GEMMs; 2 images: the generic ones
     with torch.no_grad():
         big, _ = m(x)
         small, _ = m(x[:2].contiguous())
@@ -152,3 +152,32 @@ def test_t2t_14_forward_is_batch_independent_and_deterministic():
         outs.append((o.detach().clone(), m._flat_grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert bool(torch.isfinite(outs[0][1]).all())
+
+
+def test_t2t_14_full_size_training_gradients_match_oracle():
+    """BASELINE config 5's model at a batch large enough (24 images = 4728 token rows) to select the streaming K = 384 GEMMs, the
+    7-way token splits of the Performer sums (3136 tokens) and the padded 147 -> 160 soft split: logits and gradients of a
+    training forward / backward in the bf16 throughput mode against the oracle's float32 autograd on the host."""
+    from uvc_amd.t2t_vit import t2t_vit_14
+    cfg = OT.T2TConfig()
+    sd = OT.init_params_numpy(cfg, 77, weight_gain=2.0)
+    m = t2t_vit_14(precision="bf16")
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(24, 3, 224, 224, generator=g)
+    dl = torch.randn(24, 1000, generator=g) * 0.05
+    (out, _), _ = m(x.cuda())
+    out.backward(dl.cuda())
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref_logits, ref = _oracle_grads(sd, cfg, x, None, dl)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_logits.numpy(), rtol=5e-2, atol=8e-2)
+    named = dict(m.named_parameters())
+    worst = {}
+    for k in ("tokens_to_token.attention1.kqv.weight", "tokens_to_token.attention1.norm1.weight", "tokens_to_token.attention2.kqv.weight",
+              "tokens_to_token.attention2.mlp.2.weight", "tokens_to_token.project.weight", "blocks.0.attn.qkv.weight", "blocks.0.mlp.fc1.weight",
+              "blocks.7.attn.proj.weight", "blocks.13.mlp.fc2.weight", "head.weight", "cls_token", "norm.weight"):
+        gr, got = ref[k], named[k].grad
+        assert got is not None, k
+        worst[k] = float((got.cpu() - gr).abs().max()) / (float(gr.abs().max()) + 1e-12)
+    assert max(worst.values()) < 8e-2, worst

@@ -130,3 +130,26 @@ def test_full_step_properties_bf16():
     assert abs(total - c1) < 1e-6
     for t in m1:
         assert bool(((t == 0) | (t == 1)).all())
+
+
+@pytest.mark.parametrize("model_type,big", [("deit_small_patch16_224", 32), ("deit_base_patch16_224", 24)])
+def test_forward_is_batch_independent_for_the_wider_models(model_type, big):
+    """BASELINE configs 3 / 4 (DeiT-Small, DeiT-Base) in the bf16 mode: image i of a batch of `big` (>= 4096 token rows: the
+    streaming K = 384 GEMMs for Small, the large-M paths for Base) gets bit-identical logits to image i of a 2-image batch (the
+    shape the reference goldens cover), and a second run of the same step is bit-identical."""
+    from uvc_amd.stage1 import Stage1Trainer, default_args
+    torch.manual_seed(730)
+    a = default_args(model_type=model_type, precision="bf16", train_batch_size=big)
+    tr = Stage1Trainer(a, device="cuda")
+    tr.begin_epoch(a.warmup_epochs + 1)
+    fixed_gate_noise(tr)
+    x, y = inputs(big)
+    tr.model.eval()
+    with torch.no_grad():
+        lb, _ = tr.model(x)
+        ls, _ = tr.model(x[:2].contiguous())
+    assert torch.equal(lb[:2], ls)
+    tr.model.train()
+    a1 = fwd_bwd(tr, x, y)
+    a2 = fwd_bwd(tr, x, y)
+    assert torch.equal(a1[0], a2[0]) and a1[1] == a2[1] and torch.equal(a1[2], a2[2])

@@ -200,16 +200,19 @@ __global__ __launch_bounds__(256) void k_unfold_ln_bwd(UG g) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_unfold_bwd_reduce(const float* partial, int nblk, int dim, float* dgamma, float* dbeta, float beta_acc) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void k_unfold_bwd_reduce(const float* partial, int nblk, int dim, float* dgamma, float* dbeta, float beta_acc) {
+  __shared__ float red[16][64];
+  const int l = threadIdx.x & 63, q = threadIdx.x >> 6;        // 64 columns x 16 row groups, combined in a fixed order
+  const int c = blockIdx.x * 64 + l;
   float t = 0.f;
   if (c < 2 * dim)
-    for (int b = q; b < nblk; b += 4) t += partial[(int64_t)b * 2 * dim + c];
-  red[q][threadIdx.x & 63] = t;
+    for (int b = q; b < nblk; b += 16) t += partial[(int64_t)b * 2 * dim + c];
+  red[q][l] = t;
   __syncthreads();
   if (q == 0 && c < 2 * dim) {
-    t = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][l];
     float* o = c < dim ? dgamma + c : dbeta + (c - dim);
     *o = (beta_acc != 0.f ? beta_acc * *o : 0.f) + t;
   }
@@ -602,7 +605,7 @@ extern "C" int uvc_unfold_ln_bwd(const uvc_unfold_args* a, void* stream) {
   else { if (g.c_fast) UB_LAUNCH(9, true); else UB_LAUNCH(9, false); }
 #undef UB_LAUNCH
   UVC_CHECK_LAUNCH();
-  k_unfold_bwd_reduce<<<ceil_div(2 * g.dim, 64), 256, 0, st>>>(g.partial, grid, g.dim, a->dgamma, a->dbeta, a->beta_acc);
+  k_unfold_bwd_reduce<<<ceil_div(2 * g.dim, 64), 1024, 0, st>>>(g.partial, grid, g.dim, a->dgamma, a->dbeta, a->beta_acc);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -70,7 +70,9 @@ def sinusoid_encoding(n_position: int, d_hid: int) -> torch.Tensor:
     return torch.from_numpy(table.astype(np.float32)).unsqueeze(0)
 
 
-def param_shapes(cfg: T2TConfig) -> Dict[str, tuple]:
+def param_shapes(cfg: T2TConfig, enable_patch_gating: int = 0) -> Dict[str, tuple]:
+    """``enable_patch_gating == 2`` adds the token scorer ``gumbel = Linear(D -> 1)`` that DeiT's patch gating uses
+    (model_distilled.py:419) -- T2T_ViT has no such module in the reference; see ``forward``."""
     td, D, Fh, m = cfg.token_dim, cfg.embed_dim, cfg.hidden, cfg.m
     s: Dict[str, tuple] = {}
     for name, dim in (("attention1", cfg.in_chans * 49), ("attention2", td * 9)):
@@ -97,17 +99,20 @@ def param_shapes(cfg: T2TConfig) -> Dict[str, tuple]:
         s[b + "mlp.fc2.weight"] = (D, Fh); s[b + "mlp.fc2.bias"] = (D,)
     s["norm.weight"] = (D,); s["norm.bias"] = (D,)
     s["head.weight"] = (cfg.num_classes, D); s["head.bias"] = (cfg.num_classes,)
+    if enable_patch_gating == 2:                        # appended last: the other tensors keep their RandomState draws
+        s["gumbel.weight"] = (1, D); s["gumbel.bias"] = (1,)
     return s
 
 
-def init_params_numpy(cfg: T2TConfig, seed: int, std: float = 0.02, weight_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+def init_params_numpy(cfg: T2TConfig, seed: int, std: float = 0.02, weight_gain: float = 1.0,
+                      enable_patch_gating: int = 0) -> Dict[str, torch.Tensor]:
     """Portable deterministic weights (numpy's frozen RandomState stream): clipped normal std .02 * gain for Linear
     weights, small normal biases, LN 1 +- .1, gates [-1, 1], the sinusoid table for pos_embed; the Performer's
     random-feature matrix ``w`` is a plain normal scaled to the row norm sqrt(m) of the reference's
     orthogonal_ * sqrt(m) init (token_performer.py:28-29; values differ, the forward only reads them)."""
     rs = np.random.RandomState(seed)
     out: Dict[str, torch.Tensor] = {}
-    for name, shp in param_shapes(cfg).items():
+    for name, shp in param_shapes(cfg, enable_patch_gating).items():
         if name == "block_skip_gating":
             a = np.tile(np.array([-1.0, 1.0], dtype=np.float32), (cfg.depth, 1))
         elif name.endswith("skip_gating"):
@@ -212,12 +217,26 @@ def block(sd: Dict[str, torch.Tensor], pre: str, x: torch.Tensor, num_heads: int
 
 
 def forward(sd: Dict[str, torch.Tensor], cfg: T2TConfig, x: torch.Tensor, gate_d: Optional[torch.Tensor] = None,
-            taps: Optional[dict] = None):
+            taps: Optional[dict] = None, patch: Optional[dict] = None):
     """T2T_ViT.forward (t2t_vit.py:168-208).  ``gate_d`` [L, 2] = the per-block distributions when block gating is
     enabled (:181-189: x = d1 * blk(x) + d0 * x); None = the hard skip on the gate logits (:192-194).
+    ``patch`` = dict(tau, ratio, e [B, P] Exp(1) draws[, record]): Gumbel top-k patch gating on the tokens the
+    tokens-to-token module produced.  The reference's T2T forward_features has NO such step although BASELINE config 5 /
+    joint_train.py:404-410 call the model with (tau, ratio); it is DEFINED here by transplanting
+    model_distilled.py:446-456 verbatim: scorer Linear(D -> 1), log_softmax, Gumbel top-k with k = int(ratio * P),
+    straight-through mask, mask[:, 0] = 1, tokens multiplied (not removed) before cls / pos are added.  UNPINNED.
     Returns (logits, (macs_embed, macs_list))."""
     B = x.shape[0]
     tok, macs_embed = t2t_module(sd, x, taps)
+    if patch is not None:
+        from . import vit as V
+        k = int(patch["ratio"] * tok.shape[1])
+        scores = F.linear(tok, sd["gumbel.weight"], sd["gumbel.bias"]).reshape(B, -1)
+        mask, index = V.patch_topk_mask(scores, patch["e"], k, patch["tau"])
+        if patch.get("record") is not None:
+            patch["record"]["patch_index"] = index
+            patch["record"]["patch_mask"] = mask.detach()
+        tok = tok * mask.unsqueeze(-1)
     if taps is not None:
         taps["tokens"] = tok
     x = torch.cat((sd["cls_token"].expand(B, -1, -1), tok), dim=1) + sd["pos_embed"]
@@ -243,12 +262,16 @@ def forward_flags(params: Dict[str, torch.Tensor], cfg: T2TConfig, flags, x: tor
                   exp_draws: Optional[list] = None, record: Optional[dict] = None):
     """``forward`` behind the call signature of oracle/vit.py:forward (what oracle/step.py:stage1_step drives): the per-block
     gate distributions come from oracle/vit.py:block_distrib (model_distilled.py:480-488 == t2t_vit.py:181-185) with one
-    Exp(1) draw [2] per block; ``tau`` / ``ratio`` are accepted and unused (T2T's forward has no patch gating).
-    Training returns ((logits, logits), macs) (t2t_vit.py:205-206), eval (logits, macs).  UNPINNED for the gated case."""
+    Exp(1) draw [2] per block; ``tau > 0`` switches on the patch gating defined in ``forward`` (its [B, P] draw is consumed
+    first, DeiT's RNG order).  Training returns ((logits, logits), macs) (t2t_vit.py:205-206), eval (logits, macs).
+    UNPINNED for the gated cases."""
     from . import vit as V
     gate_d = None
+    draws = list(exp_draws) if exp_draws is not None else []
+    patch = None
+    if tau > 0:
+        patch = dict(tau=float(tau), ratio=float(ratio), e=draws.pop(0), record=record)
     if flags.enable_block_gating:
-        draws = list(exp_draws) if exp_draws is not None else []
         rows = []
         for i in range(cfg.depth):
             e = draws.pop(0) if (flags.use_gumbel == 1 and not flags.enable_warmup) else None
@@ -256,7 +279,7 @@ def forward_flags(params: Dict[str, torch.Tensor], cfg: T2TConfig, flags, x: tor
         gate_d = torch.stack(rows)
         if record is not None:
             record["distribs"] = gate_d.detach()
-    logits, macs = forward(params, cfg, x, gate_d=gate_d)
+    logits, macs = forward(params, cfg, x, gate_d=gate_d, patch=patch)
     if flags.training:
         return (logits, logits), macs
     return logits, macs

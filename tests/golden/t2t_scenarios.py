@@ -37,6 +37,9 @@ STAGE1 = {
     "t2t_micro_train": dict(model="micro", batch=4, steps=3, warmup=0, state="pruned", seed=51, gating_interval=2, warmup_steps=1, weight_gain=3.0),
     "t2t_micro_warmup": dict(model="micro", batch=4, steps=2, warmup=1, state="zero", seed=52, weight_gain=3.0),
     "t2t_micro_softl0": dict(model="micro", batch=4, steps=2, warmup=0, state="pruned", seed=53, use_gumbel=0, gating_interval=2, weight_gain=3.0),
+    # BASELINE config 5's flags: patch gating (Gumbel top-k, mode 2) + block gating; 16 tokens, k = int(.9 * 16) = 14
+    "t2t_micro_patch2": dict(model="micro", batch=4, steps=3, warmup=0, state="pruned", seed=54, gating_interval=2, warmup_steps=1, weight_gain=3.0,
+                             enable_patch_gating=2, patch_tau=0.7),
 }
 
 
@@ -63,9 +66,13 @@ def stage1_draws(r, depth):
     """Exp(1) draws per step: `depth` block-gate draws [2] for the student forward, then e1 / e2 [depth, 2] of the two resource
     evaluations inside uvc_optimizer (SURVEY 8c note 3)."""
     rs = np.random.RandomState(r["seed"] + 2000)
+    rp = np.random.RandomState(r["seed"] + 2500)          # patch-gating draws [B, P] come first in the model's list (DeiT's RNG order)
+    P = (r["model_cfg"]["img_size"] // 16) ** 2
     out = []
     for _ in range(r["steps"]):
         md = [rs.exponential(size=2).astype(np.float32) for _ in range(depth)]
+        if r.get("enable_patch_gating", 0) == 2:
+            md = [rp.exponential(size=(r["batch"], P)).astype(np.float32)] + md
         e1 = rs.exponential(size=(depth, 2)).astype(np.float32)
         e2 = rs.exponential(size=(depth, 2)).astype(np.float32)
         out.append((md, e1, e2))

@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 B_FULL = 512
 
 
-def make_trainer(precision, batch):
+def make_trainer(precision, batch, **over):
     from uvc_amd.stage1 import Stage1Trainer, default_args
     torch.manual_seed(730)
-    a = default_args(precision=precision, train_batch_size=batch)
+    a = default_args(precision=precision, train_batch_size=batch, **over)
     tr = Stage1Trainer(a, device="cuda")
     mm = tr.minimax
     L, H, F = mm.n_layers, mm.num_heads, mm.dims.F
@@ -72,21 +72,40 @@ def test_forward_is_batch_independent_at_full_size(precision):
     assert torch.equal(t_big[:8], t_small)
 
 
-def test_backward_is_linear_in_the_batch_and_deterministic_at_full_size():
-    tr = make_trainer("fp32", B_FULL)
+# BASELINE configs 2 / 3 / 4 at their stated per-GPU shapes.  Config 3's "batch=1024" is read as the reference reads
+# --train_batch_size: per GPU (data_utils.py:88-90); config 4 is DeiT-Base WITH the distillation token (N = 198, two heads) at
+# the reference's per-GPU batch 128 (log/deit-base-log.log: global 512 on 4 ranks).
+FULL = {
+    "tiny512": dict(batch=512, over=dict()),
+    "small1024": dict(batch=1024, over=dict(model_type="deit_small_patch16_224", budget=0.58)),
+    "base128_dist": dict(batch=128, over=dict(model_type="deit_base_patch16_224", enable_deit=1)),
+}
+
+
+@pytest.mark.parametrize("precision,cfg", [("fp32", "tiny512"), ("bf16", "tiny512"), ("bf16", "small1024"), ("bf16", "base128_dist")])
+def test_backward_is_linear_in_the_batch_and_deterministic_at_full_size(precision, cfg):
+    """The bf16 mode selects different kernels from the float32 one (k_gemm_tn_dma wgrads, bf16 gradient streams), so the
+    properties are checked in both.  Halving the batch doubles dL/dlogits exactly (a power of two survives the bf16 rounding
+    of the gradient streams), so linearity holds to float32 summation order in bf16 as well; the stated tolerance leaves room
+    for the per-row bf16 roundings that see differently-rounded float32 partial sums."""
+    spec = FULL[cfg]
+    B = spec["batch"]
+    tr = make_trainer(precision, B, **spec["over"])
     fixed_gate_noise(tr)
-    x, y = inputs(B_FULL)
-    _, loss, g_full = fwd_bwd(tr, x, y)
-    _, loss2, g_again = fwd_bwd(tr, x, y)
-    assert loss == loss2 and torch.equal(g_full, g_again), "the step is not deterministic"
-    h = B_FULL // 2
-    _, la, ga = fwd_bwd(tr, x[:h].contiguous(), y[:h].contiguous())
-    _, lb, gb = fwd_bwd(tr, x[h:].contiguous(), y[h:].contiguous())
+    x, y = inputs(B)
+    o1, loss, g_full = fwd_bwd(tr, x, y)
+    o2, loss2, g_again = fwd_bwd(tr, x, y)
+    assert torch.isfinite(g_full).all() and float(g_full.abs().max()) > 0
+    assert loss == loss2 and torch.equal(o1, o2) and torch.equal(g_full, g_again), "the step is not deterministic"
+    h = B // 2
+    oa, la, ga = fwd_bwd(tr, x[:h].contiguous(), y[:h].contiguous())
+    ob, lb, gb = fwd_bwd(tr, x[h:].contiguous(), y[h:].contiguous())
+    assert torch.equal(o1[:h], oa) and torch.equal(o1[h:], ob), "training forward is not batch independent"
     assert abs(loss - 0.5 * (la + lb)) <= 1e-5 * abs(loss)
     ref = 0.5 * (ga.double() + gb.double())
     err = (g_full.double() - ref).abs().max().item()
     scale = ref.abs().max().item()
-    assert err <= 2e-5 * scale, (err, scale)
+    assert err <= (2e-5 if precision == "fp32" else 2e-3) * scale, (err, scale)
     # checksum of checksums: the flat buffer is the concatenation of the parameters' .grad views
     total = sum(float(p.grad.double().sum()) for p in tr.model.parameters() if p.grad is not None)
     live = torch.zeros_like(g_full, dtype=torch.bool)
@@ -130,6 +149,34 @@ def test_full_step_properties_bf16():
     assert abs(total - c1) < 1e-6
     for t in m1:
         assert bool(((t == 0) | (t == 1)).all())
+
+
+@pytest.mark.parametrize("cfg", ["small1024", "base128_dist"])
+def test_eval_and_teacher_forward_batch_independent_at_config_3_and_4_shapes(cfg):
+    """Eval-mode student (soft block gates, fixed noise) and teacher forwards of BASELINE configs 3 / 4 at their full per-GPU batch in
+    bf16: image i gets bit-identical logits to image i of a 2-image batch -- the shape of the reference goldens
+    small2_pruned / base2_deit (the latter with the distillation token: N = 198, the two-head average of :528-531)."""
+    spec = FULL[cfg]
+    B = spec["batch"]
+    tr = make_trainer("bf16", B, **spec["over"])
+    fixed_gate_noise(tr)               # block gating draws Gumbel noise in eval mode too (model_distilled.py:480-488)
+    x, _ = inputs(B)
+    tr.model.eval()
+    with torch.no_grad():
+        lb, _ = tr.model(x)
+        ls, _ = tr.model(x[:2].contiguous())
+        tb, _ = tr.teacher(x)
+        ts, _ = tr.teacher(x[:2].contiguous())
+    assert torch.isfinite(lb).all() and torch.equal(lb[:2], ls) and torch.equal(tb[:2], ts)
+    # one full UVC-train step at this shape: finite, clip bound, resource in range
+    tr.model.train()
+    _, y = inputs(B, seed=6)
+    out = tr.step(x, y, zero_grad=False)
+    gn = float(out["gnorm"])
+    assert np.isfinite(float(out["loss"])) and np.isfinite(gn) and 0.0 < float(out["cur"]) < 1.5
+    if tr.model.num_tokens == 2:
+        assert tr.model.head_dist.weight.grad is not None and float(tr.model.head_dist.weight.grad.abs().sum()) > 0
+        assert tr.model.dist_token.grad is not None and float(tr.model.dist_token.grad.abs().sum()) > 0
 
 
 @pytest.mark.parametrize("model_type,big", [("deit_small_patch16_224", 32), ("deit_base_patch16_224", 24)])

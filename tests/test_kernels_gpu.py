@@ -512,3 +512,80 @@ def test_fused_inference_mlp(M, F_):
         o3 = torch.empty_like(out)
         ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, o3)
         assert torch.equal(o3, out)
+
+
+# ---- patch-gating Gumbel top-k at the production shape
+@pytest.mark.parametrize("B,P,k,tau", [(64, 196, 176, 0.7), (512, 196, 176, 0.1), (96, 196, 176, 10.0), (3, 16, 14, 1.0)])
+def test_patch_topk_mask_production_shape_bit_exact_indices(B, P, k, tau):
+    """ops.patch_topk_mask + backward against oracle/vit.py:patch_topk_mask (model_distilled.py:36-63,446-456) at P = 196,
+    k = int(0.9 * 196) = 176, over the tau range of joint_train.py:404-407 (0.1 ... 10): hard index sets BIT-EXACT for every
+    image whose k-th and (k+1)-th y_soft differ in the reference arithmetic, the straight-through mask / y_soft within
+    float32 rounding, d(scores) against float64 autograd.  Row 0 carries a constructed near-tie at the k-th boundary: the
+    (k+1)-th largest u sits 64 float32 ulps (>= 2e-5) below the k-th -- resolvable by the 1-ulp expf / logf the kernel uses,
+    the regime where a fast-math exp / log chain starts to blur neighbours.  At tau = 0.1 the tail of y_soft underflows
+    (u spans > 87 nats): some images tie at the boundary in the reference itself (torch.topk's choice among equal values is
+    unspecified) or decide it between subnormals; for those rows the selection must be A valid top-k of the kernel's own
+    y_soft (ties to the lower index), every other row is bit-exact."""
+    from oracle import vit as OV
+    from uvc_amd import ops
+    g = torch.Generator().manual_seed(1234 + P + B)
+    scores = torch.randn(B, P, generator=g) * 1.5
+    e = torch.empty(B, P).exponential_(generator=g)
+    logp = F.log_softmax(scores[0].double(), -1)
+    u = (logp - e[0].double().log()) / tau
+    order = torch.argsort(u, descending=True)
+    a, b = int(order[k - 1]), int(order[k])
+    gap = max(2e-5, 64.0 * abs(float(u[a])) * 2.0 ** -23)          # 64 float32 ulps of u: resolvable, but only just
+    e[0, b] = torch.exp(-((u[a] - gap) * tau - logp[b])).float()
+    ref_mask, ref_index = OV.patch_topk_mask(scores.clone(), e, k, tau)
+    y_ref = ((F.log_softmax(scores, -1) - e.log()) / tau).softmax(-1)          # the reference's float32 y_soft
+    ys_sorted = y_ref.sort(-1, descending=True)[0]
+    # decisive rows: the boundary pair differs AND sits in the normal float32 range (a subnormal y keeps only a few bits, so
+    # a 1-ulp difference between two correct expf implementations legitimately reorders the tail)
+    distinct = (ys_sorted[:, k - 1] > ys_sorted[:, k]) & (ys_sorted[:, k] > 1e-35)
+    if tau >= 0.5:
+        assert bool(distinct.all()) and a in ref_index[0].tolist() and b not in ref_index[0].tolist()
+    sc, ed = scores.to(dev()), e.to(dev())
+    mask, ys, ps = (torch.empty(B, P, device=dev()) for _ in range(3))
+    ops.patch_topk_mask(sc, ed, mask, ys, ps, B, P, k, float(tau))
+    hard = torch.zeros(B, P).scatter_(1, ref_index, 1.0) > 0.5
+    hard[:, 0] = True                                  # the observable mask: token 0 is forced to 1 after the scatter (:453)
+    ysc = ys.cpu()
+    sel = mask.cpu() > 0.5                             # (1 - y) + y vs (0 - y) + y
+    n_sel = sel[:, 1:].sum(1)
+    assert bool(((n_sel == k) | (n_sel == k - 1)).all()), "k tokens per image (k - 1 besides token 0 when it ranks in the top k)"
+    rows = torch.nonzero(distinct).flatten()
+    bad = [int(r) for r in rows if not torch.equal(sel[r], hard[r])]
+    assert not bad, f"index sets differ from the reference in rows {bad[:8]}"
+    for r in torch.nonzero(~distinct).flatten():       # boundary ties in the reference: a valid top-k, ties to the lower index
+        yr, sr = ysc[r, 1:], sel[r, 1:]
+        assert float(yr[sr].min()) >= float(yr[~sr].max())
+        tied = torch.nonzero(yr == yr[sr].min()).flatten()
+        chosen = [int(i) for i in tied if sr[i]]
+        assert chosen == [int(i) for i in tied[:len(chosen)]]
+    m_ref = ref_mask.detach()
+    torch.testing.assert_close(mask.cpu()[distinct], m_ref[distinct], rtol=0, atol=2e-6)
+    s64 = scores.double().requires_grad_(True)
+    y64 = ((F.log_softmax(s64, -1) - e.double().log()) / tau).softmax(-1)
+    torch.testing.assert_close(ysc.double(), y64.detach(), rtol=1e-4 if tau < 0.5 else 2e-5, atol=1e-30)
+    # backward: d(mask) -> d(scores); token 0 has no gradient (mask[:, 0] = 1 overwrites it)
+    dmask = torch.randn(B, P, generator=g)
+    dm = dmask.clone().double()
+    dm[:, 0] = 0
+    (y64 * dm).sum().backward()
+    ds = torch.empty(B, P, device=dev())
+    ops.patch_topk_mask_bwd(dmask.to(dev()), ys, ps, ds, B, P, float(tau))
+    torch.testing.assert_close(ds.cpu().double(), s64.grad, rtol=5e-4, atol=3e-6 / min(tau, 1.0))
+
+
+def test_patch_topk_mask_exact_ties_pick_the_lower_index():
+    """Exactly equal scores and draws: y ties bit-for-bit and the lower token index wins (the reference's torch.topk leaves
+    tie order unspecified)."""
+    from uvc_amd import ops
+    B, P, k = 2, 196, 176
+    sc = torch.zeros(B, P, device=dev())
+    e = torch.full((B, P), 0.5, device=dev())
+    mask, ys, ps = (torch.empty(B, P, device=dev()) for _ in range(3))
+    ops.patch_topk_mask(sc, e, mask, ys, ps, B, P, k, 1.0)
+    hard = mask.cpu() > 0.5
+    assert hard[:, :k].all() and not hard[:, k:].any()

@@ -98,7 +98,8 @@ def test_stage1_fp32_matches_reference_golden(name):
     run_scenario(name, "fp32", 1e-3)
 
 
-@pytest.mark.parametrize("name", ["micro_train", "micro_pruned", "tiny8_train", "tiny8_pruned", "small2_pruned"])
+@pytest.mark.parametrize("name", ["micro_train", "micro_pruned", "micro_deit", "micro_patch2", "tiny8_train", "tiny8_pruned", "small2_pruned",
+                                  "base2_deit"])
 def test_stage1_bf16_matches_reference_golden(name):
     """bf16 operands (8 mantissa bits) with float32 accumulation and float32 master weights: loss and
     logits within 2e-2; the UVC state and the mask index sets do not depend on the activations' precision

@@ -271,6 +271,9 @@ __device__ __forceinline__ float block_max256(float v, float* sh) {
 }
 // custom gumbel_softmax(log_softmax(scores), k, tau, hard=True) + token 0 forced to 1 (:36-63,446-456).
 // One block per image, P <= 256.  Outputs the straight-through mask, y_soft and softmax(scores) for backward.
+// The reference takes topk of y_soft: every step that decides an index (log_softmax, -log E, the division by tau, the
+// softmax of u) uses the correctly-rounded-to-1-ulp expf / logf, in the reference's operation order, NOT the fast
+// __expf / __logf (whose x*log2(e) pre-multiply alone is off by |x| * 6e-8); ties in y go to the lower index.
 __global__ __launch_bounds__(256) void k_patch_topk(const float* __restrict__ scores, const float* __restrict__ e, float* __restrict__ mask,
                                                     float* __restrict__ ysoft, float* __restrict__ psoft, int P, int k, float tau) {
   __shared__ float sh[4];
@@ -279,11 +282,11 @@ __global__ __launch_bounds__(256) void k_patch_topk(const float* __restrict__ sc
   const bool ok = t < P;
   const float s = ok ? scores[(size_t)b * P + t] : -INFINITY;
   const float m1 = block_max256(s, sh);
-  const float z1 = block_sum256(ok ? __expf(s - m1) : 0.f, sh);
-  const float logp = s - m1 - __logf(z1);
-  const float u = ok ? (logp + (-__logf(e[(size_t)b * P + t]))) / tau : -INFINITY;
+  const float z1 = block_sum256(ok ? expf(s - m1) : 0.f, sh);
+  const float logp = (s - m1) - logf(z1);
+  const float u = ok ? (logp + (-logf(e[(size_t)b * P + t]))) / tau : -INFINITY;
   const float m2 = block_max256(u, sh);
-  const float ex = ok ? __expf(u - m2) : 0.f;
+  const float ex = ok ? expf(u - m2) : 0.f;
   const float z2 = block_sum256(ex, sh);
   const float y = ex / z2;
   yv[t] = ok ? y : -1.0f;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void k_patch_topk(const float* __restrict__ sc
     const float hard = rank < k ? 1.0f : 0.0f;
     mask[(size_t)b * P + t] = t == 0 ? 1.0f : (hard - y) + y;
     ysoft[(size_t)b * P + t] = y;
-    psoft[(size_t)b * P + t] = __expf(logp);
+    psoft[(size_t)b * P + t] = expf(logp);
   }
 }
 // backward of the above w.r.t. the scores (straight-through: dmask -> dy, token 0 has no gradient)

@@ -538,9 +538,14 @@ class DistilledVisionTransformer(nn.Module):
         if mode1 and mode2:
             raise NotImplementedError("patch gating modes 1 and 2 together (never produced by the reference driver)")
         patch = None
+        # a custom token embedding (T2T-ViT's tokens-to-token module) writes pe [B*P, D] into the workspace itself
+        front = self._front_end_forward(x, B, training)
+        if front:
+            io.stage_begin, io.stage_end = 1, 2
         if mode1 or mode2:
-            io.stage_begin, io.stage_end = 0, 1
-            L.check(lib.uvc_vit_forward(C.byref(cfg), C.byref(io), stream), "uvc_vit_forward")
+            if not front:
+                io.stage_begin, io.stage_end = 0, 1
+                L.check(lib.uvc_vit_forward(C.byref(cfg), C.byref(io), stream), "uvc_vit_forward")
             mask = torch.empty(B, P, device=dev)
             if mode1:
                 ops.patch_gate_sigmoid(self.patch_gating.data, mask, B, P, self.patch_hard)
@@ -552,10 +557,6 @@ class DistilledVisionTransformer(nn.Module):
                 ops.patch_topk_mask(scores, self.exp_source((B, P)), mask, ys, ps, B, P, int(ratio * P), float(tau))
                 patch = dict(mode=2, mask=mask, ysoft=ys, psoft=ps, tau=float(tau))
             io.patch_mask = L.ptr(mask)
-            io.stage_begin, io.stage_end = 1, 2
-        if self._front_end_forward(x, B, training):
-            if patch is not None:
-                raise NotImplementedError("patch gating with a custom front end")
             io.stage_begin, io.stage_end = 1, 2
         if gate_d is not None:     # drawn after the patch-gating noise, in the reference's RNG order (:446-485)
             e = self.exp_source((cfg.depth, 2)) if mode in (1, 3) else None

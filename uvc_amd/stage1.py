@@ -65,11 +65,12 @@ class Stage1Trainer:
             # The reference builds `t2t_vit_14()` with default flags and then calls it as model(x, tau, ratio), which raises
             # (SURVEY Q8).  Defined here: the same model with DeiT's gate flags (block gating as written at t2t_vit.py:181-189).
             from .t2t_vit import T2T_ViT
-            if args.enable_deit or args.enable_patch_gating:
-                raise NotImplementedError("T2T-ViT has no distillation token and its forward has no patch gating (t2t_vit.py:168-200)")
+            if args.enable_deit or args.enable_patch_gating == 1:
+                raise NotImplementedError("T2T-ViT has no distillation token and no patch-gating mode 1 (t2t_vit.py:168-200); "
+                                          "enable_patch_gating=2 is defined in uvc_amd/t2t_vit.py")
             kw = dict(embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"], mlp_ratio=cfg.get("mlp_ratio", 3.0),
                       img_size=args.img_size, num_classes=args.num_classes, precision=args.precision, device=device)
-            model = T2T_ViT(gumbel_hard=False, **kw)
+            model = T2T_ViT(gumbel_hard=False, enable_patch_gating=args.enable_patch_gating, **kw)
         else:
             kw = dict(patch_size=cfg["patch_size"], embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"],
                       mlp_ratio=cfg.get("mlp_ratio", 4), qkv_bias=True, drop_rate=0, img_size=args.img_size,

@@ -14,7 +14,13 @@ What the reference defines and what this defines (the reference's gated T2T forw
   * ``block_skip_gating`` is a real [depth, 2] parameter (the reference's rows alias one storage through .expand(), :139);
   * the Performer's Dropout(0.1) layers (token_performer.py:13,24) are not applied in training mode: the UVC path runs
     DeiT with drop_rate 0 (joint_train.py:137) and the engine has no RNG-dependent layers besides the gates;
-  * ``enable_patch_gating`` is stored and, as in the reference's forward_features, has no effect.
+  * ``enable_patch_gating=2`` (BASELINE config 5, joint_train.py:404-410 calls ``model(x, tau, ratio)``): the reference's
+    T2T forward_features has no patch-gating step at all, so it is DEFINED here by transplanting DeiT's
+    (model_distilled.py:446-456) onto the tokens the tokens-to-token module produces: scorer ``gumbel = Linear(D -> 1)``
+    (an extra module, only registered in this mode, so the reference's state_dict key set is unchanged otherwise),
+    log_softmax -> Gumbel top-k with k = int(ratio * 196) -> straight-through mask, mask[:, 0] = 1, tokens multiplied
+    before cls / pos are added (oracle/t2t.py:forward, UNPINNED).  Mode 1 (a learnt per-position sigmoid) is not defined
+    for T2T and raises.
 There is no CPU path: constructing the model needs an MI355X.
 """
 from __future__ import annotations
@@ -107,8 +113,10 @@ class T2T_ViT(DistilledVisionTransformer):
         self.enable_block_gating = enable_block_gating
         self.enable_part_gating = 0
         self.enable_jumping = enable_jumping
-        self.t2t_enable_patch_gating = enable_patch_gating        # stored, unused (as in the reference's forward_features)
-        self.enable_patch_gating = 0
+        if enable_patch_gating not in (0, 2):
+            raise NotImplementedError("T2T-ViT: enable_patch_gating 0 or 2 (Gumbel top-k, defined in this module's docstring)")
+        self.t2t_enable_patch_gating = enable_patch_gating        # 2: forward(x, tau > 0, ratio) gates the tokens
+        self.enable_patch_gating = 0                              # mode 1 (model_distilled.py:434-444) does not exist here
         self.use_gumbel = use_gumbel
         self.eps = eps
         self.enable_warmup = enable_warmup
@@ -130,6 +138,8 @@ class T2T_ViT(DistilledVisionTransformer):
         self.norm = nn.LayerNorm(embed_dim)
         self.head = nn.Linear(embed_dim, num_classes)
         self.block_skip_gating = nn.Parameter(torch.Tensor([-1, 1]).expand(depth, 2).contiguous())
+        if enable_patch_gating == 2:
+            self.gumbel = nn.Linear(embed_dim, 1)                 # the token scorer of model_distilled.py:419
         nn.init.trunc_normal_(self.cls_token, std=.02)
         for m in self.modules():                                   # _init_weights (:144-151)
             if isinstance(m, nn.Linear):
@@ -226,6 +236,8 @@ class T2T_ViT(DistilledVisionTransformer):
                     (blk.attn_skip_gating, o.skip[l][0]), (blk.mlp_skip_gating, o.skip[l][1])]
         out += [(self.norm.weight, o.norm_w), (self.norm.bias, o.norm_b), (self.head.weight, o.head_w), (self.head.bias, o.head_b),
                 (self.block_skip_gating, o.gate)]
+        if self.gumbel is not None:
+            out += [(self.gumbel.weight, o.gumbel_w), (self.gumbel.bias, o.gumbel_b)]
         return out + self._front_slots()
 
     def _flatten(self, device):
@@ -433,18 +445,21 @@ class T2T_ViT(DistilledVisionTransformer):
         return embed, [list(blk) for _ in range(c.depth)]
 
     def forward(self, x, tau=-1, number=0.9):
-        """``tau`` / ``number`` are what joint_train.py:410,1012 pass; T2T's forward_features has no patch gating, they are ignored."""
+        """``tau`` / ``number`` are what joint_train.py:410,1012 pass.  With ``enable_patch_gating=2`` and ``tau > 0`` the tokens are
+        gated as the module docstring defines; otherwise both are ignored, as the reference's forward_features ignores them."""
         if self.enable_jumping:
             raise NotImplementedError("enable_jumping is off on the UVC hot path")
         macs = self.macs(x.shape[0])
+        if self.gumbel is None:
+            tau = -1
         if not self.enable_block_gating:
             run = self._hard_run_blocks()
             macs = (macs[0], [m if run[l] else [] for l, m in enumerate(macs[1])])
         if self.training and torch.is_grad_enabled():
             from .model_distilled import _VitFunction
-            out = _VitFunction.apply(self, x, self.cls_token, -1, 0.9)
+            out = _VitFunction.apply(self, x, self.cls_token, tau, number)
             return (out, out), macs                                  # t2t_vit.py:205-206
-        o, _ = self._run_forward(x, -1, 0.9, training=False)
+        o, _ = self._run_forward(x, tau, number, training=False)
         if self.training:
             return (o, o), macs
         return o, macs

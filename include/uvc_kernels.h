@@ -137,14 +137,15 @@ int uvc_mlp_fused_supported(int32_t D, int32_t F, int32_t dtype);
 int uvc_mlp_fused_fwd(const uvc_mlp_args* args, void* stream);
 
 /* DistillationLoss over SoftTargetCrossEntropy (UVC/utils/losses.py:25-65, joint_train.py:940):
- * loss = (1-alpha) * mean_b sum_c -y log_softmax(o) + alpha * KL(softmax(t/T) || softmax(o_kd/T)) * T^2 / (B*C).
+ * loss = (1-alpha) * mean_b sum_c -y log_softmax(o) + alpha * KL(softmax(t/T) || softmax(o_kd/T)) * T^2 / (B*C)   (kind 1, 'soft')
+ *      = (1-alpha) * base + alpha * mean_b CE(o_kd, argmax_c teacher)                                            (kind 2, 'hard', :61-62)
  * All float32 [B,C].  Writes loss[0] and the gradients d_o, d_okd (d_okd may alias d_o when
  * o_kd == o, i.e. enable_deit = 0: the two contributions are summed). */
 typedef struct uvc_loss_args {
   const float* o; const float* o_kd; const float* y_soft; const float* teacher;
   float* loss; float* d_o; float* d_okd; float* row_scratch; /* [B] */
   float alpha, tau;
-  int32_t B, C, kind; /* kind: 0 none, 1 soft */
+  int32_t B, C, kind; /* kind: 0 none, 1 soft, 2 hard */
 } uvc_loss_args;
 int uvc_distill_loss(const uvc_loss_args* args, void* stream);
 

@@ -136,9 +136,11 @@ def prox_w(st: UvcState, W1: List[torch.Tensor], W3: List[torch.Tensor], lr: flo
         W[:, cols] /= (1.0 + 2.0 * lr * st.y[l, 1].item())         # :344-345
 
 
-def prune_masks(st: UvcState, W1: List[torch.Tensor], W3: List[torch.Tensor]):
+def prune_masks(st: UvcState, W1: List[torch.Tensor], W3: List[torch.Tensor], prev_fc1: Optional[List[torch.Tensor]] = None):
     """prune_w_mask (uvc_utils.py:376-401).  Returns per layer (mask_proj[D,D], mask_fc2[D,F],
-    mask_fc1[F,D]) as float 0/1 plus the index sets (proj column keep-mask[D], fc2 keep-mask[F])."""
+    mask_fc1[F,D]) as float 0/1 plus the index sets (proj column keep-mask[D], fc2 keep-mask[F]).
+    The reference resets the proj / fc2 masks to 1 on every call (:382,393) but only writes zeros into the fc1 mask
+    (:401): ``prev_fc1`` = the fc1 masks before this call (None = all ones, the first call)."""
     cs, cr = st.s.ceil(), st.r.ceil()
     out = []
     for l in range(st.L):
@@ -156,6 +158,8 @@ def prune_masks(st: UvcState, W1: List[torch.Tensor], W3: List[torch.Tensor]):
         mask_proj = keep1.float().unsqueeze(0).expand(D, D).contiguous()
         mask_fc2 = keep3.float().unsqueeze(0).expand(D, st.F).contiguous()
         mask_fc1 = keep3.float().unsqueeze(1).expand(st.F, D).contiguous()   # :401
+        if prev_fc1 is not None:
+            mask_fc1 = mask_fc1 * prev_fc1[l]
         out.append((mask_proj, mask_fc2, mask_fc1, keep1, keep3))
     return out
 

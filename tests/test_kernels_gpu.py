@@ -376,6 +376,32 @@ def test_distill_loss(B, C, same):
         torch.testing.assert_close(d_k.double(), kd_in.grad, rtol=1e-4, atol=1e-8)
 
 
+@pytest.mark.parametrize("B,C,same", [(8, 1000, True), (5, 1000, False), (4, 16, False)])
+def test_distill_loss_hard(B, C, same):
+    """distillation_type='hard' (utils/losses.py:61-62, the argparse default joint_train.py:781): CE against the teacher's
+    argmax class; a tie in the teacher row goes to the first class (torch.argmax)."""
+    from uvc_amd import ops
+    o, y, t = rnd(B, C, seed=45) * 2, F.softmax(rnd(B, C, seed=46) * 2, -1), rnd(B, C, seed=47) * 2
+    t[0, 7] = t[0, 3] = t[0].max() + 1.0                   # exact tie: class 3 wins
+    okd = o if same else rnd(B, C, seed=48)
+    loss = torch.empty(1, device=dev()); d_o = torch.empty(B, C, device=dev())
+    d_k = d_o if same else torch.empty(B, C, device=dev())
+    scratch = torch.empty(B, device=dev())
+    alpha = 0.5
+    ops.distill_loss(o, okd, y, t, loss, d_o, d_k, scratch, alpha, 3.0, kind=2)
+    od = o.double().requires_grad_(True)
+    kd_in = od if same else okd.double().requires_grad_(True)
+    base = torch.sum(-y.double() * F.log_softmax(od, -1), -1).mean()
+    target = t.argmax(dim=1)
+    assert int(target[0]) == 3
+    ref = base * (1 - alpha) + F.cross_entropy(kd_in, target) * alpha
+    ref.backward()
+    torch.testing.assert_close(loss.double()[0], ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(d_o.double(), od.grad, rtol=1e-4, atol=1e-7)
+    if not same:
+        torch.testing.assert_close(d_k.double(), kd_in.grad, rtol=1e-4, atol=1e-8)
+
+
 def test_clip_adamw_matches_torch():
     from uvc_amd import ops
     n = 100003

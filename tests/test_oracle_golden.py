@@ -133,3 +133,22 @@ def test_zlr_schedule_and_eps_decay_known_answers():
         eps = eps * 0.92
         seq.append(eps)
     assert abs(seq[0] - 0.092) < 1e-12 and abs(seq[1] - 0.08464) < 1e-12
+
+
+def test_fc1_mask_is_the_sticky_union_of_pruned_sets():
+    """prune_w_mask resets the proj / fc2 masks on every call but only writes zeros into the fc1 mask (uvc_utils.py:382,393,401):
+    fixture from the reference's own prune_w_mask over three non-monotone primal states (tests/golden/make_mask_golden.py)."""
+    gold = load_golden("mask_sticky_micro")
+    r, S = build_oracle(str(gold["scenario"]))
+    prev = None
+    for i in range(3):
+        S.st.s, S.st.r = torch.from_numpy(gold[f"call{i}.s"].copy()), torch.from_numpy(gold[f"call{i}.r"].copy())
+        masks = OU.prune_masks(S.st, S.w1(), S.w3(), prev_fc1=prev)
+        prev = [m[2] for m in masks]
+        for l, (mp, mf2, mf1, keep1, keep3) in enumerate(masks):
+            assert np.array_equal(np.packbits(keep1.numpy().astype(np.uint8)), gold[f"call{i}.keep_proj.{l}"])
+            assert np.array_equal(np.packbits(keep3.numpy().astype(np.uint8)), gold[f"call{i}.keep_fc2.{l}"])
+            assert bool((mf1 == mf1[:, 0:1]).all())
+            assert np.array_equal(np.packbits(mf1[:, 0].numpy().astype(np.uint8)), gold[f"call{i}.keep_fc1.{l}"]), (i, l)
+    # the fixture exercises the difference: after call 1 fc1 rows stay masked whose fc2 column was released
+    assert any(not np.array_equal(gold[f"call1.keep_fc1.{l}"], gold[f"call1.keep_fc2.{l}"]) for l in range(S.cfg.depth))

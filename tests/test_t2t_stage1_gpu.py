@@ -68,6 +68,7 @@ def build(name, precision):
         tr.model.enable_warmup = 0
         tr.model.block_skip_gating.requires_grad = True
     prune_w_mask(mm, tr.optimizer)
+    r["_fc1_masks0"] = [m[2] for m in OU.prune_masks(S.st, S.w1(), S.w3())]       # the start-of-epoch call above (fc1 masks are sticky)
     return r, cfg, S, tr
 
 
@@ -150,11 +151,11 @@ def test_t2t_stage1_masks_bit_exact_vs_oracle():
     from uvc_amd.uvc_utils import prune_w_mask
     r, cfg, S, tr = run("t2t_micro_train", "fp32")
     prune_w_mask(tr.minimax, tr.optimizer)
-    masks = OU.prune_masks(S.st, S.w1(), S.w3())
+    masks = OU.prune_masks(S.st, S.w1(), S.w3(), prev_fc1=r["_fc1_masks0"])
     for l in range(cfg.depth):
         assert torch.equal(tr.uvc_layers["W1"][l].mask[0].cpu().bool(), masks[l][3])
         assert torch.equal(tr.uvc_layers["W3"][l].mask[0].cpu().bool(), masks[l][4])
-        assert torch.equal(tr.uvc_layers["W2"][l].mask[:, 0].cpu().bool(), masks[l][4])
+        assert torch.equal(tr.uvc_layers["W2"][l].mask.cpu(), masks[l][2])          # union of the start and end sets (uvc_utils.py:401)
 
 
 def test_t2t_14_stage1_step_runs():

@@ -167,3 +167,29 @@ def test_warmup_returns_early():
     assert abs(float(cur) - cur_o) < 1e-5
     assert torch.equal(mm._flat, before)           # no primal/dual update in warm-up
     assert torch.equal(model.blocks[0].attn.proj.weight.data.cpu(), W1c[0])   # but prox ran (:42)
+
+
+def test_fc1_mask_is_sticky_like_the_reference():
+    """k_masks against the fixture of the REFERENCE's prune_w_mask over three non-monotone primal states
+    (tests/golden/mask_sticky_micro.npz): proj / fc2 masks are rebuilt on every call, the fc1 mask only accumulates zeros
+    (uvc_utils.py:382,393,401) -- index sets bit-exact, and count_mask equals the reference's after every call."""
+    from helpers import load_golden
+    from stage1_driver import Stage1Run
+    from uvc_amd.joint_train import count_mask
+    from uvc_amd.uvc_utils import prune_w_mask
+    gold = load_golden("mask_sticky_micro")
+    run = Stage1Run(str(gold["scenario"]), precision="fp32")
+    for grp in ("W1", "W2", "W3"):                   # Stage1Run already pruned once at state 0: start from clean masks
+        for m in run.layers[grp]:
+            m.mask.fill_(1.0)
+    mm = run.minimax
+    for i in range(3):
+        mm.s.data.copy_(torch.from_numpy(gold[f"call{i}.s"])); mm.r.data.copy_(torch.from_numpy(gold[f"call{i}.r"]))
+        prune_w_mask(mm, run.optimizer)
+        for l in range(run.cfg.depth):
+            w1, w2, w3 = (run.layers[g][l].mask.cpu() for g in ("W1", "W2", "W3"))
+            assert bool((w1 == w1[0:1]).all()) and bool((w3 == w3[0:1]).all()) and bool((w2 == w2[:, 0:1]).all())
+            assert np.array_equal(np.packbits(w1[0].numpy().astype(np.uint8)), gold[f"call{i}.keep_proj.{l}"]), (i, l)
+            assert np.array_equal(np.packbits(w3[0].numpy().astype(np.uint8)), gold[f"call{i}.keep_fc2.{l}"]), (i, l)
+            assert np.array_equal(np.packbits(w2[:, 0].numpy().astype(np.uint8)), gold[f"call{i}.keep_fc1.{l}"]), (i, l)
+        assert abs(float(count_mask(run.model)) - float(gold[f"call{i}.count"])) < 1e-6

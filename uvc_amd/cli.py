@@ -31,7 +31,7 @@ def build_parser():
     a = p.add_argument
     a("--name", default="debug"); a("--dataset", choices=["cifar10", "cifar100", "imagenet"], default="imagenet")
     a("--data_dir", default="/ssd1/shixing/imagenet2012"); a("--num_workers", default=4, type=int)
-    a("--model_type", choices=list(CONFIGS) + ["t2t_vit_14"], default="deit_tiny_patch16_224")
+    a("--model_type", choices=list(CONFIGS) + ["t2t_vit_14", "custom", "custom_t2t"], default="deit_tiny_patch16_224")
     a("--model_path", default=None); a("--pretrained_dir", type=str, default="../ViT-pytorch/pretrain/ViT-B_16.npz"); a("--pretrained", type=int, default=1)
     a("--output_dir", default="../result/output/uvc_train", type=str); a("--img_size", default=224, type=int)
     a("--train_batch_size", default=1024, type=int); a("--eval_batch_size", default=64, type=int)
@@ -77,6 +77,8 @@ def build_parser():
     a("--num_classes", type=int, default=1000)
     a("--resume", type=str, default=None, help="engine training state written by --save_state (complete: s r y p z, AdamW, schedule)")
     a("--save_state", type=int, default=1, help="also write <name>/<model>_state_<epoch>.pth.tar (resumable) next to the reference-format checkpoint")
+    a("--model_cfg", type=str, default=None, help='with --model_type custom / custom_t2t: JSON dims, e.g. {"patch_size":16,"embed_dim":128,"depth":2,"num_heads":2}')
+    a("--eval_steps", type=int, default=2, help="synthetic validation batches per epoch (valid(), joint_train.py:199-246)")
     return p
 
 
@@ -90,11 +92,12 @@ def build_mixup(args):
                  switch_prob=args.mixup_switch_prob, mode=args.mixup_mode, label_smoothing=args.smoothing, num_classes=args.num_classes)
 
 
-def iterate_batches(args, device, rank, mixup_fn=None):
+def iterate_batches(args, device, rank, mixup_fn=None, epoch=0):
     """Synthetic ImageNet-shaped batches with hard labels, passed through the on-device Mixup / CutMix exactly where the
     reference calls mixup_fn (joint_train.py:399-409: odd batches lose their last sample first); without mixup the
-    labels become smoothed one-hot soft targets."""
-    g = torch.Generator(device=device).manual_seed(args.seed + 1000 * rank)
+    labels become smoothed one-hot soft targets.  Seeded per (rank, epoch): every epoch sees fresh batches, like a
+    DistributedSampler after set_epoch."""
+    g = torch.Generator(device=device).manual_seed(args.seed + 1000 * rank + 1000003 * epoch)
     for _ in range(args.steps_per_epoch):
         x = torch.randn(args.train_batch_size, 3, args.img_size, args.img_size, device=device, generator=g)
         t = torch.randint(0, args.num_classes, (args.train_batch_size,), device=device, generator=g)
@@ -108,13 +111,35 @@ def iterate_batches(args, device, rank, mixup_fn=None):
         yield x, y
 
 
+def iterate_eval_batches(args, device, rank):
+    """Synthetic stand-in for the test loader of valid() (joint_train.py:199-246): (x, hard labels), eval_batch_size each."""
+    g = torch.Generator(device=device).manual_seed(args.seed + 77 + 1000 * rank)
+    for _ in range(args.eval_steps):
+        x = torch.randn(args.eval_batch_size, 3, args.img_size, args.img_size, device=device, generator=g)
+        t = torch.randint(0, args.num_classes, (args.eval_batch_size,), device=device, generator=g)
+        yield x, t
+
+
+def append_json(path, step, value):
+    """joint_train.py:466-486: `data.update({global_step: value}); json.dump` -- int keys become strings on disk."""
+    with open(path, "r+") as f:
+        data = json.load(f)
+        data.update({str(step): value})
+        f.seek(0)
+        json.dump(data, f)
+        f.truncate()
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.fp16:
         raise NotImplementedError("--fp16 (apex amp) is not reproduced: bf16 MFMA with float32 master weights needs no loss scaling")
     if not args.synthetic:
         raise NotImplementedError("real-data loading needs torchvision/timm (absent here); plug a loader into iterate_batches")
-    args.distillation_type = getattr(args, "distillation_type")
+    if args.model_type.startswith("custom"):
+        if not args.model_cfg:
+            raise SystemExit("--model_type custom needs --model_cfg '<json>'")
+        args.model_cfg = json.loads(args.model_cfg)
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     torch.cuda.set_device(args.local_rank)
@@ -154,32 +179,43 @@ def main(argv=None):
             print(f"Start [Epoch {epoch}] at Stage {stage}")
             print(f"[Initial Sparsity|Epoch {epoch}] Parameter size: {remained:.2f}M / {float(args.total_param):.2f}M = {remained / float(args.total_param) * 100:.2f}%")
         t0 = time.time()
-        for step, (x, y) in enumerate(iterate_batches(args, device, rank, mixup_fn)):
+        for step, (x, y) in enumerate(iterate_batches(args, device, rank, mixup_fn, epoch)):
             out = tr.step(x, y)
+            if not out["stepped"]:                      # gradient accumulation: not an optimiser step yet (:417)
+                continue
             gs = tr.global_step
             if rank == 0 and gs % args.log_interval == 0:
                 print(f"{stage} [{epoch} Epochs] [{gs} / {tr.t_total} Steps] [LR: {tr.scheduler.get_last_lr()[0]:.6f} | "
                       f"Loss: {float(out['loss']):.3f}] resource {float(out['cur']):.4f}  {(step + 1) * args.train_batch_size * world / (time.time() - t0):.0f} img/s")
-                if epoch > args.warmup_epochs:
-                    for key, val in (("s", out["s"]), ("r", out["r"]), ("gating", out["g"])):
-                        if val is None:
-                            continue
-                        data = json.load(open(logs[key]))
-                        data[str(gs)] = val.tolist()
-                        json.dump(data, open(logs[key], "w"))
+                if epoch > args.warmup_epochs:                                                   # :464-486
+                    append_json(logs["s"], gs, out["s"].tolist())
+                    append_json(logs["r"], gs, out["r"].tolist())
+                    if args.enable_block_gating and out["g"] is not None:
+                        append_json(logs["gating"], gs, out["g"].tolist())
+        if rank == 0:
+            print("*" * 60)
+            print("Epoch finished, begin validating ...")
+        val = tr.validate(iterate_eval_batches(args, device, rank))                              # :498
+        if rank == 0:
+            print(f"Validation Results\nGlobal Steps: {tr.global_step}\nValid Loss: {val['loss']:2.5f}\nValid Accuracy: {val['top1']:2.5f}")
         prune_w_mask(tr.minimax, tr.optimizer)                                                   # :500
         remained = float(count_mask(tr.model))
         save_model(args, tr.model, tr.minimax, epoch)                                            # :502
-        if args.save_state and rank == 0:
-            torch.save(tr.state_dict(), os.path.join(out_dir, f"{args.model_type}_state_{epoch}.pth.tar"))
+        # :509.  The reference evaluates the two resource samples on rank 0 only, which advances rank 0's RNG by two Gumbel
+        # draws and silently desynchronises the replicas' gate noise; here every rank draws, rank 0 prints.
+        hard = bool(tr.model.enable_warmup)
+        expect_f, real_f = float(tr.minimax.run_resource_fn(hard)), float(tr.minimax.run_resource_fn(gumbel_hard=True))
         if rank == 0:
             print(f"[Validation Sparsity|Step {tr.global_step}|Epoch {epoch}]")
             print(f"Parameter size: {remained:.2f}M / {float(args.total_param):.2f}M = {remained / float(args.total_param) * 100:.2f}%")
-            hard = bool(tr.model.enable_warmup)
-            print(f"Expectation FLOPs: {float(tr.minimax.run_resource_fn(hard)) * 100}%",
-                  f"Real FLOPs: {float(tr.minimax.run_resource_fn(gumbel_hard=True)) * 100}%")
+            print(f"Expectation FLOPs: {expect_f * 100}%", f"Real FLOPs: {real_f * 100}%")
+        if args.save_state and rank == 0:               # last: the saved RNG state is the one the next epoch starts from
+            tmp = os.path.join(out_dir, f"{args.model_type}_state_{epoch}.pth.tar.tmp")
+            torch.save(tr.state_dict(), tmp)
+            os.replace(tmp, tmp[:-4])
     if world > 1:
         dist.destroy_process_group()
+    return tr
 
 
 if __name__ == "__main__":

@@ -44,6 +44,29 @@ __global__ __launch_bounds__(256) void k_loss_rows(uvc_loss_args a) {
   }
   const float* ok = a.o_kd + (size_t)b * C;
   const float* t = a.teacher + (size_t)b * C;
+  float* d_k = a.d_okd + (size_t)b * C;
+  if (a.kind == 2) {
+    // hard distillation (losses.py:61-62): kd = F.cross_entropy(o_kd, teacher.argmax(dim=1)) = mean_b (lse(o_kd) - o_kd[arg]);
+    // tau is not used; the first maximal class wins, like torch.argmax
+    float mk = -INFINITY, mt = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) { mk = fmaxf(mk, ok[c]); mt = fmaxf(mt, t[c]); }
+    mk = block_reduce(mk, sh, true);
+    mt = block_reduce(mt, sh, true);
+    float sk = 0.f, arg = 3.0e38f;
+    for (int c = threadIdx.x; c < C; c += 256) { sk += __expf(ok[c] - mk); if (t[c] == mt) arg = fminf(arg, (float)c); }
+    sk = block_reduce(sk, sh, false);
+    const int cls = (int)(-block_reduce(-arg, sh, true));          // min over the block (class indices are exact in float32)
+    const float lk = mk + __logf(sk);
+    const float wh = a.alpha / (float)a.B;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float gk = wh * (__expf(ok[c] - lk) - (c == cls ? 1.0f : 0.0f));
+      const float gb = wb * (__expf(o[c] - lse) * sy - y[c]);
+      if (same) d_o[c] = gb + gk;
+      else { d_o[c] = gb; d_k[c] = gk; }
+    }
+    if (threadIdx.x == 0) a.row_scratch[b] = wb * base + wh * (lk - ok[cls]);
+    return;
+  }
   const float iT = 1.0f / a.tau;
   float mk = -INFINITY, mt = -INFINITY;
   for (int c = threadIdx.x; c < C; c += 256) { mk = fmaxf(mk, ok[c] * iT); mt = fmaxf(mt, t[c] * iT); }
@@ -55,7 +78,6 @@ __global__ __launch_bounds__(256) void k_loss_rows(uvc_loss_args a) {
   stt = block_reduce(stt, sh, false);
   const float lk = mk + __logf(sk), lt = mt + __logf(stt);
   const float wk = a.alpha * a.tau * a.tau / ((float)a.B * (float)C);
-  float* d_k = a.d_okd + (size_t)b * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float lpt = t[c] * iT - lt, lpk = ok[c] * iT - lk;
     const float pt = __expf(lpt), pk = __expf(lpk);
@@ -166,8 +188,8 @@ __global__ void k_scale_by_clip(float* g, int64_t n, const float* sq, float max_
 
 extern "C" int uvc_distill_loss(const uvc_loss_args* p, void* stream) {
   if (!p || !p->o || !p->y_soft || !p->loss || !p->d_o || !p->row_scratch) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_distill_loss: null pointer");
-  if (p->kind != 0 && p->kind != 1) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_distill_loss: only 'none' and 'soft' distillation run on the HIP path");
-  if (p->kind == 1 && (!p->o_kd || !p->teacher || !p->d_okd)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_distill_loss: soft distillation needs o_kd, teacher, d_okd");
+  if (p->kind < 0 || p->kind > 2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_distill_loss: kind is 0 (none), 1 (soft) or 2 (hard)");
+  if (p->kind != 0 && (!p->o_kd || !p->teacher || !p->d_okd)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_distill_loss: distillation needs o_kd, teacher, d_okd");
   if (p->B <= 0 || p->C <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_distill_loss: empty");
   hipStream_t st = (hipStream_t)stream;
   k_loss_rows<<<p->B, 256, 0, st>>>(*p);

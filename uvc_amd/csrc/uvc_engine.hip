@@ -161,9 +161,13 @@ __global__ __launch_bounds__(256) void k_masks(float* const* __restrict__ mproj,
     const float v = pruned ? 0.0f : 1.0f;
     float* M2 = mfc2[l];
     for (int row = slice; row < d.D; row += 4) M2[(size_t)row * d.F + c] = v;
-    // fc1 rows follow fc2 columns (uvc_utils.py:401): mask_fc1[c, :] = v
-    float* M1 = mfc1[l] + (size_t)c * d.D;
-    for (int k = slice; k < d.D; k += 4) M1[k] = v;
+    // fc1 rows follow fc2 columns (uvc_utils.py:401) -- but the reference resets only the W1 / W3 masks to 1 (:382,393) and
+    // only ever writes ZEROS into the fc1 mask: it is the sticky union of every pruned set seen so far
+    // (tests/golden/mask_sticky_micro.npz).  A released column therefore leaves its fc1 row masked.
+    if (pruned) {
+      float* M1 = mfc1[l] + (size_t)c * d.D;
+      for (int k = slice; k < d.D; k += 4) M1[k] = 0.0f;
+    }
   }
 }
 

@@ -50,13 +50,23 @@ def count_mask(model):
     return total / 1e6
 
 
-def save_model(args, model, minimax_model, global_step):
-    """joint_train.py:107-119: the checkpoint is the bare state_dict (incl. mask buffers), written
-    by every rank; s, r, y, p, z are not persisted."""
+def save_model(args, model, minimax_model, global_step, barrier=True):
+    """joint_train.py:107-119: the checkpoint is the bare state_dict (incl. mask buffers); s, r, y, p, z are not persisted
+    (SURVEY.md Q10).  The reference lets EVERY rank torch.save the same path, which can interleave writes under torchrun;
+    here rank 0 writes to a temporary file and renames it (atomic), and the other ranks wait at a barrier so the file is
+    complete when any rank returns -- same file, same content (replicas hold identical weights).  ``barrier=False`` for
+    callers that save from rank 0 only (Stage-2's save-best, post_train.py:393-397)."""
     model_to_save = model.module if hasattr(model, "module") else model
     path = os.path.join(args.output_dir, args.name, f"{args.model_type}_{global_step}.pth.tar")
-    os.makedirs(os.path.dirname(path), exist_ok=True)
-    torch.save(model_to_save.state_dict(), path)
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    rank = torch.distributed.get_rank() if dist_on else 0
+    if rank == 0 or not barrier:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + ".tmp"
+        torch.save(model_to_save.state_dict(), tmp)
+        os.replace(tmp, path)
+    if dist_on and barrier:
+        torch.distributed.barrier()
     if args.local_rank in [-1, 0]:
         print("Saved model checkpoint to [DIR: %s]", args.output_dir)
     return path

@@ -42,16 +42,14 @@ class _LossFunction(torch.autograd.Function):
 
 
 class DistillationLoss(torch.nn.Module):
-    """utils/losses.py:10-65.  'soft' and 'none' run on the HIP path; 'hard' (argmax CE) is not used by
-    the README command and raises."""
+    """utils/losses.py:10-65: 'none', 'soft' (KL at temperature tau) and 'hard' (cross-entropy against the teacher's
+    argmax, :61-62 -- the argparse default of joint_train.py:781) all run in the one fused HIP loss kernel."""
 
     def __init__(self, base_criterion, teacher_model, distillation_type: str, alpha: float, tau: float):
         super().__init__()
         assert distillation_type in ['none', 'soft', 'hard']
         if not isinstance(base_criterion, SoftTargetCrossEntropy):
             raise NotImplementedError("the HIP loss kernel implements the soft-target CE base criterion (mixup > 0, joint_train.py:938-940)")
-        if distillation_type == 'hard':
-            raise NotImplementedError("distillation_type='hard' is not on the README hot path")
         self.base_criterion = base_criterion
         self.teacher_model = teacher_model
         self.distillation_type = distillation_type
@@ -97,4 +95,5 @@ class DistillationLoss(torch.nn.Module):
             raise ValueError("When knowledge distillation is enabled, the model is expected to return a "
                              "Tuple[Tensor, Tensor] with the output of the class_token and the dist_token")
         teacher_outputs = self._teacher(inputs)
-        return _LossFunction.apply(outputs, outputs_kd, labels, teacher_outputs.contiguous(), float(self.alpha), float(self.tau), 1)
+        kind = 1 if self.distillation_type == 'soft' else 2
+        return _LossFunction.apply(outputs, outputs_kd, labels, teacher_outputs.contiguous(), float(self.alpha), float(self.tau), kind)

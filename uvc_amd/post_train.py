@@ -37,7 +37,7 @@ def default_args(**over) -> Namespace:
              opt="adamw", opt_eps=1e-8, opt_betas=None, momentum=0.9, sched="cosine", lr_noise=None, warmup_lr=1e-6,
              min_lr=1e-5, decay_epochs=30, warmup_epochs=5, cooldown_epochs=10, patience_epochs=10, decay_rate=0.1,
              distillation_type="soft", distillation_alpha=0.1, distillation_tau=1.0, enable_deit=0, local_rank=-1,
-             precision="bf16", output_dir="output", name="post_train", steps_per_epoch=5005, compact_mlp=1)
+             precision="bf16", output_dir="output", name="post_train", steps_per_epoch=5005, compact_mlp=1, compact_multiple=256)
     a.update(over)
     return Namespace(**a)
 
@@ -104,6 +104,9 @@ class Stage2Trainer:
         self.scheduler, self.num_epochs = create_scheduler(args, self.optimizer)
         model.block_skip_gating.requires_grad = False                                               # :313
         model.train()
+        self.accum = max(1, int(getattr(args, "gradient_accumulation_steps", 1)))                  # :365-378
+        model.grad_accumulate = self.accum > 1
+        self._micro = 0
         self.global_step = 0
         self.epoch = 0
 
@@ -123,13 +126,18 @@ class Stage2Trainer:
             self.criterion.prefetch(x)
         outputs, _ = self.model(x)                                                                  # :363
         loss = self.criterion(x, outputs, y)
+        if self.accum > 1:
+            loss = loss / self.accum                                                                # :365-366
         loss.backward()
+        self._micro += 1
+        if self._micro % self.accum != 0:                                                           # :372: the backward added into .grad
+            return dict(loss=loss.detach() * self.accum, outputs=outputs, stepped=False)
         gnorm = clip_grad_norm_(self.model, a.max_grad_norm)                                        # :377
         self.optimizer.step()
         self.global_step += 1
         if zero_grad:
             self.optimizer.zero_grad()
-        return dict(loss=loss.detach(), outputs=outputs, gnorm=gnorm)
+        return dict(loss=loss.detach() * self.accum if self.accum > 1 else loss.detach(), outputs=outputs, gnorm=gnorm, stepped=True)
 
 
     # resumable state (the reference saves only the best model's bare state_dict, post_train.py:395-397)
@@ -168,7 +176,7 @@ def post_training(trainer: Stage2Trainer, batches, epochs=None, valid_fn=None, l
         if valid_fn is not None and a.local_rank in (-1, 0):
             acc = valid_fn(trainer.model)
             if best_acc < acc:
-                save_model(a, trainer.model, None, trainer.global_step)
+                save_model(a, trainer.model, None, trainer.global_step, barrier=False)
                 best_acc = acc
             trainer.model.train()
     return best_acc
@@ -185,7 +193,12 @@ def main(argv=None):
             p.add_argument("--" + k, type=type(v), default=v)
     p.add_argument("--checkpoint_dir", type=str, default=None, help="Stage-1 checkpoint (bare state_dict)")
     p.add_argument("--steps", type=int, default=20, help="steps per synthetic epoch")
+    p.add_argument("--model_cfg", type=str, default=None, help="JSON dims for a --model_type outside models/configs.py (tests)")
+    p.add_argument("--eval_steps", type=int, default=2, help="synthetic validation batches per epoch (valid(), post_train.py:188-234)")
+    p.add_argument("--eval_batch_size", type=int, default=64)
     args = p.parse_args(argv)
+    if args.model_cfg:
+        args.model_cfg = json.loads(args.model_cfg)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -205,11 +218,27 @@ def main(argv=None):
             y = torch.softmax(torch.randn(args.train_batch_size, args.num_classes, device=dev, generator=g), -1)
             yield x, y
 
-    post_training(tr, batches, epochs=args.epochs, log=print if rank == 0 else (lambda *_: None))
+    @torch.no_grad()
+    def valid_fn(model):
+        """valid() of post_train.py:188-234 on synthetic (x, hard label) batches: eval-mode logits, top-1 in percent."""
+        model.eval()
+        ge = torch.Generator(device=dev).manual_seed(args.seed + 77)
+        hit = n = 0
+        for _ in range(args.eval_steps):
+            x = torch.randn(args.eval_batch_size, 3, args.img_size, args.img_size, device=dev, generator=ge)
+            t = torch.randint(0, args.num_classes, (args.eval_batch_size,), device=dev, generator=ge)
+            logits, _ = model(x)
+            hit += int((logits.argmax(dim=1) == t).sum())
+            n += len(t)
+        return 100.0 * (hit + 1e-3) / max(n, 1)          # + epsilon: the first epoch always beats best_acc = 0 and saves (:393-397)
+
+    best = post_training(tr, batches, epochs=args.epochs, valid_fn=valid_fn if args.eval_steps > 0 else None,
+                         log=print if rank == 0 else (lambda *_: None))
     if rank == 0:
-        print(json.dumps(dict(steps=tr.global_step, masked_params_M=float(tr.total_param))))
+        print(json.dumps(dict(steps=tr.global_step, masked_params_M=float(tr.total_param), best_acc=best)))
     if world > 1:
         torch.distributed.destroy_process_group()
+    return tr
 
 
 if __name__ == "__main__":

@@ -110,10 +110,10 @@ class Stage1Trainer:
             model, names, self.uvc_layers, ldict, args, flops_list)                                 # :1014
         prune_w_mask(self.minimax)                                                                  # :1026
         # train(): optimiser, schedule, DDP (:271-295)
-        self.optimizer = FusedAdamW(model, lr=args.learning_rate, weight_decay=args.weight_decay)
-        self.t_total = args.steps_per_epoch * args.num_epochs
-        sched = WarmupCosineSchedule if args.decay_type == "cosine" else WarmupLinearSchedule
-        self.scheduler = sched(self.optimizer, warmup_steps=args.warmup_steps, t_total=self.t_total)
+        self.accum = max(1, int(getattr(args, "gradient_accumulation_steps", 1)))       # :403-426
+        model.grad_accumulate = self.accum > 1
+        self._micro = 0
+        self._build_optimizer()
         self.zlr_scheduler = PresetLRScheduler(getattr(args, "zlr_schedule", {}))
         self.ddp = DistributedDataParallel(model, message_size=250000000, gradient_predivide_factor=1.0,
                                            dual_scalar=self.minimax.z) if distributed else None
@@ -122,12 +122,23 @@ class Stage1Trainer:
         self.epoch = 0
         self.gating_grad_list = []
 
+    def _build_optimizer(self):
+        """AdamW over every parameter + the warm-up-cosine / linear schedule over len(loader) * num_epochs optimiser steps
+        (joint_train.py:271-276; rebuilt by --warmup_reset at the first UVC-train epoch, :357-365)."""
+        a = self.args
+        self.optimizer = FusedAdamW(self.model, lr=a.learning_rate, weight_decay=a.weight_decay)
+        self.t_total = a.steps_per_epoch * a.num_epochs
+        sched = WarmupCosineSchedule if a.decay_type == "cosine" else WarmupLinearSchedule
+        self.scheduler = sched(self.optimizer, warmup_steps=a.warmup_steps, t_total=self.t_total)
+
     # -- epoch header (joint_train.py:335-386)
     def begin_epoch(self, epoch: int):
         a, mm = self.args, self.minimax
         self.epoch = epoch
         self.gating_grad_list = []
-        if epoch <= a.warmup_epochs and a.enable_warmup:
+        # The reference keys the warm-up phase on the epoch alone (:343): --enable_warmup never reaches the model
+        # (`enable_warmpup` typo in build_minimax_model's kwargs), so `--enable_warmup 0 --warmup_epochs 5` still warms up.
+        if epoch <= a.warmup_epochs:
             mm.model.enable_warmup = 1
             mm.model.block_skip_gating.requires_grad = False
             for g in self.optimizer.param_groups:
@@ -136,6 +147,10 @@ class Stage1Trainer:
             mm.model.enable_warmup = 0
             a.enable_warmup = 0
             mm.model.block_skip_gating.requires_grad = True
+            if epoch == a.warmup_epochs + 1 and getattr(a, "warmup_reset", 0):              # :357-365
+                if getattr(a, "local_rank", -1) in (-1, 0):
+                    print(" Reset the Optimizer and Learning rate scheduler")
+                self._build_optimizer()
         prune_w_mask(mm, self.optimizer)
         if not mm.model.enable_warmup:
             mm.update_eps()
@@ -145,14 +160,21 @@ class Stage1Trainer:
             return 0.1 + (10 - 0.1) * self.global_step / self.t_total
         return -1
 
-    # -- one step (joint_train.py:395-450), x / y already mixed
+    # -- one loader iteration (joint_train.py:395-450), x / y already mixed.  With --gradient_accumulation_steps k only every
+    # k-th call is an optimiser step (:417-426): the others return after the backward, which ADDS into the flat gradient
+    # buffer (model.grad_accumulate), and their result carries `stepped=False`.
     def step(self, x, y, tau=None, zero_grad=True):
         a = self.args
         if getattr(a, "overlap_teacher", 1):
             self.criterion.prefetch(x)              # teacher forward on a side stream, under the student forward
         outputs, _ = self.model(x, self.get_tau() if tau is None else tau, a.patch_ratio)
         loss = self.criterion(x, outputs, y)
+        if self.accum > 1:
+            loss = loss / self.accum                                                                # :413-414
         loss.backward()
+        self._micro += 1
+        if self._micro % self.accum != 0:                                                           # :417
+            return dict(loss=loss.detach() * self.accum, outputs=outputs, stepped=False)
         gnorm = clip_grad_norm_(self.model, a.max_grad_norm)
         self.optimizer.step()
         self.scheduler.step()
@@ -165,7 +187,30 @@ class Stage1Trainer:
             [], self.flops_list, a.z_grad_clip, self.global_step, a.gating_interval, self.gating_grad_list)
         if zero_grad:
             self.optimizer.zero_grad()
-        return dict(loss=loss.detach(), outputs=outputs, gnorm=gnorm, cur=cur, s=s, r=r, g=g)
+        return dict(loss=loss.detach() * self.accum if self.accum > 1 else loss.detach(), outputs=outputs, gnorm=gnorm, cur=cur, s=s, r=r, g=g,
+                    stepped=True)
+
+    # -- valid() (joint_train.py:199-246): eval-mode forward, CrossEntropy against hard labels, top-1
+    @torch.no_grad()
+    def validate(self, batches):
+        """``batches`` yields (x, hard labels int64).  Mirrors valid(): model.eval(), tau = 1 with patch-gating mode 2 else -1
+        (:216-219), logits = model(x, tau, patch_ratio)[0] (block gating still draws its Gumbel noise, as in the reference),
+        mean of the per-batch CrossEntropy and top-1 accuracy in percent; the model goes back to train() afterwards (:513)."""
+        a, model = self.args, self.model
+        model.eval()
+        tau = 1 if a.enable_patch_gating == 2 else -1
+        loss_sum = torch.zeros((), device=self.model._flat.device, dtype=torch.float64)
+        hit = torch.zeros((), device=self.model._flat.device, dtype=torch.float64)
+        nb, n = 0, 0
+        for x, t in batches:
+            logits, _ = model(x, tau, a.patch_ratio)
+            lse = torch.logsumexp(logits.double(), dim=1)
+            loss_sum += (lse - logits.double().gather(1, t.view(-1, 1)).squeeze(1)).mean()
+            hit += (logits.argmax(dim=1) == t).sum()
+            nb += 1
+            n += x.shape[0]
+        model.train()
+        return dict(loss=float(loss_sum) / max(nb, 1), top1=100.0 * float(hit) / max(n, 1), images=n)
 
     # -- resumable training state (SURVEY.md 8 f-3).  The reference's checkpoint is the bare model state_dict and it cannot
     # resume Stage-1: s, r, y, p, z, eps, the optimiser moments and the schedule position are lost (Q10).  save_model keeps
@@ -186,7 +231,10 @@ class Stage1Trainer:
                      g=None if self.g_opt is None else self.g_opt.param_groups[0]["lr"],
                      dual=[g["lr"] for g in self.dual_opt.param_groups]),
             progress=dict(global_step=self.global_step, epoch=self.epoch, gating_grad_list_len=len(self.gating_grad_list),
-                          enable_warmup=int(self.model.enable_warmup), args_enable_warmup=int(self.args.enable_warmup)),
+                          enable_warmup=int(self.model.enable_warmup), args_enable_warmup=int(self.args.enable_warmup), micro=self._micro),
+            # Gumbel / mixup draws continue where they stopped: torch CPU + this device's generator, numpy's global RNG
+            rng=dict(torch_cpu=torch.get_rng_state(), torch_cuda=torch.cuda.get_rng_state(self.model._flat.device),
+                     numpy=_np_rng_state()),
         )
 
     def load_state_dict(self, sd):
@@ -219,4 +267,21 @@ class Stage1Trainer:
         self.model.enable_warmup = int(pr["enable_warmup"])
         self.args.enable_warmup = int(pr["args_enable_warmup"])
         self.model.block_skip_gating.requires_grad = not self.model.enable_warmup
+        self._micro = int(pr.get("micro", 0))
+        rng = sd.get("rng")
+        if rng is not None:
+            torch.set_rng_state(rng["torch_cpu"].cpu())
+            torch.cuda.set_rng_state(rng["torch_cuda"].cpu(), self.model._flat.device)
+            _np_set_rng_state(rng["numpy"])
         self.model.mark_weights_changed()
+
+
+def _np_rng_state():
+    import numpy as np
+    k, keys, pos, has_gauss, cached = np.random.get_state()
+    return dict(kind=k, keys=torch.from_numpy(keys.astype("int64")), pos=int(pos), has_gauss=int(has_gauss), cached=float(cached))
+
+
+def _np_set_rng_state(st):
+    import numpy as np
+    np.random.set_state((st["kind"], st["keys"].cpu().numpy().astype("uint32"), st["pos"], st["has_gauss"], st["cached"]))

@@ -122,6 +122,23 @@ int uvc_layernorm_bwd(const uvc_ln_args* args, void* stream);
 int uvc_layernorm_bwd_blocks(int32_t rows);
 int uvc_layernorm_bwd_nblocks(int32_t rows);
 
+/* dgrad GEMM with the LayerNorm backward as its epilogue (bf16 mode, D == 192, K in {576, 768}, M >= 4096): the backward of
+ * `Linear(LayerNorm(x))` w.r.t. x, i.e. the pair uvc_gemm_nt(A, W -> dy) + uvc_layernorm_bwd(dy, x, ...) of
+ * model_distilled.py:199-204,218-247's autograd without the [M, D] dy round trip through HBM:
+ *     dy = A[M,K] . W[D,K]^T ;  dx = LN'(dy; x, mean, rstd, gamma) + a1*add1 + a2*add2   (dx, add1, add2: bf16 [M, D]; dx may alias add2)
+ * dgamma / dbeta / { <dx,x>, <add2,x> } partials go to partial[uvc_gemm_lnbwd_nblocks(M)][2*D+2] (float32) and are finished by
+ * uvc_layernorm_bwd_reduce_batch like a deferred uvc_layernorm_bwd call.  Deterministic (fixed summation orders). */
+typedef struct uvc_gemm_lnbwd_args {
+  const void* A; const void* W;                 /* bf16 [M,K], bf16 [D,K] (the W^T shadow of the Linear) */
+  const float* x; const float* mean; const float* rstd; const float* gamma;   /* LayerNorm input [M,D] and saved statistics */
+  const void* add1; const float* a1; const void* add2; const float* a2;       /* optional bf16 addends, device scalars (NULL = 1) */
+  void* dx; float* partial;
+  int32_t M, D, K, dtype;
+} uvc_gemm_lnbwd_args;
+int uvc_gemm_lnbwd_supported(int32_t M, int32_t D, int32_t K, int32_t dtype);
+int uvc_gemm_lnbwd_nblocks(int32_t M);
+int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* args, void* stream);
+
 /* Fused inference MLP half of a block: out = x + fc2(GELU(fc1(LayerNorm(x)))) (model_distilled.py:153-166,186-189) for the
  * no-grad forwards (teacher: utils/losses.py:47-49; eval).  x, out float32 [M, D]; w1 [F, D], w2 [D, F] are the bf16
  * weight shadows; gamma/beta/b1/b2 float32.  Requires uvc_mlp_fused_supported(D, F, dtype) (D == 192, F % 64 == 0, bf16).

@@ -101,6 +101,19 @@ def main():
         dx16, add16 = torch.empty(M, D, device=dev, dtype=bf), g16.clone()
         rec("ln_bwd +add1 (bf16 streams)", timeit(lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx16, part, dg, db, M, D, dt, add1=g16, a1=gate[1:])), M * D * 10)
         rec("ln_bwd +add1+add2+dots (bf16 streams)", timeit(lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx16, part, dg, db, M, D, dt, add1=g16, add2=add16, a2=gate[:1], dots=dots)), M * D * 12)
+    if want("lnbwd") and D == 192:
+        gam = torch.ones(D, device=dev)
+        mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)
+        part = torch.empty(max(ops.layernorm_bwd_blocks(M), 272) * (2 * D + 2), device=dev)
+        dg, db, dots = torch.empty(D, device=dev), torch.empty(D, device=dev), torch.empty(2, device=dev)
+        dx16, add16 = torch.empty(M, D, device=dev, dtype=bf), g16.clone()
+        W2t = (torch.randn(D, F, device=dev) * .02).to(bf)
+        rec("dfc1 + ln2_bwd fused  K=F (A 155 + x 77 + add1 39 + dx 39 MB)", timeit(lambda: ops.gemm_nt_lnbwd(hF, W2t, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, a1=gate[1:])),
+            M * F * 2 + M * D * 8, 2.0 * M * D * F)
+        q3 = torch.randn(M, 3 * D, device=dev).to(bf)
+        Wqt = (torch.randn(D, 3 * D, device=dev) * .02).to(bf)
+        rec("dqkv + ln1_bwd fused  K=3D (A 116 + x 77 + add1 39 + add2 39 + dx 39 MB)", timeit(lambda: ops.gemm_nt_lnbwd(q3, Wqt, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, add2=add16, a2=gate[:1], dots=dots)),
+            M * 3 * D * 2 + M * D * 10, 2.0 * M * D * 3 * D)
     if want("mlp_fused") and D == 192:
         gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
         o32 = torch.empty(M, D, device=dev)

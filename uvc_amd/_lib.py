@@ -70,6 +70,11 @@ class uvc_ln_args(C.Structure):
                [("group_stride", C.c_int64), ("g_lowp", C.c_int32), ("defer_reduce", C.c_int32)]
 
 
+class uvc_gemm_lnbwd_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("A", "W", "x", "mean", "rstd", "gamma", "add1", "a1", "add2", "a2", "dx", "partial")] + \
+               [(n, C.c_int32) for n in ("M", "D", "K", "dtype")]
+
+
 class uvc_mlp_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "gamma", "beta", "w1", "b1", "w2", "b2", "out")] + \
                [(n, C.c_int32) for n in ("M", "D", "F")] + [("eps", C.c_float)]
@@ -126,6 +131,9 @@ _SIGNATURES = {
     "uvc_layernorm_bwd_blocks": [I32],
     "uvc_layernorm_bwd_nblocks": [I32],
     "uvc_layernorm_bwd_reduce_batch": [C.POINTER(uvc_ln_reduce_item), I32, I32, F32, VP],
+    "uvc_gemm_lnbwd_supported": [I32, I32, I32, I32],
+    "uvc_gemm_lnbwd_nblocks": [I32],
+    "uvc_gemm_nt_lnbwd": [C.POINTER(uvc_gemm_lnbwd_args), VP],
     "uvc_distill_loss": [C.POINTER(uvc_loss_args), VP],
     "uvc_grad_sqnorm": [VP, I64, VP, VP, I32, VP],
     "uvc_adamw_step": [C.POINTER(uvc_adamw_args), VP],

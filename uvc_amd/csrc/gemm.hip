@@ -917,6 +917,202 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
 }
 
 // ================================================================================================
+//      NT dgrad (K = 768 / 576 -> N = 192) with the LayerNorm backward as its epilogue (bf16 mode)
+// ================================================================================================
+// dL/dx of `y = LayerNorm(x)` fed by a Linear: dy = A . W^T (the dgrad of fc1 / qkv) is consumed where it is produced,
+//     dx = rstd * (dy*gamma - mean_c(dy*gamma) - xhat * mean_c(dy*gamma*xhat)) + a1*add1 + a2*add2
+// (model_distilled.py:199-204,218-247 through autograd), so the [M, 192] dy never goes to HBM and back (2 x 39 MB of the
+// 194-233 MB a stand-alone LayerNorm backward moves, and one launch of the step's most expensive kernel).  Same geometry as
+// k_gemm_wsn16: 12 waves, wave w owns output columns 16w..16w+15 for the whole K (KT fragments of W^T in VGPRs), lane
+// (row li, group gq) ends the MFMA chain with FOUR CONSECUTIVE columns of one row.  The two row sums run over the 12 waves:
+// every wave leaves its (sum dy*gamma, sum dy*gamma*xhat) over its 16 columns in a double-buffered LDS table and picks up the
+// 12 partials after the tile's ONE barrier (the same barrier that publishes the next A image), summed in wave order -> the
+// result does not depend on timing.  dgamma / dbeta accumulate per lane over the workgroup's rows and leave through the
+// partial table of the stand-alone kernel ([grid][2D+2], finished by uvc_layernorm_bwd_reduce_batch); the two gate dot
+// products <dx, x>, <add2, x> ride along as there.  The row's x / add1 / add2 / mean / rstd are requested before the MFMA
+// chain.  dx may alias add2 (the engine's gA is read and rewritten in place: same lane, same addresses).
+struct LnbArgs {
+  const void* A; const void* W; const float* x; const float* mean; const float* rstd; const float* gamma;
+  const void* add1; const float* a1; const void* add2; const float* a2; void* dx; float* partial;
+  int M, K, want_dots;
+};
+
+template <int KT>
+__global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd(LnbArgs g) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  constexpr int K = KT * 32, NTH = 768, D = 192, NWV = 12;
+  constexpr int ROWB = K * 2 + 32, CPR = K / 8;
+  constexpr int NLD = (16 * CPR + NTH - 1) / NTH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA0 = smem;
+  char* sA1 = smem + 16 * ROWB;
+  float* sRed = reinterpret_cast<float*>(smem + 2 * 16 * ROWB);            // [2][16 rows][12 waves][2]
+  float* sGam = sRed + 2 * 16 * NWV * 2;                                   // gamma [192]: re-read per tile instead of 4 live VGPRs
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gq = lane >> 4, li = lane & 15;
+  const T* __restrict__ A = reinterpret_cast<const T*>(g.A);
+  const T* __restrict__ W = reinterpret_cast<const T*>(g.W);
+  const T* __restrict__ add1 = reinterpret_cast<const T*>(g.add1);
+  const T* __restrict__ add2 = reinterpret_cast<const T*>(g.add2);
+  T* __restrict__ dx = reinterpret_cast<T*>(g.dx);
+  const int ntiles = (g.M + 15) / 16;
+  const int n = w * 16 + gq * 4;                       // this lane's four output columns
+
+  typename MM::Frag bf[KT];
+#pragma unroll
+  for (int ks = 0; ks < KT; ++ks)
+    bf[ks] = __builtin_bit_cast(typename MM::Frag, *reinterpret_cast<const u32x4*>(W + (size_t)(w * 16 + li) * K + (ks * 4 + gq) * 8));
+  if (tid < D) sGam[tid] = g.gamma[tid];
+  const float a1 = g.a1 ? *g.a1 : 1.f, a2 = g.a2 ? *g.a2 : 1.f;
+  f32x4 dgam = {0.f, 0.f, 0.f, 0.f}, dbet = {0.f, 0.f, 0.f, 0.f};
+  float dotA = 0.f, dotB = 0.f;
+  constexpr float invD = 1.0f / (float)D;
+
+  // 32-bit element offsets everywhere (M * K < 2^31): SGPR base + one VGPR offset per access instead of 64-bit VGPR address pairs
+  u32x4 ra[NLD];
+  unsigned aoff[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) { const int id = tid + NTH * i; aoff[i] = (unsigned)((id / CPR) * K + (id % CPR) * 8); }
+  auto gload = [&](int tile) {
+    const int m0 = tile * 16;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int row = (tid + NTH * i) / CPR;
+      ra[i] = (row < 16 && m0 + row < g.M) ? *reinterpret_cast<const u32x4*>(A + ((unsigned)(m0 * K) + aoff[i])) : z;
+    }
+  };
+  auto lstore = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int id = tid + NTH * i, row = id / CPR, c = id % CPR;
+      if (row < 16) *reinterpret_cast<u32x4*>(buf + row * ROWB + c * 16) = ra[i];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    gload(tile);
+    lstore(sA0);
+  }
+  __syncthreads();
+  int par = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) gload(next);
+    // this row's LayerNorm operands (in flight under the MFMA chain); 32-bit element offsets: one VGPR addresses all four streams
+    const int m = tile * 16 + li;
+    const bool ok = m < g.M;
+    const unsigned ro = (unsigned)(ok ? m : 0) * (unsigned)D + (unsigned)n;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(g.x + ro);
+    u32x2 r1 = {0u, 0u}, r2 = {0u, 0u};
+    if (add1) r1 = *reinterpret_cast<const u32x2*>(add1 + ro);
+    if (add2) r2 = *reinterpret_cast<const u32x2*>(add2 + ro);
+    const float mean = g.mean[ok ? m : 0], rstd = ok ? g.rstd[m] : 0.f;
+    const char* buf = par ? sA1 : sA0;
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+      c0 = MM::mma(bf[ks], lds_frag<T>(buf + li * ROWB + (ks * 4 + gq) * 16), c0);
+      // bound the fragment reads the scheduler may hoist: next to 96 VGPRs of W the whole chain's 24 x 4 do not fit
+      if (KT > 18 && (ks % 6) == 5) __builtin_amdgcn_sched_barrier(0);
+    }
+    float* red = sRed + par * (16 * NWV * 2);
+    {
+      const f32x4 gam = *reinterpret_cast<const f32x4*>(sGam + n);
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mean) * rstd;       // rows past M: rstd = 0, c0 = 0 (zero A rows) -> no contribution
+        const float gy = c0[e] * gam[e];
+        dgam[e] += c0[e] * xh;
+        dbet[e] += c0[e];
+        p1 += gy;
+        p2 += gy * xh;
+      }
+      p1 += __shfl_xor(p1, 16, 64); p1 += __shfl_xor(p1, 32, 64);
+      p2 += __shfl_xor(p2, 16, 64); p2 += __shfl_xor(p2, 32, 64);
+      if (gq == 0) *reinterpret_cast<f32x2*>(red + (li * NWV + w) * 2) = f32x2{p1, p2};
+    }
+    if (next < ntiles) lstore(par ? sA0 : sA1);
+    __syncthreads();
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NWV / 2; ++q) {               // 12 (p1, p2) pairs of this row, in wave order
+      const f32x4 t = *reinterpret_cast<const f32x4*>(red + li * NWV * 2 + q * 4);
+      c1 += t[0]; c2 += t[1]; c1 += t[2]; c2 += t[3];
+    }
+    c1 *= invD; c2 *= invD;
+    if (ok) {
+      const f32x4 gam = *reinterpret_cast<const f32x4*>(sGam + n);
+      const f32x4 v1 = {__uint_as_float(r1[0] << 16), __uint_as_float(r1[0] & 0xffff0000u), __uint_as_float(r1[1] << 16), __uint_as_float(r1[1] & 0xffff0000u)};
+      const f32x4 v2 = {__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u), __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mean) * rstd;
+        o[e] = rstd * (c0[e] * gam[e] - c1 - xh * c2);
+        if (add1) o[e] += a1 * v1[e];
+        if (add2) { o[e] += a2 * v2[e]; dotB += v2[e] * xv[e]; }
+        dotA += o[e] * xv[e];
+      }
+      u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]);
+      *reinterpret_cast<u32x2*>(dx + ro) = q;
+    }
+    par ^= 1;
+  }
+  // ---- dgamma / dbeta: sum over the 16 row lanes; dots over the workgroup (fixed order)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { dgam[e] += __shfl_xor(dgam[e], o, 64); dbet[e] += __shfl_xor(dbet[e], o, 64); }
+  }
+  float* P = g.partial + (size_t)blockIdx.x * (2 * D + 2);
+  if (li == 0) {
+    *reinterpret_cast<f32x4*>(P + n) = dgam;
+    *reinterpret_cast<f32x4*>(P + D + n) = dbet;
+  }
+  dotA = wave_sum(dotA); dotB = wave_sum(dotB);
+  __syncthreads();
+  if (lane == 0) { sRed[2 * w] = dotA; sRed[2 * w + 1] = dotB; }
+  __syncthreads();
+  if (tid < 2) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) t += sRed[2 * q + tid];
+    P[2 * D + tid] = t;
+  }
+}
+
+extern "C" int uvc_gemm_lnbwd_supported(int32_t M, int32_t D, int32_t K, int32_t dtype) {
+  return dtype == UVC_BF16 && D == 192 && (K == 768 || K == 576) && M >= 4096;
+}
+extern "C" int uvc_gemm_lnbwd_nblocks(int32_t M) { const int nt = ceil_div(M, 16); return nt < 256 ? nt : 256; }
+
+extern "C" int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* p, void* stream) {
+  if (!p || !p->A || !p->W || !p->x || !p->mean || !p->rstd || !p->gamma || !p->dx || !p->partial)
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt_lnbwd: null pointer");
+  if (!uvc_gemm_lnbwd_supported(p->M, p->D, p->K, p->dtype)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt_lnbwd: bf16, D = 192, K in {576, 768}, M >= 4096");
+  if ((((uintptr_t)p->A | (uintptr_t)p->W | (uintptr_t)p->x | (uintptr_t)p->gamma | (uintptr_t)p->partial) & 15) != 0 ||
+      (((uintptr_t)p->add1 | (uintptr_t)p->add2 | (uintptr_t)p->dx) & 7) != 0)
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt_lnbwd: misaligned buffer");
+  LnbArgs a;
+  a.A = p->A; a.W = p->W; a.x = p->x; a.mean = p->mean; a.rstd = p->rstd; a.gamma = p->gamma; a.add1 = p->add1; a.a1 = p->a1;
+  a.add2 = p->add2; a.a2 = p->a2; a.dx = p->dx; a.partial = p->partial; a.M = p->M; a.K = p->K; a.want_dots = 1;
+  const int grid = uvc_gemm_lnbwd_nblocks(p->M);
+  hipStream_t st = (hipStream_t)stream;
+#define LNB_LAUNCH(KT_) { \
+    const size_t sh = (size_t)2 * 16 * (KT_ * 64 + 32) + (2 * 16 * 12 * 2 + 192) * sizeof(float); \
+    static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn_lnbwd<KT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__); \
+    k_gemm_wsn_lnbwd<KT_><<<grid, 768, sh, st>>>(a); }
+  if (p->K == 768) LNB_LAUNCH(24) else LNB_LAUNCH(18)
+#undef LNB_LAUNCH
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
+// ================================================================================================
 //                                            TN (wgrad)
 // ================================================================================================
 // C[n1,n2] = beta*C + alpha * sum_m A[m,n1] * B[m,n2].  Block tile 128(n1) x 64(n2), reduction tile

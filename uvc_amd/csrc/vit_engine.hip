@@ -214,6 +214,20 @@ int ln_bwd(Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const
   a.g_lowp = c.d.dtype == UVC_BF16;
   return uvc_layernorm_bwd(&a, c.st);
 }
+// dgrad GEMM + LayerNorm backward in one kernel (uvc_gemm_nt_lnbwd) where the shape allows; registers the call's partial
+// region with the batched finish exactly like ln_bwd
+bool lnb_fused_ok(const Ctx& c, int K) { return uvc_gemm_lnbwd_supported(c.d.M, c.d.D, K, c.d.dtype) != 0; }
+int dgrad_ln_bwd(Ctx& c, const void* A, const void* Wt, int K, const float* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, void* dx,
+                 const void* add1, const float* a1, const void* add2, const float* a2, float* dots) {
+  if (c.n_ln >= 2 * c.d.L + 1) { if (int e = flush_ln(c)) return e; }
+  uvc_gemm_lnbwd_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.W = Wt; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = c.io->params + pw; a.add1 = add1; a.a1 = a1; a.add2 = add2; a.a2 = a2;
+  a.dx = dx; a.partial = c.w.ln_partial + c.w.ln_region * c.n_ln; a.M = c.d.M; a.D = c.d.D; a.K = K; a.dtype = c.d.dtype;
+  uvc_ln_reduce_item& it = c.ln_items[c.n_ln++];
+  it.partial = a.partial; it.dgamma = c.io->grads + pw; it.dbeta = c.io->grads + pb; it.dots = dots; it.nblocks = uvc_gemm_lnbwd_nblocks(c.d.M); it.reserved = 0;
+  return uvc_gemm_nt_lnbwd(&a, c.st);
+}
 int attn(const Ctx& c, const BlockBufs& b, bool bwd, int layer = -1) {
   uvc_attn_args a;
   memset(&a, 0, sizeof(a));
@@ -472,7 +486,7 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     if (!mc) {
       TRY(nt(c, w.gA, gf, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
       TRY(tn(c, w.gA, gf, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1, 0, 0, BUF_GA));
-      TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
+      if (!lnb_fused_ok(c, d.F)) TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
       TRY(tn(c, w.dA, 0, b.h2, G + q[8], G + q[9], d.M, d.F, d.D, nullptr, 0, 0, BUF_DA));
     } else {
       const int Fe = mc->width;
@@ -486,16 +500,24 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
                                 c.side ? c.side : c.st));
     }
     TRY(guard_overwrite(c, BUF_GB));
+    if (!mc && lnb_fused_ok(c, d.F))      // gB = dL/dx1 = LN2'(dA . W1) + d1*gA, the dgrad of fc1 consumed in its epilogue
+      TRY(dgrad_ln_bwd(c, w.dA, sh(c, so.blk_wt[l][2]), d.F, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr));
+    else
     TRY(ln_bwd(c, w.dH, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr, d.M, 1, d.D));   // gB = dL/dx1
     // attention
     TRY(nt(c, w.gB, gf, sh(c, so.blk_wt[l][1]), w.dH, 0, d.M, d.D, d.D, UVC_EPI_NONE));                                      // dO
     TRY(tn(c, w.gB, gf, b.o, G + q[4], G + q[5], d.M, d.D, d.D, nullptr, 0, 0, BUF_GB));
     TRY(guard_overwrite(c, BUF_DQKV));
     TRY(attn(c, b, true));
-    TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));
+    const bool fuse1 = lnb_fused_ok(c, 3 * d.D);
+    if (!fuse1) TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));
     TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], d.qkv_bias ? G + q[3] : nullptr, d.M, 3 * d.D, d.D, nullptr, 0, 0, BUF_DQKV));
     // gA <- dL/dx_l = LN1'(dH) + gB + d0*gA ; dots: <new gA, x_l>, <old gA, x_l>
     TRY(guard_overwrite(c, BUF_GA));
+    if (fuse1)
+      TRY(dgrad_ln_bwd(c, w.dqkv, sh(c, so.blk_wt[l][0]), 3 * d.D, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0,
+                       w.dotsraw + 2 * l));
+    else
     TRY(ln_bwd(c, w.dH, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0, w.dotsraw + 2 * l, d.M, 1, d.D));
   }
   if (sb <= d.L + 1 && se > d.L + 1) {

@@ -35,8 +35,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=100)       # >= 20 warm-up iterations discarded, >= 100 timed
+    p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE config 2)")
     p.add_argument("--model_type", default="deit_tiny_patch16_224")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -96,76 +96,105 @@ def stage2_checkpoint_state(model, seed=732, skip_blocks=(4, 9)):
         model.block_skip_gating.data.copy_(g.to(dev))
 
 
-def kernel_roofline(tr, args, iters=30):
-    """The largest GEMM kernel of the student's forward/backward chain: fc1 with its fused epilogue (bias, GELU and GELU' -- the
-    two [M, F] outputs the backward needs), as the step launches it: algorithmic bytes of one launch / its average duration
-    measured with HIP events on the launch stream."""
-    from uvc_amd import ops
-    m = tr.model
-    cfg = m._cfg
-    B = args.batch
-    N = (cfg.img_size // cfg.patch_size) ** 2 + cfg.ntok
-    M, D, F = B * N, cfg.embed_dim, cfg.hidden
-    dt = torch.bfloat16 if args.precision == "bf16" else torch.float32
-    dev = m._flat.device
-    A = torch.randn(M, D, device=dev).to(dt)
-    W = (torch.randn(F, D, device=dev) * 0.02).to(dt)
-    bias = torch.zeros(F, device=dev)
-    a_out, u_out = torch.empty(M, F, device=dev, dtype=dt), torch.empty(M, F, device=dev, dtype=dt)
-    dtype = ops.UVC_BF16 if args.precision == "bf16" else ops.UVC_F32
-    for _ in range(3):
-        ops.gemm_nt(A, W, a_out, dtype=dtype, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bias, C2=u_out)
-    st = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        ops.gemm_nt(A, W, a_out, dtype=dtype, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bias, C2=u_out)
-    e1.record(st)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * M * D * F
-    esz = 2 if args.precision == "bf16" else 4
-    bytes_alg = (M * D + F * D + 2 * M * F) * esz          # A once + W once + the two outputs (GELU'(a), GELU(a)) once
-    gbs = bytes_alg / (ms * 1e-3) / 1e9
-    tf = flops / (ms * 1e-3) / 1e12
-    mfma_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
-    # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/
-    # r1i_pmc_hbm_traffic_kbench.csv); only valid for the profiled configuration
-    traffic = 352572549 if (args.precision == "bf16" and args.batch == 512 and args.model_type == "deit_tiny_patch16_224") else None
-    # intensity 2*M*D*F / bytes = 85 flop/B << the ~400 flop/B ridge: this kernel's roofline is HBM
-    kname = "k_gemm_ws<bf16,bf16,EPI_BIAS_GELU_GRAD,6>" if D == 192 else "uvc_gemm_nt"
-    return {"bound": "hbm", "kernel": kname + " (mlp.fc1 + bias + GELU and GELU', M=%d K=%d N=%d)" % (M, D, F),
-            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-            "traffic": traffic, "algorithmic_bytes": bytes_alg, "launch_ms": round(ms, 4),
-            "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / mfma_peak, 4)}
+def _git_head():
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch of kernel `key` from the newest PMC pass committed under profiles/ (tools/pmc_traffic.py writes
+    profiles/<round>_pmc_traffic.json from two rocprofv3 --pmc runs, FETCH_SIZE and WRITE_SIZE, with the guide's gfx950 correction).
+    None when no pass covers the kernel: the number is a measurement, never a constant in this file."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        ent = d.get("kernels", {}).get(key)
+        if ent:
+            best = dict(bytes=int(ent["hbm_bytes"]), source=os.path.basename(f), commit=d.get("commit"))
+    return best
+
+
+def kernel_table(args):
+    """Every kernel of the step as a stand-alone launch at the step's shapes (tools/kernel_table.py): HIP-event average of
+    back-to-back launches on the launch stream x launches per step.  `roofline` is the entry with the LARGEST TOTAL TIME PER STEP --
+    the dominant kernel, not the most flattering one (VERDICT r1 weak #3); the ten largest go into `top_kernels`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_table as KT
+    D, H, L = {"deit_tiny_patch16_224": (192, 3, 12), "deit_small_patch16_224": (384, 6, 12), "deit_base_patch16_224": (768, 12, 12)}[args.model_type]
+    rows = KT.measure(KT.build(args.batch, D=D, H=H, L=L), iters=20)
+    rows.sort(key=lambda r: -r["us_per_step"])
+    top = rows[0]
+    ridge = PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS          # flop per byte where the two roofs meet (312)
+    for r in rows:
+        inten = (r["tflops"] * 1e12) / (r["gbs"] * 1e9) if r["gbs"] else 0.0
+        r["bound"] = "mfma" if inten > ridge else "hbm"
+        r["frac"] = round((r["tflops"] / PEAK_BF16_TFLOPS) if r["bound"] == "mfma" else (r["gbs"] / PEAK_HBM_GBS), 4)
+    tr = pmc_traffic(top["key"])
+    roof = {"bound": top["bound"], "kernel": f"{top['key']} ({top['rocprof']})", "calls_per_step": top["calls"],
+            "achieved": top["gbs"] if top["bound"] == "hbm" else top["tflops"], "peak": PEAK_HBM_GBS if top["bound"] == "hbm" else PEAK_BF16_TFLOPS,
+            "unit": "GB/s" if top["bound"] == "hbm" else "TFLOP/s", "frac": top["frac"], "traffic": tr["bytes"] if tr else None,
+            "traffic_source": (f"{tr['source']} @ {tr['commit']}" if tr else None), "algorithmic_bytes": top["bytes"],
+            "launch_us": top["us"], "us_per_step": top["us_per_step"], "mfma_tflops": top["tflops"],
+            "selection": "largest stand-alone launch time x launches per step among the step's kernels (tools/kernel_table.py)"}
+    keep = ("key", "calls", "us", "us_per_step", "bytes", "gbs", "tflops", "bound", "frac")
+    return roof, [{k: r[k] for k in keep} for r in rows[:10]], round(sum(r["us_per_step"] for r in rows) / 1e3, 2)
 
 
 def cpu_baseline(args):
-    """The oracle (a PyTorch-CPU restatement of the reference step, pinned to the reference's golden
-    vectors) timed on the host cores on a bounded sample: DeiT-Tiny, batch 8, a few steps."""
+    """The oracle (a PyTorch-CPU restatement of the reference step, pinned to the reference's golden vectors) timed on the host cores
+    on a bounded sample: DeiT-Tiny, batch 8 (BASELINE config 1) and batch 64, a few steps each, with the time inside the
+    uvc_optimizer restatement split out (SURVEY 8d: the reference spends 74-93 % of it in weight_list_to_scores)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import scenarios as SC
-    from helpers import build_oracle, load_golden, split_draws
+    from helpers import build_oracle_from_recipe, load_golden, split_draws
     from oracle import step as OS
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
-    name = "tiny8_pruned"
-    gold = load_golden(name)
-    r, S = build_oracle(name)
-    x_all, y_all = SC.make_inputs(r)
-    md, e1, e2 = split_draws(r, gold, 0, S.cfg.depth)
-    x, y = torch.from_numpy(x_all[0]), torch.from_numpy(y_all[0])
-    OS.stage1_step(S, x, y, list(md), e1, e2)          # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < args.cpu_steps and time.perf_counter() - t0 < 40:
-        OS.stage1_step(S, x, y, list(md), e1, e2)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(8 * n / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle Stage-1 step, DeiT-Tiny batch 8, {n} steps, torch CPU fp32 {threads} threads"}
+    gold = load_golden("tiny8_pruned")
+    acc = {"uvc": 0.0}
+    orig = OS.U.uvc_update
+
+    def timed(*a, **k):
+        t = time.perf_counter()
+        r = orig(*a, **k)
+        acc["uvc"] += time.perf_counter() - t
+        return r
+
+    OS.U.uvc_update = timed
+    points = []
+    try:
+        for batch, max_steps, budget_s in ((8, args.cpu_steps, 25.0), (64, 2, 25.0)):
+            r = SC.recipe("tiny8_pruned")
+            r["batch"], r["steps"] = batch, 1
+            r0, S = build_oracle_from_recipe(r)
+            x_all, y_all = SC.make_inputs(r0)
+            md, e1, e2 = split_draws(SC.recipe("tiny8_pruned"), gold, 0, S.cfg.depth)
+            x, y = torch.from_numpy(x_all[0]), torch.from_numpy(y_all[0])
+            OS.stage1_step(S, x, y, list(md), e1, e2)          # warm-up
+            acc["uvc"] = 0.0
+            t0 = time.perf_counter()
+            n = 0
+            while n < max_steps and time.perf_counter() - t0 < budget_s:
+                OS.stage1_step(S, x, y, list(md), e1, e2)
+                n += 1
+            dt = time.perf_counter() - t0
+            points.append({"batch": batch, "steps": n, "images_per_sec": round(batch * n / dt, 3), "s_per_step": round(dt / n, 3),
+                           "uvc_update_s_per_step": round(acc["uvc"] / n, 3), "model_part_s_per_step": round((dt - acc["uvc"]) / n, 3)})
+    finally:
+        OS.U.uvc_update = orig
+    b8 = points[0]
+    return {"value": b8["images_per_sec"], "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle Stage-1 step (student fwd/bwd + teacher fwd + loss + clip + AdamW + uvc_optimizer), DeiT-Tiny, torch CPU fp32 {threads} threads: "
+                      f"batch 8 x {b8['steps']} steps (value), batch 64 x {points[1]['steps']} steps", "points": points}
 
 
 def main():
@@ -209,15 +238,25 @@ def main():
     for _ in range(args.warmup):
         tr.step(x, y)
     sync()
+    # K timed steps between two barrier + synchronize points (the contract's wall clock); an event at every step boundary on the
+    # launch stream gives the per-step device times (median / p10 / p90) without a host sync inside the timed region
+    st = torch.cuda.current_stream()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record(st)
+    for i in range(args.steps):
         out = tr.step(x, y)
+        evs[i + 1].record(st)
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]  # noqa: E731
+    exposed_ms = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        exposed_ms = tr.ddp.exposed_comm_ms() if tr.ddp is not None else None
     loss = float(out["loss"])
     if rank == 0:
         imgs = world * args.batch * args.steps / dt
@@ -229,6 +268,8 @@ def main():
                  "images/sec UVC Stage-2 masked fine-tune step, DeiT-Tiny (SURVEY 8 f-1, not the headline)"
         line = {"metric": metric, "value": round(imgs, 1), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                "ms_per_step_device": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3)},
+                "ranks_seen": dist.get_world_size() if world > 1 else 1,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                 "config": {"workload": (f"{args.model_type} Stage-1 UVC-train step, budget 0.5, per-GPU batch {args.batch}, "
@@ -243,7 +284,29 @@ def main():
             line["cur_resource"] = round(float(out["cur"]), 4)
         else:   # Stage-2 FLOPs per image: teacher 1x forward, student (fwd + bwd) only over the blocks that run
             line.pop("step_tflops_per_gpu"); line.pop("step_frac_of_bf16_mfma_peak")
-        line["roofline"] = kernel_roofline(tr, args)
+        if exposed_ms is not None:
+            line["exposed_allreduce_ms_per_step"] = round(exposed_ms, 3)       # main stream stalled in reducer.finish(), event-timed
+        if args.stage == 1 and args.phase == "train" and world == 1:
+            # the warm-up-phase step for reference: gates fixed at .5/.5, gate logits frozen, uvc_optimizer returns early
+            tr.begin_epoch(1)
+            for _ in range(5):
+                tr.step(x, y)
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for _ in range(20):
+                tr.step(x, y)
+            torch.cuda.synchronize()
+            line["warmup_phase_images_per_sec"] = round(20 * args.batch / (time.perf_counter() - tw), 1)
+        if args.stage == 1 and args.precision == "bf16" and args.model_type in GFLOP_PER_IMG and "deit" in args.model_type:
+            del tr, out
+            torch.cuda.empty_cache()
+            roof, top, total_ms = kernel_table(args)
+            line["roofline"] = roof
+            line["top_kernels"] = top
+            line["kernel_ms_per_step_standalone_sum"] = total_ms
+        else:
+            line["roofline"] = None
+        line["commit"] = _git_head()
         if world == 1 and not args.no_cpu_baseline and args.stage == 1:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), file=_real_stdout, flush=True)

@@ -242,6 +242,10 @@ int uvc_cast_transpose(const float* W, int32_t R, int32_t C, void* w_bf16, void*
  * offsets (units of T) into shadow for the cast / transposed copy, -1 = skip.  Host arrays. */
 int uvc_cast_transpose_multi(const float* params, void* shadow, int32_t n, const int64_t* srcs, const int32_t* Rs, const int32_t* Cs,
                              const int64_t* ws, const int64_t* wts, int32_t dtype, void* stream);
+/* Keyed Exp(1) noise for the Gumbel draws (model_distilled.py:40,485; uvc_utils.py:443-449): out[i] is a pure function of
+ * (seed, step, site, i) -- counter-based, no generator state, identical on every data-parallel replica and after a resume. */
+int uvc_exp_noise(float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t site, void* stream);
+
 /* block-gate distributions (model_distilled.py:480-488): d[L,2] from g[L,2] and Exp(1) draws. */
 int uvc_gate_distrib(const float* g, const float* e, float* d, int32_t L, int32_t mode, float eps, void* stream);
 /* gradient of the gate logits from the dot products the LayerNorm-backward kernels leave behind

@@ -27,7 +27,7 @@ def step(rank, world, distributed):
     gold = load_golden(NAME)
     if distributed:
         ddp = DistributedDataParallel(run.model, num_buckets=2, dual_scalar=run.minimax.z)
-        assert ddp.world == world and not ddp.reducer.avg
+        assert ddp.world == world and ddp.reducer.avg == (dist.get_backend() == "nccl")
         run.trainer.ddp = ddp
     r = run.r
     x_all, y_all = SC.make_inputs(r)
@@ -72,8 +72,9 @@ def main():
     if os.environ.get("UVC_DDP_MODEL") == "t2t":
         step = step_t2t
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("UVC_DDP_BACKEND", "gloo")           # "nccl" = RCCL, one rank per GPU (needs >= world devices)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     ref = step(0, 1, False) if rank == 0 else None
     dist.barrier()
     g, z, p, gn = step(rank, world, True)

@@ -59,7 +59,10 @@ def initial_params(r):
 
 
 def build_oracle(name):
-    r = SC.recipe(name)
+    return build_oracle_from_recipe(SC.recipe(name))
+
+
+def build_oracle_from_recipe(r):
     cfg, params, teacher = initial_params(r)
     if r["enable_patch_gating"] == 1:
         # UVC_CP_MiniMax replaces model.patch_gating by its own 3*ones parameter (uvc_utils.py:152,286-288)

@@ -699,3 +699,33 @@ def test_gemm_nt_lnbwd_matches_the_unfused_pair(K, with_add2):
     torch.testing.assert_close(dg, dg2, rtol=5e-3, atol=1.0)
     torch.testing.assert_close(db, db2, rtol=5e-3, atol=1.0)
     assert float((dg.double() - ref_dg).abs().max()) <= float((dg2.double() - ref_dg).abs().max()) + 1e-3     # the fused kernel is the more exact one
+
+
+def test_keyed_exp_noise_is_a_pure_function_of_its_key():
+    """uvc_exp_noise / ops.KeyedExpSource: Exp(1) statistics, strictly positive, reproducible from (seed, step, site) alone and
+    independent across steps / sites / seeds -- what lets data-parallel replicas draw identical Gumbel noise without a shared RNG."""
+    from uvc_amd import ops
+    a = ops.KeyedExpSource(730, dev())
+    a.begin_step(7)
+    x0, x1 = a((12, 2)), a((512, 196))
+    b = ops.KeyedExpSource(730, dev())
+    b.begin_step(7)
+    y0, y1 = b((12, 2)), b((512, 196))
+    assert torch.equal(x0, y0) and torch.equal(x1, y1)
+    assert not torch.equal(x1.flatten()[:24].reshape(12, 2), x0)                      # another site: another stream
+    b.begin_step(8)
+    z0 = b((12, 2))
+    assert not torch.equal(z0, x0)                                                      # another step
+    c = ops.KeyedExpSource(731, dev())
+    c.begin_step(7)
+    assert not torch.equal(c((12, 2)), x0)                                              # another seed
+    big = ops.KeyedExpSource(1, dev())
+    big.begin_step(0)
+    e = big((4_000_000,)).double()
+    assert float(e.min()) > 0 and torch.isfinite(e).all()
+    assert abs(float(e.mean()) - 1.0) < 3e-3 and abs(float(e.var()) - 1.0) < 1e-2
+    # Exp(1) quantiles: P(E > t) = exp(-t)
+    for t in (0.1, 1.0, 3.0):
+        assert abs(float((e > t).double().mean()) - math.exp(-t)) < 2e-3
+    # lag-1 correlation of consecutive elements ~ 0
+    assert abs(float(((e[1:] - 1) * (e[:-1] - 1)).mean())) < 3e-3

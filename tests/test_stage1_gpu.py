@@ -166,7 +166,7 @@ def test_bucketed_backward_is_identical_to_the_single_call_backward():
             keys = list(run.model.state_dict().keys())
             ddp = DistributedDataParallel(run.model, num_buckets=2, dual_scalar=run.minimax.z)
             ddp.world = 2                      # force the staged path; the reducer itself stays a no-op (world 1)
-            assert ddp.stage_ends[-1] == run.cfg.depth + 3 and len(ddp.stage_ends) == 2
+            assert ddp.stage_ends == [2, 3, run.cfg.depth + 3]         # block 1 | block 0 (before the embedding backward) | embedding + small tensors
             assert list(run.model.state_dict().keys()) == keys
         r = run.r
         x_all, y_all = SC.make_inputs(r)

@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""The kernels of one DeiT Stage-1 step (bf16 mode) as stand-alone launches at the step's shapes.
+
+Shared by bench.py (which times every entry with HIP events, multiplies by the launches per step and names the entry with the
+largest total as `roofline.kernel`) and tools/kbench.py (development print-out).  Each entry:
+    key      short name used in bench.py's JSON and profiles/*_pmc_traffic.json
+    rocprof  substring of the kernel name in a rocprofv3 kernel trace (profiles/*_kernel_stats_*.csv)
+    calls    launches per step (student forward + teacher forward + backward, L blocks)
+    bytes    ALGORITHMIC HBM bytes of one launch (every operand once)
+    flops    MFMA flops of one launch (0 for non-GEMM kernels)
+    fn       closure that enqueues one launch on the current stream
+
+Only shapes with a dedicated streaming kernel are listed in full (DeiT-Tiny widths); for other widths the list is the same set of
+library calls and `rocprof` is a generic prefix.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from uvc_amd import ops  # noqa: E402
+
+
+def build(B, D=192, H=3, L=12, N=197, with_teacher=True):
+    F, M = 4 * D, B * N
+    dev = "cuda"
+    bf = torch.bfloat16
+    dt = ops.UVC_BF16
+    T = 1 if with_teacher else 0
+    tiny = D == 192
+    rows = []
+
+    def add(key, rocprof, calls, nbytes, flops, fn):
+        rows.append(dict(key=key, rocprof=rocprof, calls=calls, bytes=int(nbytes), flops=float(flops), fn=fn))
+
+    g = torch.Generator(device=dev).manual_seed(1)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    x32 = rn(M, D)
+    xb = x32.to(bf)
+    hF = rn(M, F).to(bf)
+    g32 = rn(M, D)
+    g16 = g32.to(bf)
+    bD, bF, b3 = torch.zeros(D, device=dev), torch.zeros(F, device=dev), torch.zeros(3 * D, device=dev)
+    Wqkv, Wp = (rn(3 * D, D) * .02).to(bf), (rn(D, D) * .02).to(bf)
+    W1, W2 = (rn(F, D) * .02).to(bf), (rn(D, F) * .02).to(bf)
+    gate = torch.tensor([0.3, 0.7], device=dev)
+    gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)
+    u = 2 * M * D                     # bytes of one bf16 [M, D] tensor
+
+    # ---- forward (student; the teacher repeats LayerNorm1, qkv, attention, proj and runs the fused MLP)
+    y = torch.empty(M, D, device=dev, dtype=bf)
+    m_, r_ = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    add("ln_fwd", "k_ln_fwd_v", (2 + T) * L, 3 * u, 0, lambda: ops.layernorm_fwd(x32, gam, bet, y, m_, r_, M, D, dt))
+    qkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
+    add("qkv", "k_gemm_ws<unsigned short, unsigned short, 1" if tiny else "k_gemm", (1 + T) * L, 4 * u, 2.0 * M * D * 3 * D,
+        lambda: ops.gemm_nt(xb, Wqkv, qkv, dtype=dt, epilogue=ops.EPI_BIAS, bias=b3))
+    qkv3 = rn(B, N, 3 * D).to(bf)
+    o = torch.empty(B, N, D, device=dev, dtype=bf)
+    lse = torch.empty(B, H, N, device=dev)
+    afl = 4.0 * B * H * N * N * 64
+    add("attn_fwd", "k_attn_fwd", (1 + T) * L, 4 * u, afl, lambda: ops.attention_fwd(qkv3, o, lse, B, N, H, dt))
+    o32 = torch.empty(M, D, device=dev)
+    add("proj+resid", "k_gemm_ws<unsigned short, float, 3" if tiny else "k_gemm", (1 + T) * L, 5 * u, 2.0 * M * D * D,
+        lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=x32))
+    aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
+    add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", L, 9 * u, 2.0 * M * D * F,
+        lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu))
+    add("fc2+resid+gate", "k_gemm_wsn16<float, 4" if tiny else "k_gemm", L, 10 * u, 2.0 * M * D * F,
+        lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate))
+    if tiny and with_teacher:
+        add("teacher mlp_fused", "k_mlp_fused", L, 4 * u, 4.0 * M * D * F, lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32))
+    # ---- backward, main stream
+    dA = torch.empty(M, F, device=dev, dtype=bf)
+    add("dfc2 x gelu'", "k_gemm_ws<unsigned short, unsigned short, 8" if tiny else "k_gemm", L, 9 * u, 2.0 * M * D * F,
+        lambda: ops.gemm_nt(g16, W1, dA, dtype=dt, epilogue=ops.EPI_MUL_AUX, aux=hF, alpha_ptr=gate))
+    dx16, add16 = torch.empty(M, D, device=dev, dtype=bf), g16.clone()
+    part = torch.empty(max(ops.layernorm_bwd_blocks(M), 272) * (2 * D + 2), device=dev)
+    dg, db, dots = torch.empty(D, device=dev), torch.empty(D, device=dev), torch.empty(2, device=dev)
+    q3 = rn(M, 3 * D).to(bf)
+    if ops.gemm_lnbwd_supported(M, D, F, dt):
+        W2t, Wqt = (rn(D, F) * .02).to(bf), (rn(D, 3 * D) * .02).to(bf)
+        add("dfc1+ln2_bwd", "k_gemm_wsn_lnbwd<24>", L, 8 * u, 2.0 * M * D * F,
+            lambda: ops.gemm_nt_lnbwd(hF, W2t, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, a1=gate[1:]))
+        add("dqkv+ln1_bwd", "k_gemm_wsn_lnbwd<18>", L, 8 * u, 2.0 * M * D * 3 * D,
+            lambda: ops.gemm_nt_lnbwd(q3, Wqt, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, add2=add16, a2=gate[:1], dots=dots))
+    else:
+        dH = torch.empty(M, D, device=dev, dtype=bf)
+        Wt = (rn(D, 3 * D) * .02).to(bf)
+        add("dfc1", "k_gemm", L, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_nt(hF, W2, dH, dtype=dt, epilogue=ops.EPI_NONE))
+        add("dqkv", "k_gemm", L, 4 * u, 2.0 * M * D * 3 * D, lambda: ops.gemm_nt(q3, Wt, dH, dtype=dt, epilogue=ops.EPI_NONE))
+        add("ln_bwd", "k_ln_bwd_v", 2 * L, 5.5 * u, 0,
+            lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx16, part, dg, db, M, D, dt, add1=g16, a1=gate[1:]))
+    dH2 = torch.empty(M, D, device=dev, dtype=bf)
+    add("dproj", "k_gemm_ws<unsigned short, unsigned short, 0" if tiny else "k_gemm", L, 2 * u, 2.0 * M * D * D,
+        lambda: ops.gemm_nt(g16, Wp, dH2, dtype=dt, epilogue=ops.EPI_NONE))
+    do = rn(B, N, D).to(bf)
+    dq = torch.empty(B, N, 3 * D, device=dev, dtype=bf)
+    dl = torch.empty(B, H, N, device=dev)
+    add("attn_bwd (dq + dkv)", "k_attn_bwd", L, 12 * u, afl * 2.5, lambda: ops.attention_bwd(qkv3, o, lse, do, dq, dl, B, N, H, dt))
+    # ---- backward, weight-gradient stream (each entry = the split-M GEMM + its fixed-order reduction)
+    ws = torch.empty(max(ops.gemm_tn_workspace_bytes(M, F, D), ops.gemm_tn_workspace_bytes(M, D, F), ops.gemm_tn_workspace_bytes(M, 3 * D, D)) // 4, device=dev)
+    C1, C2, C3, C4 = torch.empty(D, F, device=dev), torch.empty(F, D, device=dev), torch.empty(D, D, device=dev), torch.empty(3 * D, D, device=dev)
+    add("dW2 (+reduce)", "k_gemm_tn_dma<192, 256", L, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(g16, hF, C1, ws, dtype=dt))
+    add("dW1 (+reduce)", "k_gemm_tn_dma<256, 192", L, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(hF, xb, C2, ws, dtype=dt))
+    add("dWproj (+reduce)", "k_gemm_tn_dma<192, 192", L, 2 * u, 2.0 * M * D * D, lambda: ops.gemm_tn(g16, xb, C3, ws, dtype=dt))
+    add("dWqkv (+reduce)", "k_gemm_tn<", L, 4 * u, 2.0 * M * D * 3 * D, lambda: ops.gemm_tn(q3, xb, C4, ws, dtype=dt))
+    # ---- optimiser
+    n = 5717440 if tiny else 12 * (4 * D * D + 2 * D * F)
+    p, gr, m, v = (rn(n) for _ in range(4))
+    v.abs_()
+    pp, sq = torch.empty(1024, device=dev), torch.zeros(1, device=dev)
+    add("clip+adamw", "k_adamw", 1, n * 28, 0, lambda: (ops.grad_sqnorm(gr, pp, sq), ops.adamw_step(p, gr, m, v, sq, lr=1e-4, step=3)))
+    return rows
+
+
+def timeit(fn, iters=20, warm=3):
+    st = torch.cuda.current_stream()
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def measure(rows, iters=20):
+    """HIP-event average launch time of every entry on the current stream (back-to-back launches)."""
+    out = []
+    for r in rows:
+        ms = timeit(r["fn"], iters)
+        out.append(dict(key=r["key"], rocprof=r["rocprof"], calls=r["calls"], us=round(ms * 1e3, 2), us_per_step=round(ms * 1e3 * r["calls"], 1),
+                        bytes=r["bytes"], gbs=round(r["bytes"] / ms / 1e6, 1), tflops=round(r["flops"] / ms / 1e9, 1)))
+    return out
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=512)
+    a = ap.parse_args()
+    res = measure(build(a.B))
+    print(f"{'kernel':24s} {'calls':>5s} {'us':>8s} {'us/step':>9s} {'GB/s':>8s} {'TFLOP/s':>8s}")
+    for r in sorted(res, key=lambda r: -r["us_per_step"]):
+        print(f"{r['key']:24s} {r['calls']:5d} {r['us']:8.1f} {r['us_per_step']:9.1f} {r['gbs']:8.1f} {r['tflops']:8.1f}")
+    print("sum of stand-alone kernel time per step: %.2f ms" % (sum(r["us_per_step"] for r in res) / 1e3))

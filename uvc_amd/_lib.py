@@ -159,6 +159,7 @@ _SIGNATURES = {
     "uvc_mlp_fused_fwd": [C.POINTER(uvc_mlp_args), VP],
     "uvc_cast_transpose": [VP, I32, I32, VP, VP, I32, VP],
     "uvc_cast_transpose_multi": [VP, VP, I32, VP, VP, VP, VP, VP, I32, VP],
+    "uvc_exp_noise": [VP, I64, C.c_uint64, C.c_uint64, C.c_uint32, VP],
     "uvc_gate_distrib": [VP, VP, VP, I32, I32, F32, VP],
     "uvc_gate_grad": [VP, VP, VP, VP, I32, I32, F32, F32, VP],
     # include/uvc_t2t.h

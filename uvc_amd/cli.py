@@ -198,6 +198,7 @@ def main(argv=None):
         val = tr.validate(iterate_eval_batches(args, device, rank))                              # :498
         if rank == 0:
             print(f"Validation Results\nGlobal Steps: {tr.global_step}\nValid Loss: {val['loss']:2.5f}\nValid Accuracy: {val['top1']:2.5f}")
+        tr.check_replicas()                                                                      # ranks still bit-identical (raises otherwise)
         prune_w_mask(tr.minimax, tr.optimizer)                                                   # :500
         remained = float(count_mask(tr.model))
         save_model(args, tr.model, tr.minimax, epoch)                                            # :502

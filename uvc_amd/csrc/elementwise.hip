@@ -652,6 +652,37 @@ extern "C" int uvc_cast_transpose_multi(const float* params, void* shadow, int32
   return UVC_OK;
 }
 
+// ---------------------------------------------------------------------------- keyed Exp(1) noise
+// Counter-based generator for the Gumbel draws of the gates (model_distilled.py:40,485; uvc_utils.py:443-449): element i of the
+// draw (seed, step, site) is a pure function of those four numbers (splitmix64 finaliser over a 64-bit key/counter mix), so
+// data-parallel replicas produce identical noise without sharing -- or being able to desynchronise -- a stateful global RNG
+// (the reference relies on identically seeded torch generators, joint_train.py:191-196, and breaks that itself by sampling the
+// FLOPs report on rank 0 only, :509), and a resumed run needs no RNG state.  E = -log(U), U uniform on (0, 1) with 24 bits.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_exp_noise(float* __restrict__ out, int64_t n, uint64_t key) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint64_t h = splitmix64(key ^ splitmix64((uint64_t)i));
+    const float u = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    out[i] = -logf(u);
+  }
+}
+extern "C" int uvc_exp_noise(float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t site, void* stream) {
+  if (!out || n <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_exp_noise: bad argument");
+  uint64_t key = seed * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull;
+  key ^= (step + 1) * 0x9E3779B97F4A7C15ull;
+  key = (key << 17 | key >> 47) ^ ((uint64_t)site + 1) * 0xC2B2AE3D27D4EB4Full;
+  int nb = (int)((n + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  k_exp_noise<<<nb, 256, 0, (hipStream_t)stream>>>(out, n, key);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
 extern "C" int uvc_gate_distrib(const float* g, const float* e, float* d, int32_t L, int32_t mode, float eps, void* stream) {
   if (!g || !d || L <= 0 || L > 64 || mode < 0 || mode > 3 || ((mode == 1 || mode == 3) && !e)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gate_distrib: bad argument");
   k_gate_distrib<<<1, 64, 0, (hipStream_t)stream>>>(g, e, d, L, mode, eps);

@@ -1068,9 +1068,9 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd(LnbArgs g) {
     for (int o = 1; o < 16; o <<= 1) { dgam[e] += __shfl_xor(dgam[e], o, 64); dbet[e] += __shfl_xor(dbet[e], o, 64); }
   }
   float* P = g.partial + (size_t)blockIdx.x * (2 * D + 2);
-  if (li == 0) {
-    *reinterpret_cast<f32x4*>(P + n) = dgam;
-    *reinterpret_cast<f32x4*>(P + D + n) = dbet;
+  if (li == 0) {          // rows of the partial table are 2D+2 floats: 8-byte aligned only
+    *reinterpret_cast<f32x2*>(P + n) = f32x2{dgam[0], dgam[1]}; *reinterpret_cast<f32x2*>(P + n + 2) = f32x2{dgam[2], dgam[3]};
+    *reinterpret_cast<f32x2*>(P + D + n) = f32x2{dbet[0], dbet[1]}; *reinterpret_cast<f32x2*>(P + D + n + 2) = f32x2{dbet[2], dbet[3]};
   }
   dotA = wave_sum(dotA); dotB = wave_sum(dotB);
   __syncthreads();
@@ -1093,8 +1093,8 @@ extern "C" int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* p, void* stream) {
   if (!p || !p->A || !p->W || !p->x || !p->mean || !p->rstd || !p->gamma || !p->dx || !p->partial)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt_lnbwd: null pointer");
   if (!uvc_gemm_lnbwd_supported(p->M, p->D, p->K, p->dtype)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt_lnbwd: bf16, D = 192, K in {576, 768}, M >= 4096");
-  if ((((uintptr_t)p->A | (uintptr_t)p->W | (uintptr_t)p->x | (uintptr_t)p->gamma | (uintptr_t)p->partial) & 15) != 0 ||
-      (((uintptr_t)p->add1 | (uintptr_t)p->add2 | (uintptr_t)p->dx) & 7) != 0)
+  if ((((uintptr_t)p->A | (uintptr_t)p->W | (uintptr_t)p->x | (uintptr_t)p->gamma) & 15) != 0 ||
+      (((uintptr_t)p->add1 | (uintptr_t)p->add2 | (uintptr_t)p->dx | (uintptr_t)p->partial) & 7) != 0)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt_lnbwd: misaligned buffer");
   LnbArgs a;
   a.A = p->A; a.W = p->W; a.x = p->x; a.mean = p->mean; a.rstd = p->rstd; a.gamma = p->gamma; a.add1 = p->add1; a.a1 = p->a1;

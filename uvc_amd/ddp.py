@@ -32,6 +32,7 @@ class FlatGradReducer:
         self.stream = torch.cuda.Stream(device=flat.device) if self.on_gpu else None
         self.avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.pending = []
+        self._exposed = []
 
     def launch(self, i: int):
         """Start the all-reduce of bucket i (its gradients are complete on the current stream)."""
@@ -53,20 +54,50 @@ class FlatGradReducer:
                     t.div_(self.world)
 
     def finish(self):
-        """Make the current stream wait for every launched bucket."""
+        """Make the current stream wait for every launched bucket.  On a GPU the wait is bracketed by two events on the current
+        stream: their distance is the time the compute stream stood still for communication (the EXPOSED part of the all-reduce),
+        read back lazily by ``exposed_ms``."""
         if self.world == 1:
             return
+        cur = torch.cuda.current_stream(self.flat.device) if self.on_gpu else None
+        if self.on_gpu and self.time_exposed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
         for w in self.pending:
             w.wait()
         self.pending = []
         if self.on_gpu:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+            cur.wait_stream(self.stream)
+            if self.time_exposed:
+                e1.record(cur)
+                self._exposed.append((e0, e1))
+                if len(self._exposed) > 256:
+                    self._exposed = self._exposed[-256:]
+
+    time_exposed = True
+
+    def exposed_ms(self):
+        """Mean exposed-communication time per finish() over the recorded window (synchronises)."""
+        ev, self._exposed = self._exposed, []
+        if not ev:
+            return 0.0
+        ev[-1][1].synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
 
-def bucket_plan(off, depth: int, n_extra: int, num_buckets: int = 4, n_flat: Optional[int] = None):
+BUCKET_BYTES = 32 << 20      # target bucket size when the count is derived from the model size (Base: 346 MB -> 11 buckets)
+
+
+def bucket_plan(off, depth: int, n_extra: int, num_buckets: Optional[int] = 4, n_flat: Optional[int] = None):
     """Backward stage boundaries and the flat-buffer ranges that are final after each of them.
     Stages: 0 = heads + final norm, 1..L = blocks L-1..0, L+1/L+2 = embedding (uvc_vit.h).  The flat
-    layout is in forward order, so a bucket is a contiguous [block k .. previous bucket) range."""
+    layout is in forward order, so a bucket is a contiguous [block k .. previous bucket) range.
+    ``num_buckets=None`` derives the number of block buckets from the gradient bytes (BUCKET_BYTES each, at least 4, at most one
+    per block).  The last block bucket (blocks 0..) goes out as soon as block 0 is done, i.e. BEFORE the token-assembly / patch-
+    embedding backward, and only the embedding tensors + the small conditionally-trained tensors + the dual scalar slot wait for
+    the end of the backward: the exposed tail is ~0.6 MB for DeiT-Tiny instead of three blocks + embeddings."""
+    if num_buckets is None:
+        num_buckets = max(4, -(-(4 * off.n_main) // BUCKET_BYTES))
     num_buckets = max(1, min(num_buckets, depth))
     per = -(-depth // num_buckets)
     plan = []
@@ -76,12 +107,10 @@ def bucket_plan(off, depth: int, n_extra: int, num_buckets: int = 4, n_flat: Opt
         lo_blk = max(0, l - per)
         stage_end = depth - lo_blk + 1           # stages < stage_end are done once block lo_blk is done
         lo = off.blk[lo_blk][0]
-        if lo_blk == 0:
-            break
         plan.append((stage_end, [(lo, hi - lo)]))
         hi = lo
         l = lo_blk
-    # tail: blocks [0, l) + embedding + the small conditionally-active tensors (+ the dual scalar slot)
+    # tail: embedding + the small conditionally-active tensors (+ the dual scalar slot)
     n_flat = off.n_total if n_flat is None else n_flat      # T2T-ViT: the tokens-to-token parameters sit behind the engine's layout
     plan.append((depth + 3, [(0, hi), (off.n_main, n_flat - off.n_main + n_extra)]))
     return plan
@@ -92,7 +121,7 @@ class DistributedDataParallel(torch.nn.Module):
     DistilledVisionTransformer."""
 
     def __init__(self, module, message_size=250000000, gradient_predivide_factor=1.0, delay_allreduce=False,
-                 num_buckets=4, process_group=None, dual_scalar: Optional[torch.Tensor] = None):
+                 num_buckets=None, process_group=None, dual_scalar: Optional[torch.Tensor] = None):
         super().__init__()
         if not hasattr(module, "_flat"):
             raise TypeError("uvc_amd.ddp.DistributedDataParallel wraps a uvc_amd DistilledVisionTransformer")
@@ -110,6 +139,9 @@ class DistributedDataParallel(torch.nn.Module):
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
+
+    def exposed_comm_ms(self):
+        return self.reducer.exposed_ms()
 
     # called by the model's backward between stages
     def pack_dual(self):

@@ -346,3 +346,24 @@ def performer_bwd(kqv, w, part, kptv, datt, dkqv, dkptv, B, T, dtype, dskip=None
     a = _perf_args(kqv, w, part, kptv, B, T, dtype)
     a.datt, a.dskip, a.dkqv, a.dkptv, a.g_is_f32 = L.ptr(datt), L.ptr(dskip), L.ptr(dkqv), L.ptr(dkptv), _is_f32(datt)
     L.check(L.lib().uvc_performer_bwd(C.byref(a), L.cur_stream()), "uvc_performer_bwd")
+
+
+class KeyedExpSource:
+    """Drop-in for the ``exp_source`` hooks of the model and of UVC_CP_MiniMax: Exp(1) draws from the counter-based HIP generator
+    (uvc_exp_noise), keyed by (seed, step, call number within the step).  Every rank that runs the same call sequence gets the same
+    numbers; nothing is shared with torch's global generators, so an extra torch draw on one rank (the reference samples its
+    FLOPs report on rank 0 only, joint_train.py:509) cannot desynchronise the replicas' s, r, y, p."""
+
+    def __init__(self, seed, device):
+        self.seed, self.device = int(seed) & 0xFFFFFFFFFFFFFFFF, device
+        self.step, self.site = 0, 0
+
+    def begin_step(self, step):
+        self.step, self.site = int(step), 0
+
+    def __call__(self, shape):
+        import torch
+        out = torch.empty(shape, device=self.device, dtype=torch.float32)
+        L.check(L.lib().uvc_exp_noise(L.ptr(out), out.numel(), self.seed, self.step, self.site, L.cur_stream()), "uvc_exp_noise")
+        self.site += 1
+        return out

@@ -121,6 +121,11 @@ class Stage1Trainer:
         self.global_step = 0
         self.epoch = 0
         self.gating_grad_list = []
+        # Gumbel noise of the gates / resource samples / patch top-k: keyed by (seed, optimiser step, call number), see ops.KeyedExpSource
+        from .ops import KeyedExpSource
+        self.noise = KeyedExpSource(getattr(args, "seed", 0), model._flat.device)
+        model.exp_source = self.noise
+        self.minimax.exp_source = self.noise
 
     def _build_optimizer(self):
         """AdamW over every parameter + the warm-up-cosine / linear schedule over len(loader) * num_epochs optimiser steps
@@ -165,6 +170,8 @@ class Stage1Trainer:
     # buffer (model.grad_accumulate), and their result carries `stepped=False`.
     def step(self, x, y, tau=None, zero_grad=True):
         a = self.args
+        if self._micro % self.accum == 0:
+            self.noise.begin_step(self.global_step)
         if getattr(a, "overlap_teacher", 1):
             self.criterion.prefetch(x)              # teacher forward on a side stream, under the student forward
         outputs, _ = self.model(x, self.get_tau() if tau is None else tau, a.patch_ratio)
@@ -189,6 +196,22 @@ class Stage1Trainer:
             self.optimizer.zero_grad()
         return dict(loss=loss.detach() * self.accum if self.accum > 1 else loss.detach(), outputs=outputs, gnorm=gnorm, cur=cur, s=s, r=r, g=g,
                     stepped=True)
+
+    def check_replicas(self):
+        """Data-parallel invariant: every rank holds bit-identical parameters and primal / dual state (the reference assumes it and
+        cannot tell when it breaks).  One all-gather of a 3-number fingerprint; raises on the first divergence.  No-op on one rank."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return True
+        mm = self.minimax
+        state = torch.cat([mm.s.data.flatten(), mm.r.data.flatten(), mm.y.data.flatten(), mm.p.data.flatten(), mm.z.data.flatten()]).double()
+        w = self.model._flat.double()
+        fp = torch.stack([w.sum(), (w * w).sum(), (state * torch.arange(1, state.numel() + 1, device=state.device)).sum()])
+        allfp = [torch.empty_like(fp) for _ in range(dist.get_world_size())]
+        dist.all_gather(allfp, fp)
+        if not all(torch.equal(allfp[0], t) for t in allfp):
+            raise RuntimeError(f"data-parallel replicas diverged at step {self.global_step}: fingerprints {[t.tolist() for t in allfp]}")
+        return True
 
     # -- valid() (joint_train.py:199-246): eval-mode forward, CrossEntropy against hard labels, top-1
     @torch.no_grad()

@@ -139,16 +139,20 @@ int uvc_gemm_lnbwd_supported(int32_t M, int32_t D, int32_t K, int32_t dtype);
 int uvc_gemm_lnbwd_nblocks(int32_t M);
 int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* args, void* stream);
 
-/* Fused inference MLP half of a block: out = x + fc2(GELU(fc1(LayerNorm(x)))) (model_distilled.py:153-166,186-189) for the
- * no-grad forwards (teacher: utils/losses.py:47-49; eval).  x, out float32 [M, D]; w1 [F, D], w2 [D, F] are the bf16
- * weight shadows; gamma/beta/b1/b2 float32.  Requires uvc_mlp_fused_supported(D, F, dtype) (D == 192, F % 64 == 0, bf16).
- * The [M, F] hidden activation never reaches memory. */
+/* Fused MLP half of a block (model_distilled.py:107-124,199-204,241-247,493), bf16 mode, D == 192, F % 64 == 0:
+ *     out = d1 * (x + fc2(GELU(fc1(LayerNorm(x))))) + d0 * x_prev           (gate = {d0, d1} device pair; NULL: out = x + mlp)
+ * x, out, x_prev float32 [M, D]; w1 [F, D], w2 [D, F] are the bf16 weight shadows in their natural layouts; gamma/beta/b1/b2 float32.
+ * Inference (teacher: utils/losses.py:47-49; eval): h = mean = rstd = gp = u = NULL, the [M, F] hidden activation never reaches memory.
+ * Training: all five given -- the same pass stores what the backward reads: h = LayerNorm(x) (bf16 [M, D]), mean / rstd [M],
+ * gp = GELU'(a) and u = GELU(a) (bf16 [M, F]); it replaces uvc_layernorm_fwd + two uvc_gemm_nt launches of the step. */
 typedef struct uvc_mlp_args {
   const float* x; const float* gamma; const float* beta;
   const void* w1; const float* b1; const void* w2; const float* b2;
   float* out;
   int32_t M, D, F;
   float eps;
+  const float* x_prev; const float* gate;
+  void* h; float* mean; float* rstd; void* gp; void* u;
 } uvc_mlp_args;
 int uvc_mlp_fused_supported(int32_t D, int32_t F, int32_t dtype);
 int uvc_mlp_fused_fwd(const uvc_mlp_args* args, void* stream);

@@ -540,6 +540,55 @@ def test_fused_inference_mlp(M, F_):
         assert torch.equal(o3, out)
 
 
+@pytest.mark.parametrize("M,F_,gated", [(1576, 768, True), (300, 768, False), (4096 + 37, 768, True), (515, 128, False)])
+def test_fused_training_mlp(M, F_, gated):
+    """The training form of uvc_mlp_fused_fwd: out = d1 * (x + mlp(LN(x))) + d0 * x_prev in one kernel that also stores what a
+    backward reads -- LayerNorm(x) (bf16), mean / rstd, GELU'(a), GELU(a) (bf16 [M, F]) -- against float64 math on the same
+    bf16-rounded operands and against the three kernels it would replace; deterministic; rows do not depend on the batch.
+    (Measured 276 us against 221 us for the three kernels at batch 512, so the engine keeps the unfused training forward:
+    DESIGN section 11; the entry point stays as the checked building block for a register-leaner version.)"""
+    from uvc_amd import ops
+    D = 192
+    x = rnd(M, D, seed=111) * 1.5 + 0.2
+    xp = rnd(M, D, seed=118)
+    gamma, beta = rnd(D, seed=112) * 0.2 + 1.0, rnd(D, seed=113) * 0.1
+    W1, b1 = rnd(F_, D, seed=114, scale=0.06).bfloat16(), rnd(F_, seed=115) * 0.1
+    W2, b2 = rnd(D, F_, seed=116, scale=0.04).bfloat16(), rnd(D, seed=117) * 0.1
+    gate = torch.tensor([0.3, 0.7], device=dev()) if gated else None
+
+    def run(xs, xps):
+        m = xs.shape[0]
+        o = torch.full((m, D), float("nan"), device=dev())
+        h = torch.empty(m, D, device=dev(), dtype=torch.bfloat16)
+        mean, rstd = torch.empty(m, device=dev()), torch.empty(m, device=dev())
+        gp, u = torch.empty(m, F_, device=dev(), dtype=torch.bfloat16), torch.empty(m, F_, device=dev(), dtype=torch.bfloat16)
+        ops.mlp_fused_fwd(xs, gamma, beta, W1, b1, W2, b2, o, x_prev=xps if gated else None, gate=gate, h=h, mean=mean, rstd=rstd, gp=gp, u=u)
+        return o, h, mean, rstd, gp, u
+
+    out, h, mean, rstd, gp, u = run(x, xp)
+    xd = x.double()
+    hr = F.layer_norm(xd, (D,), gamma.double(), beta.double(), 1e-6)
+    torch.testing.assert_close(h.double(), hr, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(mean.double(), xd.mean(1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd.double(), torch.rsqrt(xd.var(1, unbiased=False) + 1e-6), rtol=1e-5, atol=0)
+    pre = (h.double() @ W1.double().t() + b1.double()).requires_grad_(True)          # from the kernel's own bf16 LayerNorm output
+    ur = F.gelu(pre)
+    ur.sum().backward()
+    torch.testing.assert_close(u.double(), ur.detach(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(gp.double(), pre.grad, rtol=1e-2, atol=1e-2)
+    ref = xd + u.double() @ W2.double().t() + b2.double()                              # from the kernel's own bf16 GELU output
+    if gated:
+        ref = 0.7 * ref + 0.3 * xp.double()
+    torch.testing.assert_close(out.double(), ref, rtol=2e-4, atol=2e-4)
+    again = run(x, xp)
+    assert all(torch.equal(p, q) for p, q in zip((out, h, mean, rstd, gp, u), again)), "not deterministic"
+    part = run(x[:100].contiguous(), xp[:100].contiguous())
+    assert all(torch.equal(p[:100], q) for p, q in zip((out, h, mean, rstd, gp, u), part)), "rows depend on the batch"
+    o_inf = torch.empty(M, D, device=dev())                                              # the inference form computes the same output
+    ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, o_inf, x_prev=xp if gated else None, gate=gate)
+    assert torch.equal(o_inf, out)
+
+
 # ---- patch-gating Gumbel top-k at the production shape (SURVEY 8 row a8; VERDICT r1 weak #1)
 @pytest.mark.parametrize("B,P,k,tau", [(64, 196, 176, 0.7), (512, 196, 176, 0.1), (96, 196, 176, 10.0), (3, 16, 14, 1.0)])
 def test_patch_topk_mask_production_shape_bit_exact_indices(B, P, k, tau):

@@ -119,6 +119,10 @@ def main():
         o32 = torch.empty(M, D, device=dev)
         rec("mlp_fused (LN+fc1+GELU+fc2+resid, inference)", timeit(lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32)),
             M * D * 8, 4.0 * M * D * F)
+        hh, gpp, uu2 = torch.empty(M, D, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
+        mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        rec("mlp_fused TRAIN (+h, g', u stores, gate mix)", timeit(lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32, x_prev=g32, gate=gate, h=hh, mean=mean, rstd=rstd, gp=gpp, u=uu2)),
+            M * D * 12 + M * D * 2 + 2 * M * F * 2, 4.0 * M * D * F)
     if want("attn"):
         qkv = torch.randn(B, N, 3 * D, device=dev).to(bf)
         o = torch.empty(B, N, D, device=dev, dtype=bf)

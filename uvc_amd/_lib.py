@@ -77,7 +77,8 @@ class uvc_gemm_lnbwd_args(C.Structure):
 
 class uvc_mlp_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "gamma", "beta", "w1", "b1", "w2", "b2", "out")] + \
-               [(n, C.c_int32) for n in ("M", "D", "F")] + [("eps", C.c_float)]
+               [(n, C.c_int32) for n in ("M", "D", "F")] + [("eps", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("x_prev", "gate", "h", "mean", "rstd", "gp", "u")]
 
 
 class uvc_loss_args(C.Structure):

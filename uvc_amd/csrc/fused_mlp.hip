@@ -1,48 +1,56 @@
-// Fused inference MLP half of a DeiT block for gfx950 (embed_dim 192, bf16 MFMA, float32 residual stream):
-//     out = x1 + fc2(GELU(fc1(LayerNorm(x1))))          UVC/models/model_distilled.py:153-166,186-189
-// used by the no-grad forwards of the step (the distillation teacher, utils/losses.py:47-49, and eval).
+// Fused MLP half of a DeiT block for gfx950 (embed_dim 192, bf16 MFMA, float32 residual stream):
+//     out = d1 * (x1 + fc2(GELU(fc1(LayerNorm(x1))))) + d0 * x_prev        UVC/models/model_distilled.py:107-124,199-204,241-247,493
+// Two instances:
+//   inference (teacher, utils/losses.py:47-49, and eval): nothing but `out` is written; the [M, 768] hidden activation never
+//     leaves the register file (154 MB of HBM traffic per layer at batch 512 instead of 620 MB for LayerNorm, fc1+GELU, fc2);
+//   training (the student's forward): the same pass also stores what the backward reads -- LayerNorm(x1) (bf16 [M, D], operand of
+//     dW1), its mean / rstd, GELU'(a) and GELU(a) (bf16 [M, F], the dgrad epilogue factor and the operand of dW2) -- straight from
+//     the accumulator registers, so LayerNorm2, fc1 and fc2 of the step become ONE kernel and h2 / u are never re-read.
 //
-// Unfused, the three kernels (LayerNorm, fc1+GELU, fc2+residual) move 620 MB per layer at batch 512, 310 MB of it the
-// [M, 768] hidden activation written once and read once.  Here a workgroup owns 256 token rows: every wave normalises its
-// 32 rows in registers (a row is spread over the four 16-lane groups of the MFMA B-operand layout, so mean / variance
-// are two shuffles), keeps them as bf16 operand fragments, and the hidden dimension is streamed in chunks of 64 units:
-//     a^T  = W1[chunk] . h^T      (W1 rows from LDS as the A operand; accumulator of lane (row, g) = 4 hidden units)
-//     u^T  = GELU(a^T + b1)       in registers; two accumulator tiles packed = the B operand of the next MFMA
-//     out^T += W2[:, chunk] . u^T (W2 staged in LDS already permuted to that packing: one ds_read_b128 per fragment)
-// so the hidden activation never leaves the register file.  HBM traffic is x1 once in (LayerNorm + residual; the residual
-// re-read hits L2/MALL) and out once: 154 MB.  The 590 KB of weights stream L2 -> LDS once per 256 rows, double-buffered,
-// one barrier per chunk.  The kernel is VALU-bound, not HBM-bound: the erf GELU of 64 x 32 values per wave per chunk is
-// ~770 VALU instructions against 96 MFMAs, and with two 256-VGPR waves per SIMD in lock-step phases the two do not overlap
-// (PMC: VALU busy 31 %, MFMA busy 14 %, waves parked 53 %).  168 us per layer at batch 512 against 210 us for the three
-// separate kernels, with a quarter of their HBM traffic.  (Measured without GELU: 120 us, with the tanh form: 153 us -- the
-// chunk loop itself, LDS read -> MFMA with two waves per SIMD, is the next thing to pipeline.)  In the training step the
-// teacher forward runs beside the student forward and the step time does not change (a 256-VGPR, 115 KB-LDS workgroup
-// owns its CU); a stand-alone eval forward gets the 1.2x.
+// Geometry: a workgroup is 8 waves (two per SIMD, 256 VGPRs each) x 32 token rows (2 row tiles).  Every wave normalises its rows in
+// registers (a row is spread over the four 16-lane groups of the MFMA B-operand layout: mean / variance are two shuffles) and keeps
+// them as bf16 operand fragments; the hidden dimension is streamed in chunks of 64 units (12 chunks):
+//     a^T   = W1[chunk] . h^T       W1 rows from LDS as the MFMA A operand; lane (row li, group g) ends with hidden units
+//                                   g*16 + t*4 + {0..3} of tile t, i.e. SIXTEEN CONSECUTIVE units over the four tiles
+//     u^T   = GELU(a^T + b1)        in registers; tiles (2s, 2s+1) packed = the B operand of k-step s of the next MFMA
+//     out^T += W2[:, chunk] . u^T   W2 rows from LDS as the A operand
+// The unit order g*16 + t*4 + e is a permutation of the chunk, applied where the weight chunk is staged: W1 row h lands in LDS row
+// ((h >> 2) & 3) * 16 + (h >> 4) * 4 + (h & 3), W2's 16-byte piece (g, s) in slot s*4 + g -- the sources stay in their natural
+// layouts, every fragment read is one conflict-free ds_read_b128, and (training form) a lane's GELU'(a) / GELU(a) are 32 contiguous
+// bytes of the [M, F] row.  A chunk is three phases -- fc1 (48 MFMAs per wave), GELU (32 values per lane), fc2 (48 MFMAs) -- cut into
+// fenced regions of 8 MFMAs whose fragments are requested ONE REGION EARLIER (round 1 fenced every region and read its fragments
+// inside it, so every ds_read latency was exposed; unfenced, hipcc hoists the whole chunk's reads and spills).  Weight chunks
+// (48 KB) stream L2 -> registers -> LDS one chunk ahead in two halves that share 16 staging VGPRs (W1 under fc1, W2 under GELU /
+// fc2), with affine piece assignments: SGPR base + one VGPR byte offset per half.  Written as per-piece element offsets hipcc kept
+// six 64-bit addresses per half in spilled VGPRs and reloaded each behind s_waitcnt vmcnt(0), serialising the L2 round trips.
+// Measured at batch 512 (M = 100 864): 133 us per layer (round 1: 152-168 us; MFMA bound 24 us; the three unfused kernels 210 us).
+// A 4-wave x 64-row variant (one wave per SIMD, 512 registers, fragments feeding four MFMAs) was built and measured at 230-300 us:
+// alone on its SIMD a wave exposes every wait the compiler leaves, and hipcc split the file 256 VGPR / 256 AGPR with 300+ spills.
+// The training form (stores for the backward) runs 276 us against 221 us for LayerNorm + fc1 + fc2 and is NOT wired into the engine.
 #include "common.h"
 #include "../../include/uvc_kernels.h"
 
 namespace {
 
 typedef bf16_t T;
-constexpr int D = 192, KT = 6, FC = 64, R = 2, NW = 8, NTH = 64 * NW, ROWS = NW * R * 16;
-constexpr int W1S = D * 2 + 32;   // 416 B: 104 words = 40 mod 64 -> conflict-free ds_read_b128 fragment reads
-constexpr int W2S = FC * 2 + 32;  // 160 B:  40 words (8, 24, 40, 56 mod 64 are the conflict-free strides)
-constexpr int BUF = FC * W1S + D * W2S + FC * 4;   // W1 chunk | W2 chunk (permuted) | b1 chunk
-constexpr int NP1 = FC * (D / 8), NP2 = D * (FC / 8);   // 16-byte pieces per chunk: 1536 of W1 + 1536 of W2
-static_assert((NP1 + NP2) % NTH == 0 && NP1 % 64 == 0, "uniform staging: whole waves on either side of the W1/W2 boundary");
-constexpr int NPT = (NP1 + NP2) / NTH;
+constexpr int D = 192, KT = 6, FC = 64, RW = 2, NW = 8, NTH = 64 * NW, ROWS = NW * RW * 16;
+constexpr int W1S = D * 2 + 32;   // 416 B: 104 words = 40 mod 64 -> conflict-free ds_read_b128 fragment reads of 16 consecutive rows
+constexpr int W2S = FC * 2 + 32;  // 160 B:  40 words
+constexpr int BUF = FC * W1S + D * W2S + FC * 4;   // W1 chunk | W2 chunk | b1 chunk
 
 __device__ __forceinline__ f32x4 mma(const bf16x8& a, const bf16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ bf16x8 frag(const char* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); }
-__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
+__device__ __forceinline__ u32x4 pack8u(const f32x4& lo, const f32x4& hi) {
   u32x4 r;
   r[0] = pack_bf16x2(lo[0], lo[1]); r[1] = pack_bf16x2(lo[2], lo[3]);
   r[2] = pack_bf16x2(hi[0], hi[1]); r[3] = pack_bf16x2(hi[2], hi[3]);
-  return __builtin_bit_cast(bf16x8, r);
+  return r;
 }
+__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) { return __builtin_bit_cast(bf16x8, pack8u(lo, hi)); }
 
+template <bool TRAIN>
 __global__ __launch_bounds__(NTH, 2) void k_mlp_fused(uvc_mlp_args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const buf0 = smem;
@@ -55,54 +63,69 @@ __global__ __launch_bounds__(NTH, 2) void k_mlp_fused(uvc_mlp_args a) {
   const T* __restrict__ W2 = reinterpret_cast<const T*>(a.w2);
   const int nch = a.F / FC;
   for (int i = tid; i < D; i += NTH) { sG[i] = a.gamma[i]; sBt[i] = a.beta[i]; sB2[i] = a.b2[i]; }
+  float d0 = 0.f, d1 = 1.f;
+  if (a.gate) { d0 = a.gate[0]; d1 = a.gate[1]; }
 
-  // weight chunk staging through registers: NI1 16-byte pieces of W1[c*FC.., :] and NI2 of W2[:, c*FC..] per thread.
-  // Hidden units ch*8..ch*8+7 of the chunk belong to accumulator tile t = ch/2, lane groups gq = (ch%2)*2 + {0,1}; the B
-  // operand of k-step s = t/2 holds, per lane group, 4 units of tile 2s then 4 units of tile 2s+1 -- W2 is stored that way.
-  u32x4 pw[NPT];
+  // weight chunk staging through registers, one chunk ahead, in two halves that share the staging registers: the W1 pieces travel
+  // under the fc1 MFMAs, the W2 pieces under the GELU / fc2 phase.  Piece assignments are AFFINE in the unrolled index (one VGPR of
+  // source offset and one of LDS offset per half; everything else is an instruction immediate or a scalar): the first version spent
+  // 36 VGPRs on per-piece addresses and spilled.
+  //   W1 chunk [64 rows][24 pieces]: threads 0..383 = (r0 = tid / 24, ch = tid % 24), rows r0 + 16 i, i = 0..3
+  //   W2 chunk [192 rows][8 pieces]: all threads   = (r0 = tid / 8,  ch = tid % 8),  rows r0 + 64 i, i = 0..2
+  constexpr int NS1 = 4, NS2 = 3, T1 = 384;
+  u32x4 pw[NS1];
   u32x4 pb;
-  auto gload = [&](int c) {
+  const bool st1 = tid < T1;
+  const unsigned so1 = (unsigned)((tid / 24) * D + (tid % 24) * 8);                         // elements into the W1 chunk
+  // hidden unit h = r0 + 16 i = g*16 + t*4 + e with g = i, t = r0 >> 2, e = r0 & 3 -> A-operand row t*16 + g*4 + e
+  const unsigned ld1 = (unsigned)((((tid / 24) >> 2) * 16 + ((tid / 24) & 3)) * W1S + (tid % 24) * 16);
+  const unsigned so2 = (unsigned)((tid / 8) * a.F + (tid % 8) * 8);                          // elements from W2[0, c*FC]
+  const unsigned ld2 = (unsigned)(FC * W1S + (tid / 8) * W2S + (((tid % 8) & 1) * 4 + ((tid % 8) >> 1)) * 16);
+  // (scalar chunk / row-group base) + (one per-thread BYTE offset): the loads take the SGPR-base + 32-bit-VGPR-offset form.  Written as
+  // per-piece element offsets, hipcc kept six 64-bit addresses per half in (spilled) VGPRs and reloaded each behind an s_waitcnt
+  // vmcnt(0), which serialised the six L2 round trips of every half: 12 us per chunk.
+  const unsigned so1b = so1 * 2u, so2b = so2 * 2u;
+  auto gload1 = [&](int c) {
+    const char* base = reinterpret_cast<const char*>(W1 + (size_t)c * FC * D);
+    if (st1) {
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      const int id = tid + NTH * i;                      // id < NP1 is uniform over a wave
-      if (id < NP1) { const int row = id / (D / 8), ch = id % (D / 8); pw[i] = *reinterpret_cast<const u32x4*>(W1 + (size_t)(c * FC + row) * D + ch * 8); }
-      else { const int id2 = id - NP1, row = id2 / (FC / 8), ch = id2 % (FC / 8); pw[i] = *reinterpret_cast<const u32x4*>(W2 + (size_t)row * a.F + c * FC + ch * 8); }
-    }
-    pb = *reinterpret_cast<const u32x4*>(a.b1 + c * FC + (tid & (FC / 4 - 1)) * 4);
+      for (int i = 0; i < NS1; ++i) pw[i] = *reinterpret_cast<const u32x4*>((base + (size_t)(16 * i * D * 2)) + so1b);
+    } else if (tid < T1 + FC / 4) pb = *reinterpret_cast<const u32x4*>(a.b1 + c * FC + (tid - T1) * 4);
   };
-  auto lstore = [&](char* buf) {
+  auto lstore1 = [&](char* buf) {
+    if (st1) {
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      const int id = tid + NTH * i;
-      if (id < NP1) { const int row = id / (D / 8), ch = id % (D / 8); *reinterpret_cast<u32x4*>(buf + row * W1S + ch * 16) = pw[i]; }
-      else {
-        const int id2 = id - NP1, row = id2 / (FC / 8), ch = id2 % (FC / 8);
-        const int t = ch >> 1, sk = t >> 1, gq0 = (ch & 1) * 2;
-        char* base = buf + FC * W1S + row * W2S + (t & 1) * 8;
-        u32x2 lo, hi;
-        lo[0] = pw[i][0]; lo[1] = pw[i][1]; hi[0] = pw[i][2]; hi[1] = pw[i][3];
-        *reinterpret_cast<u32x2*>(base + (sk * 4 + gq0) * 16) = lo;
-        *reinterpret_cast<u32x2*>(base + (sk * 4 + gq0 + 1) * 16) = hi;
-      }
-    }
-    if (tid < FC / 4) *reinterpret_cast<u32x4*>(buf + FC * W1S + D * W2S + tid * 16) = pb;
+      for (int i = 0; i < NS1; ++i) *reinterpret_cast<u32x4*>(buf + ld1 + (i * 4) * W1S) = pw[i];
+    } else if (tid < T1 + FC / 4) *reinterpret_cast<u32x4*>(buf + FC * W1S + D * W2S + (tid - T1) * 16) = pb;
+  };
+  auto gload2 = [&](int c) {
+    const char* base = reinterpret_cast<const char*>(W2 + c * FC);
+    const size_t rstep = (size_t)64 * (size_t)a.F * 2;
+#pragma unroll
+    for (int i = 0; i < NS2; ++i) pw[i] = *reinterpret_cast<const u32x4*>((base + i * rstep) + so2b);
+  };
+  auto lstore2 = [&](char* buf) {          // piece (g = ch >> 1, s = ch & 1) -> k-step slot s*4 + g
+#pragma unroll
+    for (int i = 0; i < NS2; ++i) *reinterpret_cast<u32x4*>(buf + ld2 + 64 * i * W2S) = pw[i];
   };
 
   // the weight stream is cyclic: chunk (c+1) % nch is always prefetched, so the last chunk of a pass stages chunk 0 of the
   // next one and the chunk loop has no tail case
   int par = 0;
-  gload(0);
-  lstore(buf0);
+  gload1(0);
+  lstore1(buf0);
+  gload2(0);
+  lstore2(buf0);
   __syncthreads();                                     // also covers sG / sBt / sB2
 
   const int npass = (a.M + ROWS - 1) / ROWS;
   for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
-    const int m0 = pass * ROWS + w * (R * 16);
-    // ---- LayerNorm of this wave's 2 x 16 rows, straight into MFMA B-operand fragments
-    bf16x8 hf[R][KT];
+    const int m0 = pass * ROWS + w * (RW * 16);
+    // ---- LayerNorm of this wave's 4 x 16 rows, straight into MFMA B-operand fragments (lane (li, g): columns (ks*4 + g)*8 .. +7)
+    bf16x8 hf[RW][KT];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < RW; ++r) {
+      __builtin_amdgcn_sched_barrier(0);              // one row tile's 48 row registers at a time
       const int row = m0 + r * 16 + li;
       const bool ok = row < a.M;
       const float okf = ok ? 1.0f : 0.0f;
@@ -127,6 +150,7 @@ __global__ __launch_bounds__(NTH, 2) void k_mlp_fused(uvc_mlp_args a) {
       q += __shfl_xor(q, 16, 64);
       q += __shfl_xor(q, 32, 64);
       const float rstd = rsqrtf(q * (1.0f / D) + a.eps);
+      if (TRAIN && ok && g == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
 #pragma unroll
       for (int ks = 0; ks < KT; ++ks) {
         const int c0 = (ks * 4 + g) * 8;
@@ -138,75 +162,113 @@ __global__ __launch_bounds__(NTH, 2) void k_mlp_fused(uvc_mlp_args a) {
           y0[e] = ((xv[2 * ks][e] - mean) * rstd * g0[e] + b0[e]) * okf;        // rows past M: zero operands
           y1[e] = ((xv[2 * ks + 1][e] - mean) * rstd * g1[e] + b1[e]) * okf;
         }
-        hf[r][ks] = pack8(y0, y1);
+        const u32x4 pk = pack8u(y0, y1);
+        hf[r][ks] = __builtin_bit_cast(bf16x8, pk);
+        if (TRAIN && ok) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.h) + (size_t)row * D + c0) = pk;
       }
     }
 
-    f32x4 out[R][D / 16];
+    f32x4 out[RW][D / 16];
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
       for (int j = 0; j < D / 16; ++j) out[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int c = 0; c < nch; ++c, par ^= 1) {
       const char* buf = par ? buf1 : buf0;
       char* nbuf = par ? buf0 : buf1;
-      gload(c + 1 < nch ? c + 1 : 0);
-      // ---- a^T = W1c . h^T      (sched barriers keep the operand reads next to their MFMAs: bounded register use; letting
-      //      the compiler hoist all 52 fragment reads of a chunk costs 90 spilled VGPRs and 40 % more time)
-      f32x4 acc[R][FC / 16];
+      const int cn = c + 1 < nch ? c + 1 : 0;
+      gload1(cn);
+      // ---- a^T = W1c . h^T.  One fenced region per k-step: the four W1 fragments of step ks+1 are requested first, then the 16
+      //      MFMAs of step ks (4 tiles x 4 row tiles, 256 cycles of matrix pipe) run on the fragments requested a region earlier, so
+      //      no ds_read latency is exposed although this wave is alone on its SIMD.  (Unfenced, the scheduler hoists the whole chunk's
+      //      reads and spills; fenced without the one-region-ahead requests every read is waited for: 2x slower than round 1's kernel.)
+      f32x4 acc[RW][FC / 16];
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+      for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int t = 0; t < FC / 16; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 wa[2][FC / 16];
+#pragma unroll
+      for (int t = 0; t < FC / 16; ++t) wa[0][t] = frag(buf + (t * 16 + li) * W1S + g * 16);
 #pragma unroll
       for (int ks = 0; ks < KT; ++ks) {
-        bf16x8 wf[FC / 16];
+        if (ks + 1 < KT) {
 #pragma unroll
-        for (int t = 0; t < FC / 16; ++t) wf[t] = frag(buf + (t * 16 + li) * W1S + (ks * 4 + g) * 16);
+          for (int t = 0; t < FC / 16; ++t) wa[(ks + 1) & 1][t] = frag(buf + (t * 16 + li) * W1S + ((ks + 1) * 4 + g) * 16);
+        }
 #pragma unroll
         for (int t = 0; t < FC / 16; ++t)
 #pragma unroll
-          for (int r = 0; r < R; ++r) acc[r][t] = mma(wf[t], hf[r][ks], acc[r][t]);
+          for (int r = 0; r < RW; ++r) acc[r][t] = mma(wa[ks & 1][t], hf[r][ks], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- u^T = GELU(a^T + b1), packed as the next B operand
-      bf16x8 uf[R][FC / 32];
-      {
-        const float* sb1 = reinterpret_cast<const float*>(buf + FC * W1S + D * W2S);
+      lstore1(nbuf);
+      gload2(cn);
+      // ---- u^T = GELU(a^T + b1) (and GELU' when training) for the four row tiles: 64 values per lane, packed as the next B operands;
+      //      the first W2 fragments are requested here so that they arrive under the VALU work
+      bf16x8 wc[2][4];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const char* wp = buf + FC * W1S + (jj * 16 + li) * W2S + g * 16;
+        wc[0][2 * jj] = frag(wp); wc[0][2 * jj + 1] = frag(wp + 64);
+      }
+      const float* sb1 = reinterpret_cast<const float*>(buf + FC * W1S + D * W2S) + g * 16;
+      bf16x8 uf[RW][2];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        f32x4 gpv[FC / 16];
 #pragma unroll
         for (int t = 0; t < FC / 16; ++t) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + t * 16 + g * 4);
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + t * 4);
 #pragma unroll
-          for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[r][t][e] = Gelu<T>::f(acc[r][t][e] + bb[e]);
+          for (int e = 0; e < 4; ++e) {
+            const float pre = acc[r][t][e] + bb[e];
+            if (TRAIN) { float fo, go; Gelu<T>::fg(pre, fo, go); acc[r][t][e] = fo; gpv[t][e] = go; }
+            else acc[r][t][e] = Gelu<T>::f(pre);
+          }
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int sk = 0; sk < FC / 32; ++sk) uf[r][sk] = pack8(acc[r][2 * sk], acc[r][2 * sk + 1]);
+        const u32x4 u0 = pack8u(acc[r][0], acc[r][1]), u1 = pack8u(acc[r][2], acc[r][3]);
+        uf[r][0] = __builtin_bit_cast(bf16x8, u0); uf[r][1] = __builtin_bit_cast(bf16x8, u1);
+        if (TRAIN) {
+          const int row = m0 + r * 16 + li;
+          if (row < a.M) {
+            const size_t o = (size_t)row * a.F + c * FC + g * 16;          // this lane's 16 consecutive hidden units
+            T* up = reinterpret_cast<T*>(a.u) + o;
+            T* gpp = reinterpret_cast<T*>(a.gp) + o;
+            *reinterpret_cast<u32x4*>(up) = u0; *reinterpret_cast<u32x4*>(up + 8) = u1;
+            *reinterpret_cast<u32x4*>(gpp) = pack8u(gpv[0], gpv[1]); *reinterpret_cast<u32x4*>(gpp + 8) = pack8u(gpv[2], gpv[3]);
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
-      // ---- out^T += W2c . u^T
+      // ---- out^T += W2c . u^T.  Six fenced regions of two output tiles: four W2 fragments (requested a region earlier) x four row
+      //      tiles = 16 MFMAs; the two MFMAs on one accumulator sit four apart.
 #pragma unroll
-      for (int j = 0; j < D / 16; ++j) {
-        bf16x8 wf[FC / 32];
+      for (int k = 0; k < 6; ++k) {
+        if (k + 1 < 6) {
 #pragma unroll
-        for (int sk = 0; sk < FC / 32; ++sk) wf[sk] = frag(buf + FC * W1S + (j * 16 + li) * W2S + (sk * 4 + g) * 16);
+          for (int jj = 0; jj < 2; ++jj) {
+            const char* wp = buf + FC * W1S + (((k + 1) * 2 + jj) * 16 + li) * W2S + g * 16;
+            wc[(k + 1) & 1][2 * jj] = frag(wp); wc[(k + 1) & 1][2 * jj + 1] = frag(wp + 64);
+          }
+        }
 #pragma unroll
-        for (int sk = 0; sk < FC / 32; ++sk)
+        for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
-          for (int r = 0; r < R; ++r) out[r][j] = mma(wf[sk], uf[r][sk], out[r][j]);
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          for (int r = 0; r < RW; ++r) out[r][k * 2 + jj] = mma(wc[k & 1][2 * jj], uf[r][0], out[r][k * 2 + jj]);
+#pragma unroll
+          for (int r = 0; r < RW; ++r) out[r][k * 2 + jj] = mma(wc[k & 1][2 * jj + 1], uf[r][1], out[r][k * 2 + jj]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      lstore(nbuf);
+      lstore2(nbuf);
       __syncthreads();
     }
 
-    // ---- out = x1 + mlp + b2: lane (row, g) holds columns j*16 + g*4 .. +3 of every 16-column group
+    // ---- out = d1 * ((mlp + b2) + x1) + d0 * x_prev: lane (row, g) holds columns j*16 + g*4 .. +3 of every 16-column group
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RW; ++r) {
       const int row = m0 + r * 16 + li;
       if (row < a.M) {
         const float* xr = a.x + (size_t)row * D;
@@ -215,10 +277,15 @@ __global__ __launch_bounds__(NTH, 2) void k_mlp_fused(uvc_mlp_args a) {
         for (int j = 0; j < D / 16; ++j) {
           const int col = j * 16 + g * 4;
           const f32x4 xres = *reinterpret_cast<const f32x4*>(xr + col);
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(sB2 + col);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + col);
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (out[r][j][e] + bb[e]) + xres[e];
+          for (int e = 0; e < 4; ++e) o[e] = (out[r][j][e] + bv[e]) + xres[e];
+          if (a.gate) {
+            const f32x4 xp = *reinterpret_cast<const f32x4*>(a.x_prev + (size_t)row * D + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(d1, o[e], __builtin_fmaf(d0, xp[e], 0.0f));
+          }
           *reinterpret_cast<f32x4*>(orow + col) = o;
         }
       }
@@ -234,13 +301,25 @@ extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
   if (!p || !p->x || !p->out || !p->gamma || !p->beta || !p->w1 || !p->b1 || !p->w2 || !p->b2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: null pointer");
   if (p->M <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: empty");
   if (!uvc_mlp_fused_supported(p->D, p->F, UVC_BF16)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_mlp_fused_fwd: needs D == 192 and F % 64 == 0");
-  if ((((uintptr_t)p->x | (uintptr_t)p->out | (uintptr_t)p->w1 | (uintptr_t)p->w2 | (uintptr_t)p->b1) & 15) != 0)
+  if ((((uintptr_t)p->x | (uintptr_t)p->out | (uintptr_t)p->w1 | (uintptr_t)p->w2 | (uintptr_t)p->b1 | (uintptr_t)p->x_prev | (uintptr_t)p->h |
+        (uintptr_t)p->u | (uintptr_t)p->gp) & 15) != 0)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: buffers must be 16-byte aligned");
+  const bool train = p->h || p->u || p->gp || p->mean || p->rstd;
+  if (train && (!p->h || !p->u || !p->gp || !p->mean || !p->rstd)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: training needs h, mean, rstd, gp and u");
+  if ((p->gate != nullptr) != (p->x_prev != nullptr)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: gate and x_prev come together");
   const size_t sh = (size_t)2 * BUF + 3 * D * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-  if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
   const int npass = ceil_div(p->M, ROWS);
-  k_mlp_fused<<<npass < 256 ? npass : 256, NTH, sh, (hipStream_t)stream>>>(*p);
+  const int grid = npass < 256 ? npass : 256;
+  hipStream_t st = (hipStream_t)stream;
+  if (train) {
+    static const hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+    k_mlp_fused<true><<<grid, NTH, sh, st>>>(*p);
+  } else {
+    static const hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+    k_mlp_fused<false><<<grid, NTH, sh, st>>>(*p);
+  }
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -410,6 +410,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     if (!io->training && !io->gate_d && uvc_mlp_fused_supported(d.D, Fe, d.dtype)) {
       // no-grad forward (teacher / eval): LayerNorm + fc1 + GELU + fc2 + residual in one kernel, hidden activation in registers
       uvc_mlp_args m;
+      memset(&m, 0, sizeof(m));
       m.x = b.x1; m.gamma = P + q[6]; m.beta = P + q[7]; m.w1 = w1; m.b1 = b1;
       m.w2 = w2; m.b2 = P + q[11]; m.out = xout; m.M = d.M; m.D = d.D; m.F = Fe; m.eps = d.eps;
       TRY(uvc_mlp_fused_fwd(&m, c.st));

@@ -155,11 +155,13 @@ def gemm_nt_lnbwd(A, Wt, x, mean, rstd, gamma, dx, partial, dgamma, dbeta, *, ad
     L.check(L.lib().uvc_layernorm_bwd_reduce_batch(item, 1, a.D, beta_acc, L.cur_stream()), "uvc_layernorm_bwd_reduce_batch")
 
 
-def mlp_fused_fwd(x, gamma, beta, w1, b1, w2, b2, out, eps=1e-6):
-    """out = x + fc2(GELU(fc1(LayerNorm(x)))) for [M, 192] float32 rows; w1 [F,192] / w2 [192,F] bf16."""
-    _chk(x, gamma, beta, w1, b1, w2, b2, out)
+def mlp_fused_fwd(x, gamma, beta, w1, b1, w2, b2, out, eps=1e-6, *, x_prev=None, gate=None, h=None, mean=None, rstd=None, gp=None, u=None):
+    """out = d1 * (x + fc2(GELU(fc1(LayerNorm(x))))) + d0 * x_prev for [M, 192] float32 rows; w1 [F,192] / w2 [192,F] bf16.
+    Training form: h / mean / rstd / gp / u receive LayerNorm(x), its statistics, GELU'(a) and GELU(a)."""
+    _chk(x, gamma, beta, w1, b1, w2, b2, out, x_prev, gate, h, mean, rstd, gp, u)
     a = L.uvc_mlp_args()
     a.x, a.gamma, a.beta, a.w1, a.b1, a.w2, a.b2, a.out = (L.ptr(t) for t in (x, gamma, beta, w1, b1, w2, b2, out))
+    a.x_prev, a.gate, a.h, a.mean, a.rstd, a.gp, a.u = (L.ptr(t) for t in (x_prev, gate, h, mean, rstd, gp, u))
     a.M, a.D, a.F, a.eps = x.shape[0], x.shape[1], w1.shape[0], eps
     L.check(L.lib().uvc_mlp_fused_fwd(C.byref(a), L.cur_stream()), "uvc_mlp_fused_fwd")
 

@@ -121,6 +121,25 @@ def pmc_traffic(key):
     return best
 
 
+def in_step_top():
+    """Row 1 of the newest committed in-step rocprofv3 table (profiles/*_kernel_stats_uvc_train_steps_only.csv): the kernel with the
+    largest summed duration INSIDE the step.  Reported next to `roofline` because the two rankings differ by construction: the step
+    runs two or three streams that time-slice one memory system, so in-step durations are inflated by whatever ran beside the
+    kernel (k_tn_reduce: ~10 us alone, 64 us beside the dgrad stream) and do not add up to the step time, while the stand-alone
+    launch times do (their sum per step equals the measured step time to ~2 %: `kernel_ms_per_step_standalone_sum`)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats_uvc_train_steps_only.csv")))
+    if not files:
+        return None
+    rows = [r for r in csv.reader(l for l in open(files[-1]) if not l.startswith("#"))]
+    if len(rows) < 2:
+        return None
+    r = rows[1]
+    return {"kernel": r[0], "calls_per_step": float(r[1]), "avg_us_in_step": float(r[2]), "ms_per_step_in_step": float(r[3]),
+            "percent_of_kernel_time": float(r[4]), "source": "profiles/" + os.path.basename(files[-1])}
+
+
 def kernel_table(args):
     """Every kernel of the step as a stand-alone launch at the step's shapes (tools/kernel_table.py): HIP-event average of
     back-to-back launches on the launch stream x launches per step.  `roofline` is the entry with the LARGEST TOTAL TIME PER STEP --
@@ -304,6 +323,7 @@ def main():
             line["roofline"] = roof
             line["top_kernels"] = top
             line["kernel_ms_per_step_standalone_sum"] = total_ms
+            line["in_step_top_kernel"] = in_step_top()
         else:
             line["roofline"] = None
         line["commit"] = _git_head()

@@ -696,12 +696,13 @@ def test_bf16_mode_gelu_approximant_error_bounds():
 
 @pytest.mark.parametrize("K", [768, 576])
 @pytest.mark.parametrize("with_add2", [False, True])
-def test_gemm_nt_lnbwd_matches_the_unfused_pair(K, with_add2):
+@pytest.mark.parametrize("M", [4096 + 53, 4096 + 48, 16 * 1031])     # ragged M: register-staged kernel; M % 16 == 0: the LDS-DMA ring (260 and 1031 tiles: more than one per workgroup)
+def test_gemm_nt_lnbwd_matches_the_unfused_pair(K, with_add2, M):
     """uvc_gemm_nt_lnbwd (dgrad GEMM with the LayerNorm backward as its epilogue) against float64 math and against the two
     kernels it replaces (uvc_gemm_nt -> bf16 dy -> uvc_layernorm_bwd): dx, dgamma, dbeta, the two gate dot products; ragged M;
     dx aliasing add2 (the engine updates gA in place); two runs bit-identical."""
     from uvc_amd import ops
-    M, D = 4096 + 53, 192
+    D = 192
     A = rnd(M, K, seed=201).to(torch.bfloat16)
     Wt = rnd(D, K, seed=202, scale=0.05).to(torch.bfloat16)
     x = rnd(M, D, seed=203) * 1.5 + 0.3
@@ -733,7 +734,8 @@ def test_gemm_nt_lnbwd_matches_the_unfused_pair(K, with_add2):
     torch.testing.assert_close(dx.double(), ref, rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(dg.double(), ref_dg, rtol=2e-3, atol=2e-2)
     torch.testing.assert_close(db.double(), ref_db, rtol=2e-3, atol=2e-2)
-    torch.testing.assert_close(dots[0].double(), (dx.double() * x.double()).sum(), rtol=2e-3, atol=0.5)
+    # <dx, x> from the unrounded dx against the bf16-rounded one: a random walk of M*D roundings of relative size 2^-9
+    torch.testing.assert_close(dots[0].double(), (dx.double() * x.double()).sum(), rtol=2e-3, atol=0.5 + 0.01 * math.sqrt(M * D))
     if with_add2:
         torch.testing.assert_close(dots[1].double(), (add2.double() * x.double()).sum(), rtol=1e-4, atol=0.1)
     # the unfused pair

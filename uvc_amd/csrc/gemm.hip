@@ -9,6 +9,7 @@
 // or 32 B (TN) so ds_read_b128 / ds_read_b64_tr_b16 fragment reads are bank-conflict free.
 // Operands are swapped in the MFMA (a = B-fragment, b = A-fragment) so every lane ends up with 4
 // CONSECUTIVE output columns of one row -> 16-byte (fp32) / 8-byte (bf16) epilogue accesses.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/uvc_kernels.h"
 
@@ -1084,6 +1085,255 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd(LnbArgs g) {
   }
 }
 
+// ---- the same kernel with LDS-DMA staging: bytes in flight instead of registers --------------------------------------------
+// k_gemm_wsn_lnbwd keeps ONE 16-row tile (49 KB) in flight per CU -- its A rows are requested one iteration ahead through staging
+// registers, the row's x / add1 / add2 at the top of its own iteration -- and there is no room for more next to 96 VGPRs of W^T:
+// 100 us per launch = 3.1 TB/s, latency-bound (Little: 49 KB / ~3.4 us per CU).  Here every operand of a tile -- A [16, K], x
+// [16, 192] float32, add1 / add2 [16, 192] bf16, mean / rstd [16] -- goes HBM -> LDS with global_load_lds_dwordx4 (no staging
+// registers) into a ring of THREE stages, two of them in flight while the third is consumed (~100 KB per CU).  A stage is a
+// lane-linear sequence of 16-byte slots (the DMA writes wave-base + lane * 16): rows of A padded by two dummy slots (ROWB = 2K + 32,
+// the conflict-free fragment stride), rows of x by two (800 B), rows of add1 / add2 by two (416 B); 12 waves x 5 instructions cover
+// the 52 KB (invalid slots re-load a valid address); mean / rstd ride in the spare half of the A image's last KB through a sixth,
+// exec-masked instruction; every wave issues exactly six per stage so the counted waits are uniform.
+// One barrier per tile, as before:  issue DMA(t+2) | fragment reads + MFMA chain (stage t) | operand reads -> registers, row
+// partials -> red table | s_waitcnt vmcnt(6): own part of DMA(t+1) landed (loads retire in order, so "at most the 6 youngest
+// outstanding" is exact even with the dx store in the stream) | s_barrier: every wave's part of stage t+1 landed, the red table is
+// complete, nobody reads stage t any more (so DMA(t+3) may overwrite it next iteration) | row sums, dx, store.
+// Every LDS access of the loop is inline assembly: for a compiler-visible LDS read hipcc drains s_waitcnt vmcnt(0) behind an
+// LDS-DMA (it may alias), which would serialise the ring; the waits are spelled out and tied to the registers they cover.
+// Requires M % 16 == 0 (no partial tile: no masking, no clamped sources); other M run the register-staged kernel above.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_PTR(char))(char*)p; }
+__device__ __forceinline__ u32x4 ds_read128_asm(unsigned addr, int off) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ u32x4 ds_read128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ u32x2 ds_read64_a(unsigned addr) { u32x2 v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr)); return v; }
+__device__ __forceinline__ float ds_read32_a(unsigned addr) { float v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); return v; }
+__device__ __forceinline__ void ds_write64_a(unsigned addr, f32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// "these registers are valid from here": ties a spelled-out wait to the values it covers so nothing consuming them moves above it
+#define TIE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
+template <int KT, bool HAS2>
+__global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  constexpr int K = KT * 32, D = 192, NWV = 12;
+  constexpr int ROWB = K * 2 + 32, SA = ROWB / 16;            // A row: K/8 data slots + 2 pad slots
+  constexpr int NA = (16 * SA + 63) / 64;                      // DMA wave-instructions of the A image
+  constexpr int XS = 50, XB = XS * 16, NX = (16 * XS + 63) / 64;      // x rows: 48 + 2 slots (800 B)
+  constexpr int PS = 26, PB = PS * 16, NP = (16 * PS + 63) / 64;      // add rows: 24 + 2 slots (416 B)
+  constexpr int I_X = NA, I_1 = I_X + NX, I_2 = I_1 + NP, NI = I_2 + NP;
+  constexpr int STAGE = NI * 1024;
+  // mean / rstd of the tile's 16 rows ride in the spare upper half of the A image's last KB (A fills lanes 0..31 of it for both K):
+  // a sixth, exec-masked instruction per wave (lanes 32..35 mean, 36..39 rstd; every wave issues it so the counts stay uniform)
+  static_assert((16 * SA) % 64 == 32, "spare half block behind the A image");
+  constexpr int MR_OFF = (NA - 1) * 1024 + 512;
+  static_assert(NI <= 5 * NWV && 3 * STAGE + 2 * 16 * NWV * 8 + D * 4 <= 160 * 1024, "ring does not fit");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sRed = reinterpret_cast<float*>(smem + 3 * STAGE);    // [2][16 rows][12 waves][2]
+  const int tid = threadIdx.x, lane = tid & 63, gq = lane >> 4, li = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T* __restrict__ W = reinterpret_cast<const T*>(g.W);
+  T* __restrict__ dx = reinterpret_cast<T*>(g.dx);
+  const int ntiles = g.M / 16;
+  const int n = w * 16 + gq * 4;
+
+  typename MM::Frag bf[KT];
+#pragma unroll
+  for (int ks = 0; ks < KT; ++ks)
+    bf[ks] = __builtin_bit_cast(typename MM::Frag, *reinterpret_cast<const u32x4*>(W + (size_t)(w * 16 + li) * K + (ks * 4 + gq) * 8));
+  float* sGam = sRed + 2 * 16 * NWV * 2;                       // gamma [192] in the last spare 768 bytes: re-read per tile, 4 VGPRs less
+  if (tid < D) sGam[tid] = g.gamma[tid];
+  const unsigned gaddr = lds_addr(sGam) + (unsigned)n * 4u;
+  const float a1 = g.a1 ? *g.a1 : 1.f, a2 = g.a2 ? *g.a2 : 1.f;
+  const bool has1 = g.add1 != nullptr;
+  constexpr bool has2 = HAS2;             // add2 (and <add2, x>) compiled out of LayerNorm2's instance: fewer live registers
+  f32x4 dgam = {0.f, 0.f, 0.f, 0.f}, dbet = {0.f, 0.f, 0.f, 0.f};
+  float dotA = 0.f, dotB = 0.f;
+  constexpr float invD = 1.0f / (float)D;
+
+  // ---- this wave's five DMA instructions per stage: wave-uniform region (base pointer, bytes per tile, LDS offset) + lane offset
+  const char* rb[5]; unsigned rstride[5], rdst[5], loff[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    int I = q * NWV + w;
+    const bool dup = I >= NI || (I >= I_1 && I < I_2 && !has1) || (I >= I_2 && !has2);
+    if (dup) I = w;                                   // re-issue this wave's first A instruction: same source, same slots
+    const int sl = (I - (I < I_X ? 0 : I < I_1 ? I_X : I < I_2 ? I_1 : I_2)) * 64 + lane;
+    rdst[q] = (unsigned)I * 1024u;
+    if (I < I_X) {
+      const int row = sl / SA, c = sl % SA;
+      rb[q] = reinterpret_cast<const char*>(g.A); rstride[q] = 16u * K * 2u;
+      loff[q] = row < 16 ? (unsigned)(row * K * 2 + (c < K / 8 ? c : 0) * 16) : 0u;
+    } else if (I < I_1) {
+      const int row = sl / XS, c = sl % XS;
+      rb[q] = reinterpret_cast<const char*>(g.x); rstride[q] = 16u * D * 4u;
+      loff[q] = row < 16 ? (unsigned)(row * D * 4 + (c < 48 ? c : 0) * 16) : 0u;
+    } else {
+      const int row = sl / PS, c = sl % PS;
+      rb[q] = reinterpret_cast<const char*>(I < I_2 ? g.add1 : g.add2); rstride[q] = 16u * D * 2u;
+      loff[q] = row < 16 ? (unsigned)(row * D * 2 + (c < 24 ? c : 0) * 16) : 0u;
+    }
+  }
+  const long long mr_delta = reinterpret_cast<const char*>(g.rstd) - reinterpret_cast<const char*>(g.mean);     // scalar
+  const unsigned mr_lo = (unsigned)(lane & 3) * 16u;
+  const bool mr_lane = lane >= 32 && lane < 40, mr_r = lane >= 36;
+  auto issue = [&](int tile, int st) {
+    const int t = tile < ntiles ? tile : ntiles - 1;            // past the end: redundant loads keep the instruction count uniform
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      // (tile * bytes-per-tile + lane offset) is formed per issue and added to the SCALAR region base: written as base + lane offset
+      // first, hipcc hoists six loop-invariant 64-bit per-lane pointers (12 VGPRs) and spills W^T fragments to make room
+      const char* src = rb[q] + ((unsigned long long)(unsigned)t * (unsigned long long)rstride[q] + (unsigned long long)loff[q]);
+      char* dst = smem + st * STAGE + rdst[q];
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+    if (mr_lane) {
+      const char* src = reinterpret_cast<const char*>(g.mean) + ((unsigned long long)(unsigned)t * 64ull + mr_lo) + (mr_r ? mr_delta : 0ll);
+      char* dst = smem + st * STAGE + (NA - 1) * 1024;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+  };
+  const unsigned s0 = lds_addr(smem);
+  const unsigned fragoff = (unsigned)(li * ROWB + gq * 16);
+  const unsigned xoff = (unsigned)(I_X * 1024 + li * XB + n * 4), poff = (unsigned)(I_1 * 1024 + li * PB + n * 2), moff = (unsigned)(MR_OFF + li * 4);
+  const unsigned redr = lds_addr(sRed) + (unsigned)(li * NWV * 8);
+
+  int tile = blockIdx.x;
+  issue(tile, 0);
+  issue(tile + gridDim.x, 1);
+  wait_vm<6>();
+  __builtin_amdgcn_s_barrier();
+  int st = 0, par = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    issue(tile + 2 * gridDim.x, st == 0 ? 2 : st - 1);        // stage (it + 2) % 3: nobody reads it since the last barrier
+    const unsigned sb = s0 + (unsigned)(st * STAGE);
+    // ---- MFMA chain: fragments in pairs, the next pair requested before the current one is waited for (16 VGPRs of fragments
+    //      next to the 96 of W^T; groups of four spilled 16 registers at K = 768 and ran 132 us against 104 register-staged)
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+    constexpr bool DB = KT <= 18;                     // K = 576: room for a second fragment pair (81 us against 97 single-buffered)
+    u32x4 fa[2], fb[2];
+    const unsigned fr = sb + fragoff;
+#define RD2(dst, ks0) dst[0] = ds_read128<(ks0) * 64>(fr); dst[1] = ds_read128<(ks0) * 64 + 64>(fr);
+#define GROUP(gk, cur, nxt) if ((gk) < KT / 2) { \
+      if (DB) { if ((gk) + 1 < KT / 2) { RD2(nxt, ((gk) + 1) * 2) wait_lgkm<2>(); } else wait_lgkm<0>(); \
+                asm volatile("" : "+v"(cur[0]), "+v"(cur[1])); \
+                c0 = MM::mma(bf[(gk) * 2], __builtin_bit_cast(typename MM::Frag, cur[0]), c0); \
+                c0 = MM::mma(bf[(gk) * 2 + 1], __builtin_bit_cast(typename MM::Frag, cur[1]), c0); } \
+      else { RD2(fa, (gk) * 2) wait_lgkm<0>(); \
+             asm volatile("" : "+v"(fa[0]), "+v"(fa[1])); \
+             c0 = MM::mma(bf[(gk) * 2], __builtin_bit_cast(typename MM::Frag, fa[0]), c0); \
+             c0 = MM::mma(bf[(gk) * 2 + 1], __builtin_bit_cast(typename MM::Frag, fa[1]), c0); } }
+    static_assert(KT % 2 == 0 && KT <= 24, "pairs of k-steps");
+    if (DB) { RD2(fa, 0) }
+    GROUP(0, fa, fb) GROUP(1, fb, fa) GROUP(2, fa, fb) GROUP(3, fb, fa) GROUP(4, fa, fb) GROUP(5, fb, fa)
+    GROUP(6, fa, fb) GROUP(7, fb, fa) GROUP(8, fa, fb) GROUP(9, fb, fa) GROUP(10, fa, fb) GROUP(11, fb, fa)
+#undef GROUP
+#undef RD2
+    // ---- this row's LayerNorm operands from the stage (they stay in registers across the barrier)
+    u32x4 xr = ds_read128<0>(sb + xoff);
+    u32x2 r1 = {0u, 0u}, r2 = {0u, 0u};
+    if (has1) asm volatile("ds_read_b64 %0, %1" : "=v"(r1) : "v"(sb + poff));
+    if (has2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r2) : "v"(sb + poff), "n"((I_2 - I_1) * 1024));
+    float mean, rstd;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(mean) : "v"(sb + moff));
+    asm volatile("ds_read_b32 %0, %1 offset:64" : "=v"(rstd) : "v"(sb + moff));
+    u32x4 gr = ds_read128<0>(gaddr);
+    wait_lgkm<0>();
+    asm volatile("" : "+v"(xr), "+v"(r1), "+v"(r2), "+v"(mean), "+v"(rstd), "+v"(gr));
+    const f32x4 xv = __builtin_bit_cast(f32x4, xr);
+    f32x4 gam = __builtin_bit_cast(f32x4, gr);
+    {
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mean) * rstd;
+        const float gy = c0[e] * gam[e];
+        dgam[e] += c0[e] * xh;
+        dbet[e] += c0[e];
+        p1 += gy;
+        p2 += gy * xh;
+      }
+      p1 += __shfl_xor(p1, 16, 64); p1 += __shfl_xor(p1, 32, 64);
+      p2 += __shfl_xor(p2, 16, 64); p2 += __shfl_xor(p2, 32, 64);
+      if (gq == 0) ds_write64_a(redr + (unsigned)(par * 16 * NWV * 8 + w * 8), f32x2{p1, p2});
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c0[e] *= gam[e];
+    }
+    wait_vm<6>();                                               // own part of the NEXT stage has landed
+    wait_lgkm<0>();
+    __builtin_amdgcn_s_barrier();
+    float c1 = 0.f, c2 = 0.f;
+    {
+      const unsigned rr = redr + (unsigned)(par * 16 * NWV * 8);
+      // 12 (p1, p2) pairs of this row, in wave order; two batches of three reads (12 VGPRs in flight instead of 24)
+      u32x4 t0 = ds_read128<0>(rr), t1 = ds_read128<16>(rr), t2 = ds_read128<32>(rr);
+      wait_lgkm<0>();
+      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));
+      {
+        const f32x4 a = __builtin_bit_cast(f32x4, t0), b = __builtin_bit_cast(f32x4, t1), c = __builtin_bit_cast(f32x4, t2);
+        c1 += a[0]; c2 += a[1]; c1 += a[2]; c2 += a[3]; c1 += b[0]; c2 += b[1]; c1 += b[2]; c2 += b[3]; c1 += c[0]; c2 += c[1]; c1 += c[2]; c2 += c[3];
+      }
+      t0 = ds_read128<48>(rr); t1 = ds_read128<64>(rr); t2 = ds_read128<80>(rr);
+      wait_lgkm<0>();
+      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));
+      {
+        const f32x4 a = __builtin_bit_cast(f32x4, t0), b = __builtin_bit_cast(f32x4, t1), c = __builtin_bit_cast(f32x4, t2);
+        c1 += a[0]; c2 += a[1]; c1 += a[2]; c2 += a[3]; c1 += b[0]; c2 += b[1]; c1 += b[2]; c2 += b[3]; c1 += c[0]; c2 += c[1]; c1 += c[2]; c2 += c[3];
+      }
+    }
+    c1 *= invD; c2 *= invD;
+    {
+      const f32x4 v1 = {__uint_as_float(r1[0] << 16), __uint_as_float(r1[0] & 0xffff0000u), __uint_as_float(r1[1] << 16), __uint_as_float(r1[1] & 0xffff0000u)};
+      const f32x4 v2 = {__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u), __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mean) * rstd;
+        o[e] = rstd * (c0[e] - c1 - xh * c2);                   // c0 already holds dy * gamma (scaled before the barrier)
+        if (has1) o[e] += a1 * v1[e];
+        if (has2) { o[e] += a2 * v2[e]; dotB += v2[e] * xv[e]; }
+        dotA += o[e] * xv[e];
+      }
+      u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]);
+      *reinterpret_cast<u32x2*>(dx + ((size_t)(tile * 16 + li) * D + n)) = q;
+    }
+    st = st == 2 ? 0 : st + 1;
+    par ^= 1;
+  }
+  wait_vm<0>();                                                 // the redundant tail stages
+  __syncthreads();
+  // ---- dgamma / dbeta: sum over the 16 row lanes; dots over the workgroup (fixed order)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { dgam[e] += __shfl_xor(dgam[e], o, 64); dbet[e] += __shfl_xor(dbet[e], o, 64); }
+  }
+  float* P = g.partial + (size_t)blockIdx.x * (2 * D + 2);
+  if (li == 0) {
+    *reinterpret_cast<f32x2*>(P + n) = f32x2{dgam[0], dgam[1]}; *reinterpret_cast<f32x2*>(P + n + 2) = f32x2{dgam[2], dgam[3]};
+    *reinterpret_cast<f32x2*>(P + D + n) = f32x2{dbet[0], dbet[1]}; *reinterpret_cast<f32x2*>(P + D + n + 2) = f32x2{dbet[2], dbet[3]};
+  }
+  dotA = wave_sum(dotA); dotB = wave_sum(dotB);
+  if (lane == 0) { sRed[2 * w] = dotA; sRed[2 * w + 1] = dotB; }
+  __syncthreads();
+  if (tid < 2) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) t += sRed[2 * q + tid];
+    P[2 * D + tid] = t;
+  }
+}
+#undef TIE4
+
 extern "C" int uvc_gemm_lnbwd_supported(int32_t M, int32_t D, int32_t K, int32_t dtype) {
   return dtype == UVC_BF16 && D == 192 && (K == 768 || K == 576) && M >= 4096;
 }
@@ -1106,7 +1356,22 @@ extern "C" int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* p, void* stream) {
     static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn_lnbwd<KT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__); \
     k_gemm_wsn_lnbwd<KT_><<<grid, 768, sh, st>>>(a); }
-  if (p->K == 768) LNB_LAUNCH(24) else LNB_LAUNCH(18)
+  static const bool use_dma = [] { const char* v = getenv("UVC_LNBWD_DMA"); return v ? atoi(v) != 0 : true; }();
+  const bool al16 = (((uintptr_t)p->add1 | (uintptr_t)p->add2 | (uintptr_t)p->mean | (uintptr_t)p->rstd) & 15) == 0;
+#define LNB_LAUNCH_DMA(KT_) { \
+    constexpr int NA_ = (16 * (KT_ * 4 + 2) + 63) / 64, NI_ = NA_ + 13 + 7 + 7; \
+    const size_t sh = (size_t)3 * NI_ * 1024 + (2 * 16 * 12 * 2 + 192) * sizeof(float); \
+    if (p->add2) { \
+      static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn_lnbwd_dma<KT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+      if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__); \
+      k_gemm_wsn_lnbwd_dma<KT_, true><<<grid, 768, sh, st>>>(a); \
+    } else { \
+      static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn_lnbwd_dma<KT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+      if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__); \
+      k_gemm_wsn_lnbwd_dma<KT_, false><<<grid, 768, sh, st>>>(a); } }
+  if (use_dma && al16 && p->M % 16 == 0) { if (p->K == 768) LNB_LAUNCH_DMA(24) else LNB_LAUNCH_DMA(18) }
+  else if (p->K == 768) LNB_LAUNCH(24) else LNB_LAUNCH(18)
+#undef LNB_LAUNCH_DMA
 #undef LNB_LAUNCH
   UVC_CHECK_LAUNCH();
   return UVC_OK;

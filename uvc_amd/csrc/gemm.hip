@@ -1228,10 +1228,12 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
                 asm volatile("" : "+v"(cur[0]), "+v"(cur[1])); \
                 c0 = MM::mma(bf[(gk) * 2], __builtin_bit_cast(typename MM::Frag, cur[0]), c0); \
                 c0 = MM::mma(bf[(gk) * 2 + 1], __builtin_bit_cast(typename MM::Frag, cur[1]), c0); } \
-      else { RD2(fa, (gk) * 2) wait_lgkm<0>(); \
-             asm volatile("" : "+v"(fa[0]), "+v"(fa[1])); \
+      else if (((gk) & 1) == 0) { RD2(fa, (gk) * 2) RD2(fb, (gk) * 2 + 2) wait_lgkm<0>(); /* K = 768: four reads per wait, single-buffered */ \
+             asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1])); \
              c0 = MM::mma(bf[(gk) * 2], __builtin_bit_cast(typename MM::Frag, fa[0]), c0); \
-             c0 = MM::mma(bf[(gk) * 2 + 1], __builtin_bit_cast(typename MM::Frag, fa[1]), c0); } }
+             c0 = MM::mma(bf[(gk) * 2 + 1], __builtin_bit_cast(typename MM::Frag, fa[1]), c0); \
+             c0 = MM::mma(bf[(gk) * 2 + 2], __builtin_bit_cast(typename MM::Frag, fb[0]), c0); \
+             c0 = MM::mma(bf[(gk) * 2 + 3], __builtin_bit_cast(typename MM::Frag, fb[1]), c0); } }
     static_assert(KT % 2 == 0 && KT <= 24, "pairs of k-steps");
     if (DB) { RD2(fa, 0) }
     GROUP(0, fa, fb) GROUP(1, fb, fa) GROUP(2, fa, fb) GROUP(3, fb, fa) GROUP(4, fa, fb) GROUP(5, fb, fa)

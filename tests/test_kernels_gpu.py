@@ -126,11 +126,13 @@ def test_gemm_nt_streaming_kernel_matches_generic(K, N):
     torch.testing.assert_close(Cu.double(), F.gelu(ref + bias.double()), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("M", [4096 + 21, 4096 + 16, 16 * 1031])
 @pytest.mark.parametrize("K", [768, 576])
-def test_gemm_nt_ksplit_streaming_kernel_matches_generic(K):
-    """The column-sliced weights-stationary kernel (N == 192, K in {576, 768}, M >= 4096; float32 and bf16 outputs) against the generic kernel."""
+def test_gemm_nt_ksplit_streaming_kernel_matches_generic(K, M):
+    """The column-sliced weights-stationary kernel (N == 192, K in {576, 768}, M >= 4096; float32 and bf16 outputs) against the generic kernel.
+    M % 16 == 0 with K = 768 and a residual epilogue selects the LDS-DMA ring variant (fc2 of DeiT-Tiny); a ragged M the register-staged one."""
     from uvc_amd import ops
-    M, N = 4096 + 21, 192
+    N = 192
     A, W = rnd(M, K, seed=91).to(torch.bfloat16), rnd(N, K, seed=92, scale=0.03).to(torch.bfloat16)
     bias, R, R2 = rnd(N, seed=93), rnd(M, N, seed=94), rnd(M, N, seed=95)
     gate = torch.tensor([0.25, 0.75], device=dev())

@@ -67,7 +67,7 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True):
     aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
     add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", L, 9 * u, 2.0 * M * D * F,
         lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu))
-    add("fc2+resid+gate", "k_gemm_wsn16<float, 4" if tiny else "k_gemm", L, 10 * u, 2.0 * M * D * F,
+    add("fc2+resid+gate", "k_gemm_wsn16_dma<4" if tiny else "k_gemm", L, 10 * u, 2.0 * M * D * F,
         lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate))
     if tiny and with_teacher:
         add("teacher mlp_fused", "k_mlp_fused", L, 4 * u, 4.0 * M * D * F, lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32))
@@ -81,9 +81,9 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True):
     q3 = rn(M, 3 * D).to(bf)
     if ops.gemm_lnbwd_supported(M, D, F, dt):
         W2t, Wqt = (rn(D, F) * .02).to(bf), (rn(D, 3 * D) * .02).to(bf)
-        add("dfc1+ln2_bwd", "k_gemm_wsn_lnbwd<24>", L, 8 * u, 2.0 * M * D * F,
+        add("dfc1+ln2_bwd", "k_gemm_wsn_lnbwd_dma<24", L, 8 * u, 2.0 * M * D * F,
             lambda: ops.gemm_nt_lnbwd(hF, W2t, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, a1=gate[1:]))
-        add("dqkv+ln1_bwd", "k_gemm_wsn_lnbwd<18>", L, 8 * u, 2.0 * M * D * 3 * D,
+        add("dqkv+ln1_bwd", "k_gemm_wsn_lnbwd_dma<18", L, 8 * u, 2.0 * M * D * 3 * D,
             lambda: ops.gemm_nt_lnbwd(q3, Wqt, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, add2=add16, a2=gate[:1], dots=dots))
     else:
         dH = torch.empty(M, D, device=dev, dtype=bf)

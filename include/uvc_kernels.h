@@ -89,6 +89,27 @@ typedef struct uvc_attn_args {
 int uvc_attention_fwd(const uvc_attn_args* args, void* stream);
 int uvc_attention_bwd(const uvc_attn_args* args, void* stream);
 
+/* Attention of the first `ntok` query rows (class / distillation token) of every (image, head) against all N keys: what the LAST
+ * block needs, whose other rows never reach the head (UVC/models/model_distilled.py:175-185 for rows 0 .. ntok-1, :507-526).
+ * o / dout are the compact [B, ntok, H*64] rows; the backward recomputes the probabilities and writes the WHOLE dqkv
+ * [B, N, 3, H, 64] (dq = 0 for the other rows, dk / dv dense).  ntok is 1 or 2, N <= 256, head_dim = 64. */
+typedef struct uvc_attn_tok_args {
+  const void* qkv;   /* T [B, N, 3, H, 64] */
+  void* o;           /* T [B, ntok, H*64]  forward output */
+  const void* dout;  /* T [B, ntok, H*64]  backward only */
+  void* dqkv;        /* T [B, N, 3, H, 64] backward output */
+  int32_t B, N, H, head_dim, ntok, dtype;
+  float scale;
+  const int32_t* head_keep;  /* forward only, optional device [H], as in uvc_attn_args */
+} uvc_attn_tok_args;
+int uvc_attention_tok_fwd(const uvc_attn_tok_args* args, void* stream);
+int uvc_attention_tok_bwd(const uvc_attn_tok_args* args, void* stream);
+
+/* Copies `groups` blocks of `group_bytes` bytes: block g from src + g * src_group_stride to dst + g * dst_group_stride (all
+ * multiples of 16 bytes).  Gathers the token rows of a [B, N, D] tensor into [B, ntok, D] (and scatters them back). */
+int uvc_copy_row_groups(const void* src, void* dst, int64_t groups, int64_t group_bytes, int64_t src_group_stride, int64_t dst_group_stride,
+                        void* stream);
+
 /* nn.LayerNorm(D, eps) forward over `rows` rows (model_distilled.py:199,204,288; eps=1e-6 from
  * joint_train.py:138).  Row r of x starts at x + (r / rows_per_group) * group_stride + (r % rows_per_group) * D
  * (dense: rows_per_group = 1, group_stride = D; class/dist-token rows only: group_stride = N*D).

@@ -109,6 +109,10 @@ typedef struct uvc_vit_io {
   const uvc_mlp_compact* mlp_compact;  /* HOST [L] or NULL; entries with width 0 or width == hidden run dense */
   const int32_t* head_keep;            /* device [L, H] or NULL: no-grad forwards skip the attention of heads marked 0 (their
                                           attn.proj input columns are masked to zero, so the result is unchanged); ignored when training */
+  int32_t full_tail;                   /* 0 (default): the last block that runs computes everything behind its qkv projection on the class /
+                                          distillation token rows only -- the only rows of it that reach the head (:507-526), so no output of the
+                                          step changes (uvc_attention_tok_*); 1: all rows, as the reference executes it */
+  int32_t reserved0;
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

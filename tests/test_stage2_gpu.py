@@ -184,8 +184,15 @@ def test_mlp_compaction_equals_the_dense_masked_computation(name, precision):
     # bf16: other GEMM kernels are selected for the compact widths, so bf16-rounded intermediates (dA, dH) differ in the last bit
     # (2^-8 each, and a few of them stack along the backward chain): 2 % of the largest gradient
     assert (f0 - f1).abs().max().item() <= (tol if precision == "fp32" else 2e-2) * scale
-    # one AdamW step moves an element by up to lr in the direction m/sqrt(v), which is ill-conditioned where |g| ~ eps
-    assert (p0 - p1).abs().max().item() <= (0.1 if precision == "fp32" else 2.0) * comp.args.lr
+    # one AdamW step moves an element by lr * g / (|g| + eps): where |g| ~ eps = 1e-8 a 4e-9 difference of summation order is a
+    # 0.1 lr difference of the step (one such element of blocks.11.mlp.fc2.weight at batch 8, where the last block's gradients come
+    # from the 8 class-token rows only), so the float32 bound is conditioned on the element: 0.05 lr + the first-order bound
+    if precision == "fp32":
+        n = f0.numel()
+        cond = (f0 - f1).abs() / (torch.minimum(f0.abs(), f1.abs()) + 1e-8)
+        assert bool(((p0[:n] - p1[:n]).abs() <= comp.args.lr * (0.05 + 1.5 * cond)).all())
+    else:
+        assert (p0 - p1).abs().max().item() <= 2.0 * comp.args.lr
     # rows of pruned units in dW1 / db1 are exact zeros
     m = comp.model
     for l, w in enumerate(comp.mlp_widths):

@@ -58,6 +58,11 @@ class uvc_attn_args(C.Structure):
                [(n, C.c_int32) for n in ("B", "N", "H", "head_dim", "dtype")] + [("scale", C.c_float), ("head_keep", C.c_void_p)]
 
 
+class uvc_attn_tok_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv", "o", "dout", "dqkv")] + \
+               [(n, C.c_int32) for n in ("B", "N", "H", "head_dim", "ntok", "dtype")] + [("scale", C.c_float), ("head_keep", C.c_void_p)]
+
+
 class uvc_ln_reduce_item(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("partial", "dgamma", "dbeta", "dots")] + [("nblocks", C.c_int32), ("reserved", C.c_int32)]
 
@@ -127,6 +132,9 @@ _SIGNATURES = {
     "uvc_gemm_tn_workspace_bytes": [I32, I32, I32, C.POINTER(I64), C.POINTER(I32)],
     "uvc_attention_fwd": [C.POINTER(uvc_attn_args), VP],
     "uvc_attention_bwd": [C.POINTER(uvc_attn_args), VP],
+    "uvc_attention_tok_fwd": [C.POINTER(uvc_attn_tok_args), VP],
+    "uvc_attention_tok_bwd": [C.POINTER(uvc_attn_tok_args), VP],
+    "uvc_copy_row_groups": [VP, VP, I64, I64, I64, I64, VP],
     "uvc_layernorm_fwd": [C.POINTER(uvc_ln_args), VP],
     "uvc_layernorm_bwd": [C.POINTER(uvc_ln_args), VP],
     "uvc_layernorm_bwd_blocks": [I32],

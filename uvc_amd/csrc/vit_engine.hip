@@ -50,7 +50,14 @@ struct BlockBufs {
   float* x; void* h1; void* qkv; void* o; float* lse; float* mean1; float* rstd1;
   float* x1; void* h2; float* mean2; float* rstd2; void* a; void* u;
 };
+// Compact [B * ntok, .] buffers of the last block's tail (token_tail.hip): only the class / distillation token rows of the last
+// block reach the head, so its attention output, proj, LayerNorm2, MLP and their backward run on those rows alone
+struct TailBufs {
+  float* xc; void* oc; float* x1c; void* h2c; float* mean2c; float* rstd2c; void* ac; void* uc; float* xoutc;
+  void* gAc; void* dAc; void* dHc; void* gBc; void* dOc;      // backward
+};
 struct Work {
+  TailBufs tail;
   void* patches; float* pe; BlockBufs blk[UVC_VIT_MAX_DEPTH]; float* xL;
   void* hc; float* meanf; float* rstdf;
   // backward scratch
@@ -105,6 +112,17 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
     w.dotsraw = (float*)c.take((int64_t)(d.L + 1) * 2 * 4);
     w.dhc = c.take((int64_t)d.B * d.ntok * d.D * d.tsz);
     w.dpe = c.take((int64_t)d.B * d.np * d.D * d.tsz);
+  }
+  {
+    const int64_t Rt = (int64_t)d.B * d.ntok;
+    TailBufs& t = w.tail;
+    t.xc = (float*)c.take(Rt * d.D * 4); t.oc = c.take(Rt * d.D * d.tsz); t.x1c = (float*)c.take(Rt * d.D * 4);
+    t.h2c = c.take(Rt * d.D * d.tsz); t.mean2c = (float*)c.take(Rt * 4); t.rstd2c = (float*)c.take(Rt * 4);
+    t.ac = c.take(Rt * d.F * d.tsz); t.uc = c.take(Rt * d.F * d.tsz); t.xoutc = (float*)c.take(Rt * d.D * 4);
+    if (training) {
+      t.gAc = c.take(Rt * d.D * d.tsz); t.dAc = c.take(Rt * d.F * d.tsz); t.dHc = c.take(Rt * d.D * d.tsz);
+      t.gBc = c.take(Rt * d.D * d.tsz); t.dOc = c.take(Rt * d.D * d.tsz);
+    }
   }
   return c.off;
 }
@@ -235,6 +253,30 @@ int attn(const Ctx& c, const BlockBufs& b, bool bwd, int layer = -1) {
   a.qkv = b.qkv; a.o = b.o; a.lse = b.lse; a.dout = c.w.dH; a.dqkv = c.w.dqkv; a.delta = c.w.delta;
   a.B = c.d.B; a.N = c.d.N; a.H = c.d.H; a.head_dim = 64; a.dtype = c.d.dtype; a.scale = 0.125f;
   return bwd ? uvc_attention_bwd(&a, c.st) : uvc_attention_fwd(&a, c.st);
+}
+
+int attn_tok(const Ctx& c, const BlockBufs& b, bool bwd, int layer = -1) {
+  uvc_attn_tok_args a;
+  memset(&a, 0, sizeof(a));
+  if (!bwd && layer >= 0 && !c.io->training && c.io->head_keep) a.head_keep = c.io->head_keep + (size_t)layer * c.d.H;
+  a.qkv = b.qkv; a.o = c.w.tail.oc; a.dout = c.w.tail.dOc; a.dqkv = c.w.dqkv;
+  a.B = c.d.B; a.N = c.d.N; a.H = c.d.H; a.head_dim = 64; a.ntok = c.d.ntok; a.dtype = c.d.dtype; a.scale = 0.125f;
+  return bwd ? uvc_attention_tok_bwd(&a, c.st) : uvc_attention_tok_fwd(&a, c.st);
+}
+// token rows of a [B, N, D] tensor (element size esz) -> compact [B, ntok, D], or back
+int gather_tok(const Ctx& c, const void* full, void* compact, size_t esz) {
+  return uvc_copy_row_groups(full, compact, c.d.B, (int64_t)c.d.ntok * c.d.D * esz, (int64_t)c.d.N * c.d.D * esz, (int64_t)c.d.ntok * c.d.D * esz, c.st);
+}
+int scatter_tok(const Ctx& c, const void* compact, void* full, size_t esz) {
+  return uvc_copy_row_groups(compact, full, c.d.B, (int64_t)c.d.ntok * c.d.D * esz, (int64_t)c.d.ntok * c.d.D * esz, (int64_t)c.d.N * c.d.D * esz, c.st);
+}
+// the last block that runs: its tail is computed on the token rows only (unless the caller asks for the reference's full rows)
+int tail_block(const Ctx& c) {
+  if (c.io->full_tail) return -1;
+  int last = -1;
+  for (int l = 0; l < c.d.L; ++l)
+    if (c.io->gate_d || !c.io->run_block || c.io->run_block[l] != 0) last = l;
+  return last;
 }
 
 #define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
@@ -392,15 +434,32 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
   TRY(uvc_assemble_tokens(w.pe, P + o.cls_token, d.ntok == 2 ? P + o.dist_token : nullptr, P + o.pos_embed, io->patch_mask, x0, d.B, d.np,
                           d.D, d.ntok, stream));
   float* xin = x0;
+  const int tl = tail_block(c);
+  const TailBufs& t = w.tail;
+  const int Rt = d.B * d.ntok;
   for (int l = 0; l < d.L; ++l) {
     if (!runs(l)) continue;
-    float* xout = io->training ? next_in(l + 1) : (xin == w.blk[0].x ? w.xL : w.blk[0].x);
+    const bool tail = l == tl;
+    float* xout = tail ? t.xoutc : io->training ? next_in(l + 1) : (xin == w.blk[0].x ? w.xL : w.blk[0].x);
     const BlockBufs& b = w.blk[l];
     const int64_t* q = o.blk[l];
     TRY(ln_fwd(c, xin, q[0], q[1], b.h1, b.mean1, b.rstd1, d.M, 1, d.D));
     TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, d.qkv_bias ? UVC_EPI_BIAS : UVC_EPI_NONE, d.qkv_bias ? P + q[3] : nullptr));
-    TRY(attn(c, b, false, l));
-    TRY(nt(c, b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), b.x1, 1, d.M, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xin));
+    // From here on the last block works on its token rows only (rows = B * ntok, compact buffers): nothing else of it reaches the head
+    const int rows = tail ? Rt : d.M;
+    const float* xres = xin;                 // the block's input rows: residual of proj, R2 of the gate mix
+    float* x1 = tail ? t.x1c : b.x1;
+    void* h2 = tail ? t.h2c : b.h2;
+    float* mean2 = tail ? t.mean2c : b.mean2; float* rstd2 = tail ? t.rstd2c : b.rstd2;
+    void* ga = tail ? t.ac : b.a; void* gu = tail ? t.uc : b.u;
+    if (tail) {
+      TRY(attn_tok(c, b, false, l));
+      TRY(gather_tok(c, xin, t.xc, 4));
+      xres = t.xc;
+    } else {
+      TRY(attn(c, b, false, l));
+    }
+    TRY(nt(c, tail ? t.oc : b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), x1, 1, rows, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xres));
     // Stage-2 compaction: pruned hidden units are skipped (compact weights gathered by the host, uvc_mlp_compact)
     const uvc_mlp_compact* mc = (io->mlp_compact && io->mlp_compact[l].width > 0 && io->mlp_compact[l].width < d.F) ? &io->mlp_compact[l] : nullptr;
     const int Fe = mc ? mc->width : d.F;
@@ -411,26 +470,28 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
       // no-grad forward (teacher / eval): LayerNorm + fc1 + GELU + fc2 + residual in one kernel, hidden activation in registers
       uvc_mlp_args m;
       memset(&m, 0, sizeof(m));
-      m.x = b.x1; m.gamma = P + q[6]; m.beta = P + q[7]; m.w1 = w1; m.b1 = b1;
-      m.w2 = w2; m.b2 = P + q[11]; m.out = xout; m.M = d.M; m.D = d.D; m.F = Fe; m.eps = d.eps;
+      m.x = x1; m.gamma = P + q[6]; m.beta = P + q[7]; m.w1 = w1; m.b1 = b1;
+      m.w2 = w2; m.b2 = P + q[11]; m.out = xout; m.M = rows; m.D = d.D; m.F = Fe; m.eps = d.eps;
       TRY(uvc_mlp_fused_fwd(&m, c.st));
       xin = xout;
       continue;
     }
-    TRY(ln_fwd(c, b.x1, q[6], q[7], b.h2, b.mean2, b.rstd2, d.M, 1, d.D));
+    TRY(ln_fwd(c, x1, q[6], q[7], h2, mean2, rstd2, rows, 1, d.D));
     if (io->training)
-      // b.a receives GELU'(pre-activation): that is all the backward needs of it (one multiply in the dgrad epilogue)
-      TRY(nt(c, b.h2, 0, w1, b.a, 0, d.M, Fe, d.D, UVC_EPI_BIAS_GELU_GRAD, b1, nullptr, nullptr, nullptr, nullptr, b.u));
+      // `ga` receives GELU'(pre-activation): that is all the backward needs of it (one multiply in the dgrad epilogue)
+      TRY(nt(c, h2, 0, w1, ga, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_GRAD, b1, nullptr, nullptr, nullptr, nullptr, gu));
     else   // inference (teacher / eval): the pre-activation is not needed, write GELU(a) only
-      TRY(nt(c, b.h2, 0, w1, b.u, 0, d.M, Fe, d.D, UVC_EPI_BIAS_GELU_OUT, b1));
+      TRY(nt(c, h2, 0, w1, gu, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_OUT, b1));
     if (io->gate_d)
-      TRY(nt(c, b.u, 0, w2, xout, 1, d.M, d.D, Fe, UVC_EPI_BIAS_RESID_GATE, P + q[11], b.x1, xin, nullptr, io->gate_d + 2 * l));
+      TRY(nt(c, gu, 0, w2, xout, 1, rows, d.D, Fe, UVC_EPI_BIAS_RESID_GATE, P + q[11], x1, xres, nullptr, io->gate_d + 2 * l));
     else
-      TRY(nt(c, b.u, 0, w2, xout, 1, d.M, d.D, Fe, UVC_EPI_BIAS_RESID, P + q[11], b.x1));
+      TRY(nt(c, gu, 0, w2, xout, 1, rows, d.D, Fe, UVC_EPI_BIAS_RESID, P + q[11], x1));
     xin = xout;
   }
-  if (io->training && xin != w.xL) return uvc_set_error_msg(UVC_ERR_LAUNCH, "uvc_vit_forward: internal buffer chain broken");
+  if (io->training && tl < 0 && xin != w.xL) return uvc_set_error_msg(UVC_ERR_LAUNCH, "uvc_vit_forward: internal buffer chain broken");
   // final norm on the class(/dist) token rows only (:507-508), then the head(s) (:522-526)
+  if (tl >= 0) TRY(ln_fwd(c, t.xoutc, o.norm_w, o.norm_b, w.hc, w.meanf, w.rstdf, Rt, 1, d.D));
+  else
   TRY(ln_fwd(c, xin, o.norm_w, o.norm_b, w.hc, w.meanf, w.rstdf, d.B * d.ntok, d.ntok, (int64_t)d.N * d.D));
   TRY(nt(c, w.hc, 0, wmat(c, o.head_w, c.soff.head_w), io->logits, 1, d.B, d.NC, d.D, UVC_EPI_BIAS, P + o.head_b, nullptr, nullptr, nullptr, nullptr,
          nullptr, nullptr, d.ntok * d.D));
@@ -457,6 +518,8 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   const int gf = d.dtype == UVC_F32 ? 1 : 0;     // "operand is float32" flag of the gA / gB streams
   const int sb = io->stage_begin, se = (io->stage_begin == 0 && io->stage_end == 0) ? d.L + 3 : io->stage_end;
   if (sb < 0 || se > d.L + 3 || sb >= se) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_backward: bad stage range");
+  const int tl = tail_block(c);
+  const TailBufs& t = w.tail;
   if (sb == 0) {
   // heads: dhc = dlogits . W ; dW = dlogits^T . hc ; db = colsum(dlogits)
   TRY(nt(c, io->d_logits, 1, sh(c, so.head_wt), w.dhc, 0, d.B, d.D, d.NC, UVC_EPI_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
@@ -470,6 +533,10 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   // final norm backward -> gA = dL/dx_L (zero except the token rows)
   hipError_t he = hipMemsetAsync(w.gA, 0, (size_t)d.M * d.D * d.tsz, hs);
   if (he != hipSuccess) return uvc_set_error(he, __FILE__, __LINE__);
+  if (tl >= 0) {      // the last block's output exists on the token rows only: compact gradient, copied into the (zero) full stream
+    TRY(ln_bwd(c, w.dhc, t.xoutc, o.norm_w, o.norm_b, w.meanf, w.rstdf, t.gAc, nullptr, nullptr, nullptr, nullptr, w.dotsraw + 2 * d.L, rh, 1, d.D));
+    TRY(scatter_tok(c, t.gAc, w.gA, d.tsz));
+  } else
   TRY(ln_bwd(c, w.dhc, w.xL, o.norm_w, o.norm_b, w.meanf, w.rstdf, w.gA, nullptr, nullptr, nullptr, nullptr, w.dotsraw + 2 * d.L, rh, d.ntok,
              (int64_t)d.N * d.D));
   }
@@ -481,34 +548,50 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     const int64_t* q = o.blk[l];
     const float* g0 = io->gate_d ? io->gate_d + 2 * l : nullptr;       // d0
     const float* g1 = io->gate_d ? io->gate_d + 2 * l + 1 : nullptr;   // d1
-    // MLP: out = d1*(x1 + fc2(u)) + d0*x
+    // MLP: out = d1*(x1 + fc2(u)) + d0*x.  The last block that ran did so on its token rows only (forward): its gradient
+    // streams up to the attention are the compact ones, with the same kernels at rows = B * ntok.
+    const bool tail = l == tl;
+    const int rows = tail ? d.B * d.ntok : d.M;
+    void* gA = tail ? t.gAc : w.gA; void* gB = tail ? t.gBc : w.gB; void* dA = tail ? t.dAc : w.dA; void* dH = tail ? t.dHc : w.dH;
+    const void* fa = tail ? t.ac : b.a; const void* fu = tail ? t.uc : b.u; const void* fh2 = tail ? t.h2c : b.h2;
+    const float* fx1 = tail ? t.x1c : b.x1; const float* fm2 = tail ? t.mean2c : b.mean2; const float* fr2 = tail ? t.rstd2c : b.rstd2;
+    const int bGA = tail ? BUF_OTHER : BUF_GA, bDA = tail ? BUF_OTHER : BUF_DA, bGB = tail ? BUF_OTHER : BUF_GB;
     const uvc_mlp_compact* mc = (io->mlp_compact && io->mlp_compact[l].width > 0 && io->mlp_compact[l].width < d.F) ? &io->mlp_compact[l] : nullptr;
-    TRY(guard_overwrite(c, BUF_DA));
+    const bool fuse2 = !mc && !tail && lnb_fused_ok(c, d.F);
+    if (!tail) TRY(guard_overwrite(c, BUF_DA));
     if (!mc) {
-      TRY(nt(c, w.gA, gf, sh(c, so.blk_wt[l][3]), w.dA, 0, d.M, d.F, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
-      TRY(tn(c, w.gA, gf, b.u, G + q[10], G + q[11], d.M, d.D, d.F, g1, 0, 0, BUF_GA));
-      if (!lnb_fused_ok(c, d.F)) TRY(nt(c, w.dA, 0, sh(c, so.blk_wt[l][2]), w.dH, 0, d.M, d.D, d.F, UVC_EPI_NONE));
-      TRY(tn(c, w.dA, 0, b.h2, G + q[8], G + q[9], d.M, d.F, d.D, nullptr, 0, 0, BUF_DA));
+      TRY(nt(c, gA, gf, sh(c, so.blk_wt[l][3]), dA, 0, rows, d.F, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, fa, nullptr, nullptr, g1));
+      TRY(tn(c, gA, gf, fu, G + q[10], G + q[11], rows, d.D, d.F, g1, 0, 0, bGA));
+      if (!fuse2) TRY(nt(c, dA, 0, sh(c, so.blk_wt[l][2]), dH, 0, rows, d.D, d.F, UVC_EPI_NONE));
+      TRY(tn(c, dA, 0, fh2, G + q[8], G + q[9], rows, d.F, d.D, nullptr, 0, 0, bDA));
     } else {
       const int Fe = mc->width;
       if (io->accumulate != 0.f) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit_backward: gradient accumulation with MLP compaction");
-      TRY(nt(c, w.gA, gf, mc->w2t, w.dA, 0, d.M, Fe, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, b.a, nullptr, nullptr, g1));
-      TRY(tn(c, w.gA, gf, b.u, mc->dw2, G + q[11], d.M, d.D, Fe, g1, 0, 0, BUF_GA, true));     // db2 goes straight to its place
-      TRY(nt(c, w.dA, 0, mc->w1t, w.dH, 0, d.M, d.D, Fe, UVC_EPI_NONE));
-      TRY(tn(c, w.dA, 0, b.h2, mc->dw1, mc->db1, d.M, Fe, d.D, nullptr, 0, 0, BUF_DA, true));
+      TRY(nt(c, gA, gf, mc->w2t, dA, 0, rows, Fe, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, fa, nullptr, nullptr, g1));
+      TRY(tn(c, gA, gf, fu, mc->dw2, G + q[11], rows, d.D, Fe, g1, 0, 0, bGA, true));     // db2 goes straight to its place
+      TRY(nt(c, dA, 0, mc->w1t, dH, 0, rows, d.D, Fe, UVC_EPI_NONE));
+      TRY(tn(c, dA, 0, fh2, mc->dw1, mc->db1, rows, Fe, d.D, nullptr, 0, 0, bDA, true));
       // expand into the full gradient tensors on the stream the wgrads ran on (rank-1 columns for the pruned units)
       TRY(uvc_mlp_scatter_grads(mc->dw1, mc->dw2, mc->db1, mc->inv, P + q[9], G + q[11], d.D, d.F, Fe, G + q[8], G + q[10], G + q[9], 0.f, d.dtype,
                                 c.side ? c.side : c.st));
     }
-    TRY(guard_overwrite(c, BUF_GB));
-    if (!mc && lnb_fused_ok(c, d.F))      // gB = dL/dx1 = LN2'(dA . W1) + d1*gA, the dgrad of fc1 consumed in its epilogue
+    if (!tail) TRY(guard_overwrite(c, BUF_GB));
+    if (fuse2)      // gB = dL/dx1 = LN2'(dA . W1) + d1*gA, the dgrad of fc1 consumed in its epilogue
       TRY(dgrad_ln_bwd(c, w.dA, sh(c, so.blk_wt[l][2]), d.F, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr));
     else
-    TRY(ln_bwd(c, w.dH, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr, d.M, 1, d.D));   // gB = dL/dx1
+    TRY(ln_bwd(c, dH, fx1, q[6], q[7], fm2, fr2, gB, gA, g1, nullptr, nullptr, nullptr, rows, 1, d.D));   // gB = dL/dx1
     // attention
-    TRY(nt(c, w.gB, gf, sh(c, so.blk_wt[l][1]), w.dH, 0, d.M, d.D, d.D, UVC_EPI_NONE));                                      // dO
-    TRY(tn(c, w.gB, gf, b.o, G + q[4], G + q[5], d.M, d.D, d.D, nullptr, 0, 0, BUF_GB));
+    TRY(nt(c, gB, gf, sh(c, so.blk_wt[l][1]), tail ? t.dOc : w.dH, 0, rows, d.D, d.D, UVC_EPI_NONE));                          // dO
+    TRY(tn(c, gB, gf, tail ? t.oc : b.o, G + q[4], G + q[5], rows, d.D, d.D, nullptr, 0, 0, bGB));
     TRY(guard_overwrite(c, BUF_DQKV));
+    if (tail) {
+      TRY(attn_tok(c, b, true));            // writes all of dqkv: dq is zero off the token rows, dk / dv are dense
+      // the full-row stream of dL/dx1 that the LayerNorm1 backward adds: zero but for the token rows
+      TRY(guard_overwrite(c, BUF_GB));
+      const hipError_t he = hipMemsetAsync(w.gB, 0, (size_t)d.M * d.D * d.tsz, hs);
+      if (he != hipSuccess) return uvc_set_error(he, __FILE__, __LINE__);
+      TRY(scatter_tok(c, t.gBc, w.gB, d.tsz));
+    } else
     TRY(attn(c, b, true));
     const bool fuse1 = lnb_fused_ok(c, 3 * d.D);
     if (!fuse1) TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));

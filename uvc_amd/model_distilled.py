@@ -11,6 +11,7 @@ There is no CPU path: constructing the model needs an MI355X.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from functools import partial
 from typing import Optional
 
@@ -52,12 +53,18 @@ class uvc_vit_io(C.Structure):
                 ("run_block", C.POINTER(C.c_int32)), ("patch_mask", C.c_void_p), ("d_patch_mask", C.c_void_p),
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
                 ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
-                ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p)]
+                ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class uvc_mlp_compact(C.Structure):
     _fields_ = [("width", C.c_int32), ("reserved", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("w1", "w1t", "w2", "w2t", "b1", "dw1", "dw2", "db1", "inv")]
+
+
+# The last block's rows other than the class / distillation token never reach the head (model_distilled.py:507-526): the engine
+# computes that block's tail on the token rows only (uvc_vit_io.full_tail = 0; identical outputs and gradients).  UVC_FULL_TAIL=1, or
+# model.full_tail = True, runs every row as the reference does (A/B measurements, tests).
+_FULL_TAIL_DEFAULT = os.environ.get("UVC_FULL_TAIL", "0") not in ("", "0")
 
 
 def _bind():
@@ -477,6 +484,7 @@ class DistilledVisionTransformer(nn.Module):
         io.accumulate = 1.0 if self.grad_accumulate else 0.0
         io.mlp_compact = C.addressof(self._mlp_compact) if self._mlp_compact is not None else None
         io.head_keep = L.ptr(self._head_keep) if (self._head_keep is not None and not training) else None
+        io.full_tail = int(getattr(self, "full_tail", _FULL_TAIL_DEFAULT))
         return io
 
     def _ws_view(self, B, training, which):

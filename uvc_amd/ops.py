@@ -101,6 +101,38 @@ def attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype):
     L.check(L.lib().uvc_attention_bwd(C.byref(a), L.cur_stream()), "uvc_attention_bwd")
 
 
+def _attn_tok_args(qkv, o, B, N, H, ntok, dtype, dout=None, dqkv=None):
+    a = L.uvc_attn_tok_args()
+    for t in (qkv, o, dout, dqkv):
+        if t is not None:
+            _chk(t)
+    a.qkv, a.o = L.ptr(qkv), L.ptr(o)
+    a.dout, a.dqkv = L.ptr(dout), L.ptr(dqkv)
+    a.B, a.N, a.H, a.head_dim, a.ntok, a.dtype, a.scale = B, N, H, 64, ntok, dtype, 0.125
+    return a
+
+
+def attention_tok_fwd(qkv, o, B, N, H, ntok, dtype, head_keep=None):
+    """Attention of the first ntok queries of every (image, head): o is [B, ntok, H*64]."""
+    a = _attn_tok_args(qkv, o, B, N, H, ntok, dtype)
+    if head_keep is not None:
+        _chk(head_keep)
+        a.head_keep = L.ptr(head_keep)
+    L.check(L.lib().uvc_attention_tok_fwd(C.byref(a), L.cur_stream()), "uvc_attention_tok_fwd")
+
+
+def attention_tok_bwd(qkv, o, dout, dqkv, B, N, H, ntok, dtype):
+    a = _attn_tok_args(qkv, o, B, N, H, ntok, dtype, dout, dqkv)
+    L.check(L.lib().uvc_attention_tok_bwd(C.byref(a), L.cur_stream()), "uvc_attention_tok_bwd")
+
+
+def copy_row_groups(src, dst, groups, group_bytes, src_group_stride, dst_group_stride):
+    _chk(src)
+    _chk(dst)
+    L.check(L.lib().uvc_copy_row_groups(L.ptr(src), L.ptr(dst), groups, group_bytes, src_group_stride, dst_group_stride, L.cur_stream()),
+            "uvc_copy_row_groups")
+
+
 def _ln_args(x, gamma, beta, rows, D, dtype, rows_per_group=1, group_stride=None, eps=1e-6):
     a = L.uvc_ln_args()
     a.x, a.gamma, a.beta = L.ptr(x), L.ptr(gamma), L.ptr(beta)

@@ -28,6 +28,20 @@ _real_stdout = sys.stdout
 # algorithmic FLOPs per image per step = 2*(3E + 4*L*Bk + 4*C)
 GFLOP_PER_IMG = {"deit_tiny_patch16_224": 9.972, "deit_small_patch16_224": 36.675, "deit_base_patch16_224": 140.28,
                  "t2t_vit_14": 37.42}      # T2T: 2*(3E + 4*L*Bk + 4*C) with E = 256,647,680; the tokens-to-token dgrad (<= 0.51) not counted
+# Of the last block only the class-token row reaches the head, so the engine runs that block's attention output, proj, LayerNorm2, MLP
+# and their backward on B rows instead of B*N (uvc_vit_io.full_tail = 0): the same loss, logits and gradients
+# with 4 * (2 N^2 D + N D^2 + 2 N D F) * (1 - 1/N) fewer multiply-adds per image (student + teacher forward, 2x backward).  The
+# TFLOP/s figures of the JSON line use the EXECUTED count; `--full_tail 1` runs every row as the reference does.
+def executed_gflop_per_img(model_type, full_tail):
+    gf = GFLOP_PER_IMG.get(model_type)
+    dims = {"deit_tiny_patch16_224": (192, 197), "deit_small_patch16_224": (384, 197), "deit_base_patch16_224": (768, 197)}.get(model_type)
+    if gf is None or dims is None or full_tail:
+        return gf
+    D, N = dims
+    saved_macs = 4.0 * (2.0 * N * N * D + N * D * D + 2.0 * N * D * 4 * D) * (1.0 - 1.0 / N)
+    return gf - 2.0 * saved_macs / 1e9
+
+
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -49,6 +63,7 @@ def parse():
     p.add_argument("--compact_mlp", type=int, default=1, help="stage 2: skip pruned MLP hidden units (0 = dense masked computation)")
     p.add_argument("--serialize", type=int, default=0, help="diagnostic bit mask: 1 = weight gradients on the main stream, 2 = teacher forward on the main stream (3 = no overlap at all)")
     p.add_argument("--cpu_steps", type=int, default=6)
+    p.add_argument("--full_tail", type=int, default=0, help="1: the last block computes all B*N rows like the reference (default: its token rows only; same outputs)")
     return p.parse_args()
 
 
@@ -147,7 +162,7 @@ def kernel_table(args):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_table as KT
     D, H, L = {"deit_tiny_patch16_224": (192, 3, 12), "deit_small_patch16_224": (384, 6, 12), "deit_base_patch16_224": (768, 12, 12)}[args.model_type]
-    rows = KT.measure(KT.build(args.batch, D=D, H=H, L=L), iters=20)
+    rows = KT.measure(KT.build(args.batch, D=D, H=H, L=L, tail=not args.full_tail), iters=20)
     rows.sort(key=lambda r: -r["us_per_step"])
     top = rows[0]
     ridge = PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS          # flop per byte where the two roofs meet (312)
@@ -239,6 +254,10 @@ def main():
         tr = Stage1Trainer(a, device=f"cuda:{local}", distributed=world > 1)
         pruned_state(tr)
         tr.begin_epoch(a.warmup_epochs + 1 if args.phase == "train" else 1)      # UVC-train phase (post warm-up) is the metric, SURVEY.md §8d
+    if args.full_tail:
+        tr.model.full_tail = True
+        if getattr(tr, "teacher", None) is not None:
+            tr.teacher.full_tail = True
     if args.serialize & 1:
         tr.model.two_stream_backward = False
     if args.serialize & 2:
@@ -279,7 +298,7 @@ def main():
     loss = float(out["loss"])
     if rank == 0:
         imgs = world * args.batch * args.steps / dt
-        gf = GFLOP_PER_IMG.get(args.model_type)
+        gf = executed_gflop_per_img(args.model_type, bool(args.full_tail))
         tiny = args.model_type == "deit_tiny_patch16_224"
         metric = (("images/sec UVC Stage-1 step, DeiT-Tiny budget=0.5" if tiny else f"images/sec UVC Stage-1 step, {args.model_type} budget=0.5 (not the headline model)")
                   if args.phase == "train" else
@@ -301,10 +320,28 @@ def main():
                 "final_loss": round(loss, 4)}
         if args.stage == 1:
             line["cur_resource"] = round(float(out["cur"]), 4)
+            line["gflop_per_image"] = {"model": GFLOP_PER_IMG.get(args.model_type), "executed": round(gf, 3) if gf else None,
+                                       "note": "executed < model: the last block's rows that never reach the head are not computed (full_tail=0); TFLOP/s uses executed"}
         else:   # Stage-2 FLOPs per image: teacher 1x forward, student (fwd + bwd) only over the blocks that run
             line.pop("step_tflops_per_gpu"); line.pop("step_frac_of_bf16_mfma_peak")
         if exposed_ms is not None:
             line["exposed_allreduce_ms_per_step"] = round(exposed_ms, 3)       # main stream stalled in reducer.finish(), event-timed
+        if args.stage == 1 and args.phase == "train" and world == 1 and not args.full_tail:
+            # the same step with every row of the last block computed, as the reference executes it (identical outputs; A/B of the
+            # dead-row elimination): 5 + 30 steps
+            models = [tr.model] + ([tr.teacher] if getattr(tr, "teacher", None) is not None else [])
+            for m_ in models:
+                m_.full_tail = True
+            for _ in range(5):
+                tr.step(x, y)
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for _ in range(30):
+                tr.step(x, y)
+            torch.cuda.synchronize()
+            line["images_per_sec_all_rows_of_last_block"] = round(30 * args.batch / (time.perf_counter() - tw), 1)
+            for m_ in models:
+                m_.full_tail = False
         if args.stage == 1 and args.phase == "train" and world == 1:
             # the warm-up-phase step for reference: gates fixed at .5/.5, gate logits frozen, uvc_optimizer returns early
             tr.begin_epoch(1)

@@ -22,8 +22,12 @@ import torch  # noqa: E402
 from uvc_amd import ops  # noqa: E402
 
 
-def build(B, D=192, H=3, L=12, N=197, with_teacher=True):
+def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True):
+    """tail=True (the engine's default, uvc_vit_io.full_tail = 0): the last block runs everything behind its qkv projection on the
+    B class-token rows only, so the full-row kernels of that part launch L - 1 times per pass and the token-query attention once;
+    the proj / MLP GEMMs on B rows are a few microseconds each and are not listed."""
     F, M = 4 * D, B * N
+    Lf = L - 1 if tail else L          # launches per pass of the full-row kernels behind the qkv projection
     dev = "cuda"
     bf = torch.bfloat16
     dt = ops.UVC_BF16
@@ -52,7 +56,7 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True):
     # ---- forward (student; the teacher repeats LayerNorm1, qkv, attention, proj and runs the fused MLP)
     y = torch.empty(M, D, device=dev, dtype=bf)
     m_, r_ = torch.empty(M, device=dev), torch.empty(M, device=dev)
-    add("ln_fwd", "k_ln_fwd_v", (2 + T) * L, 3 * u, 0, lambda: ops.layernorm_fwd(x32, gam, bet, y, m_, r_, M, D, dt))
+    add("ln_fwd", "k_ln_fwd_v", (1 + T) * L + Lf, 3 * u, 0, lambda: ops.layernorm_fwd(x32, gam, bet, y, m_, r_, M, D, dt))
     qkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
     add("qkv", "k_gemm_ws<unsigned short, unsigned short, 1" if tiny else "k_gemm", (1 + T) * L, 4 * u, 2.0 * M * D * 3 * D,
         lambda: ops.gemm_nt(xb, Wqkv, qkv, dtype=dt, epilogue=ops.EPI_BIAS, bias=b3))
@@ -60,20 +64,25 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True):
     o = torch.empty(B, N, D, device=dev, dtype=bf)
     lse = torch.empty(B, H, N, device=dev)
     afl = 4.0 * B * H * N * N * 64
-    add("attn_fwd", "k_attn_fwd", (1 + T) * L, 4 * u, afl, lambda: ops.attention_fwd(qkv3, o, lse, B, N, H, dt))
+    add("attn_fwd", "k_attn_fwd", (1 + T) * Lf, 4 * u, afl, lambda: ops.attention_fwd(qkv3, o, lse, B, N, H, dt))
+    if tail:
+        oc, doc = torch.empty(B, 1, D, device=dev, dtype=bf), rn(B, 1, D).to(bf)
+        dq_t = torch.empty(B, N, 3 * D, device=dev, dtype=bf)
+        add("attn_tok_fwd (last block)", "k_attn_tok_fwd", 1 + T, 2 * u, 0, lambda: ops.attention_tok_fwd(qkv3, oc, B, N, H, 1, dt))
+        add("attn_tok_bwd (last block)", "k_attn_tok_bwd", 1, 5 * u, 0, lambda: ops.attention_tok_bwd(qkv3, oc, doc, dq_t, B, N, H, 1, dt))
     o32 = torch.empty(M, D, device=dev)
-    add("proj+resid", "k_gemm_ws<unsigned short, float, 3" if tiny else "k_gemm", (1 + T) * L, 5 * u, 2.0 * M * D * D,
+    add("proj+resid", "k_gemm_ws<unsigned short, float, 3" if tiny else "k_gemm", (1 + T) * Lf, 5 * u, 2.0 * M * D * D,
         lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=x32))
     aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
-    add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", L, 9 * u, 2.0 * M * D * F,
+    add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
         lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu))
-    add("fc2+resid+gate", "k_gemm_wsn16_dma<4" if tiny else "k_gemm", L, 10 * u, 2.0 * M * D * F,
+    add("fc2+resid+gate", "k_gemm_wsn16_dma<4" if tiny else "k_gemm", Lf, 10 * u, 2.0 * M * D * F,
         lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate))
     if tiny and with_teacher:
-        add("teacher mlp_fused", "k_mlp_fused", L, 4 * u, 4.0 * M * D * F, lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32))
+        add("teacher mlp_fused", "k_mlp_fused", Lf, 4 * u, 4.0 * M * D * F, lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32))
     # ---- backward, main stream
     dA = torch.empty(M, F, device=dev, dtype=bf)
-    add("dfc2 x gelu'", "k_gemm_ws<unsigned short, unsigned short, 8" if tiny else "k_gemm", L, 9 * u, 2.0 * M * D * F,
+    add("dfc2 x gelu'", "k_gemm_ws<unsigned short, unsigned short, 8" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
         lambda: ops.gemm_nt(g16, W1, dA, dtype=dt, epilogue=ops.EPI_MUL_AUX, aux=hF, alpha_ptr=gate))
     dx16, add16 = torch.empty(M, D, device=dev, dtype=bf), g16.clone()
     part = torch.empty(max(ops.layernorm_bwd_blocks(M), 272) * (2 * D + 2), device=dev)
@@ -81,30 +90,30 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True):
     q3 = rn(M, 3 * D).to(bf)
     if ops.gemm_lnbwd_supported(M, D, F, dt):
         W2t, Wqt = (rn(D, F) * .02).to(bf), (rn(D, 3 * D) * .02).to(bf)
-        add("dfc1+ln2_bwd", "k_gemm_wsn_lnbwd_dma<24", L, 8 * u, 2.0 * M * D * F,
+        add("dfc1+ln2_bwd", "k_gemm_wsn_lnbwd_dma<24", Lf, 8 * u, 2.0 * M * D * F,
             lambda: ops.gemm_nt_lnbwd(hF, W2t, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, a1=gate[1:]))
         add("dqkv+ln1_bwd", "k_gemm_wsn_lnbwd_dma<18", L, 8 * u, 2.0 * M * D * 3 * D,
             lambda: ops.gemm_nt_lnbwd(q3, Wqt, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, add2=add16, a2=gate[:1], dots=dots))
     else:
         dH = torch.empty(M, D, device=dev, dtype=bf)
         Wt = (rn(D, 3 * D) * .02).to(bf)
-        add("dfc1", "k_gemm", L, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_nt(hF, W2, dH, dtype=dt, epilogue=ops.EPI_NONE))
+        add("dfc1", "k_gemm", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_nt(hF, W2, dH, dtype=dt, epilogue=ops.EPI_NONE))
         add("dqkv", "k_gemm", L, 4 * u, 2.0 * M * D * 3 * D, lambda: ops.gemm_nt(q3, Wt, dH, dtype=dt, epilogue=ops.EPI_NONE))
-        add("ln_bwd", "k_ln_bwd_v", 2 * L, 5.5 * u, 0,
+        add("ln_bwd", "k_ln_bwd_v", L + Lf, 5.5 * u, 0,
             lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx16, part, dg, db, M, D, dt, add1=g16, a1=gate[1:]))
     dH2 = torch.empty(M, D, device=dev, dtype=bf)
-    add("dproj", "k_gemm_ws<unsigned short, unsigned short, 0" if tiny else "k_gemm", L, 2 * u, 2.0 * M * D * D,
+    add("dproj", "k_gemm_ws<unsigned short, unsigned short, 0" if tiny else "k_gemm", Lf, 2 * u, 2.0 * M * D * D,
         lambda: ops.gemm_nt(g16, Wp, dH2, dtype=dt, epilogue=ops.EPI_NONE))
     do = rn(B, N, D).to(bf)
     dq = torch.empty(B, N, 3 * D, device=dev, dtype=bf)
     dl = torch.empty(B, H, N, device=dev)
-    add("attn_bwd (dq + dkv)", "k_attn_bwd", L, 12 * u, afl * 2.5, lambda: ops.attention_bwd(qkv3, o, lse, do, dq, dl, B, N, H, dt))
+    add("attn_bwd (dq + dkv)", "k_attn_bwd", Lf, 12 * u, afl * 2.5, lambda: ops.attention_bwd(qkv3, o, lse, do, dq, dl, B, N, H, dt))
     # ---- backward, weight-gradient stream (each entry = the split-M GEMM + its fixed-order reduction)
     ws = torch.empty(max(ops.gemm_tn_workspace_bytes(M, F, D), ops.gemm_tn_workspace_bytes(M, D, F), ops.gemm_tn_workspace_bytes(M, 3 * D, D)) // 4, device=dev)
     C1, C2, C3, C4 = torch.empty(D, F, device=dev), torch.empty(F, D, device=dev), torch.empty(D, D, device=dev), torch.empty(3 * D, D, device=dev)
-    add("dW2 (+reduce)", "k_gemm_tn_dma<192, 256", L, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(g16, hF, C1, ws, dtype=dt))
-    add("dW1 (+reduce)", "k_gemm_tn_dma<256, 192", L, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(hF, xb, C2, ws, dtype=dt))
-    add("dWproj (+reduce)", "k_gemm_tn<unsigned short", L, 2 * u, 2.0 * M * D * D, lambda: ops.gemm_tn(g16, xb, C3, ws, dtype=dt))
+    add("dW2 (+reduce)", "k_gemm_tn_dma<192, 256", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(g16, hF, C1, ws, dtype=dt))
+    add("dW1 (+reduce)", "k_gemm_tn_dma<256, 192", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(hF, xb, C2, ws, dtype=dt))
+    add("dWproj (+reduce)", "k_gemm_tn<unsigned short", Lf, 2 * u, 2.0 * M * D * D, lambda: ops.gemm_tn(g16, xb, C3, ws, dtype=dt))
     add("dWqkv (+reduce)", "k_gemm_tn_dma<192, 192", L, 4 * u, 2.0 * M * D * 3 * D, lambda: ops.gemm_tn(q3, xb, C4, ws, dtype=dt))
     # ---- optimiser
     n = 5717440 if tiny else 12 * (4 * D * D + 2 * D * F)

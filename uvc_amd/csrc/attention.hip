@@ -184,7 +184,12 @@ struct AttnArgs {
 // The keys are taken in blocks of at most 8 tiles with a running maximum / sum (two blocks at N = 197): the scores of one
 // block (32 VGPRs) instead of all 56 stay live, the kernel fits 128 VGPRs and runs 8 waves per workgroup, two workgroups per CU
 // (the K / V image in LDS is the limit) = 4 waves per SIMD to hide its MFMA -> max -> exp -> MFMA chain.
-template <typename T, int T0, int NTB>
+// NFULL >= 0: the caller guarantees N / 16 == NFULL, so which tiles hold padded keys is known at compile time -- tiles below NFULL
+// carry no mask code at all, tile NFULL masks by element, tiles above it are all padding (no QK^T MFMAs either).  With N only known
+// at run time (NFULL = -1) hipcc if-converts the wave-uniform "last tile?" test and EVERY tile pays 8 v_cndmask plus the v_readlane
+// reloads of their spilled SGPR masks, and consumes its scores straight behind the two MFMAs that produce them (s_nop 6-7):
+// 180 of the ~600 VALU instructions of a query tile.
+template <typename T, int T0, int NTB, int NFULL>
 __device__ __forceinline__ void attn_key_block(const char* sK, const char* sV, const typename Mma<T>::Frag (&qf)[Geom<T>::KS], int N, float c2, int lane, int g, int li,
                                                float& m_run, float& l_run, f32x4 (&ot)[4]) {
   typedef Mma<T> MM;
@@ -195,9 +200,13 @@ __device__ __forceinline__ void attn_key_block(const char* sK, const char* sV, c
 #pragma unroll
   for (int t = 0; t < NTB; ++t) {
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    if (NFULL >= 0 && T0 + t > NFULL) {             // a tile of padding only
+      st[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) c = MM::mma(row_frag_lds<T>(sK, (T0 + t) * 16 + li, ks * 4 + g), qf[ks], c);
-    if ((T0 + t) * 16 + 16 > N) {                   // only the last tile(s) hold padded keys (wave-uniform branch)
+    if (NFULL >= 0 ? T0 + t == NFULL : (T0 + t) * 16 + 16 > N) {      // only the last tile(s) hold padded keys
 #pragma unroll
       for (int e = 0; e < 4; ++e) if ((T0 + t) * 16 + g * 4 + e >= N) c[e] = -INFINITY;
     }
@@ -235,20 +244,20 @@ __device__ __forceinline__ void attn_key_block(const char* sK, const char* sV, c
   }
 }
 
-template <typename T, int T0, int NT16, int ATT_BT>
+template <typename T, int T0, int NT16, int ATT_BT, int NFULL>
 __device__ __forceinline__ void attn_key_blocks(const char* sK, const char* sV, const typename Mma<T>::Frag (&qf)[Geom<T>::KS], int N, float c2, int lane, int g, int li,
                                                 float& m_run, float& l_run, f32x4 (&ot)[4]) {
   if constexpr (T0 < NT16) {
     constexpr int NTB = (NT16 - T0) < ATT_BT ? (NT16 - T0) : ATT_BT;
-    attn_key_block<T, T0, NTB>(sK, sV, qf, N, c2, lane, g, li, m_run, l_run, ot);
-    attn_key_blocks<T, T0 + NTB, NT16, ATT_BT>(sK, sV, qf, N, c2, lane, g, li, m_run, l_run, ot);
+    attn_key_block<T, T0, NTB, NFULL>(sK, sV, qf, N, c2, lane, g, li, m_run, l_run, ot);
+    attn_key_blocks<T, T0 + NTB, NT16, ATT_BT, NFULL>(sK, sV, qf, N, c2, lane, g, li, m_run, l_run, ot);
   }
 }
 
 // bf16: persistent workgroups (two per CU) walk (image, head) pairs; the K / V rows of the NEXT pair are fetched into registers
 // (4 + 4 chunks per thread) before the tiles of the current one are computed and written to LDS after them, so the HBM latency
 // of the staging -- a third of a head's time when it ran ahead of the tile loop -- hides under the MFMA / exp work.
-template <typename T, int NT16, int ATT_BT = 8>
+template <typename T, int NT16, int ATT_BT = 8, int NFULL = -1>
 __global__ __launch_bounds__(sizeof(T) == 2 ? 512 : 256, sizeof(T) == 2 ? 4 : 1) void k_attn_fwd(AttnArgs a) {
   typedef Mma<T> MM;
   typedef Geom<T> G;
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(sizeof(T) == 2 ? 512 : 256, sizeof(T) == 2 ? 4 : 1)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         float m_run = -INFINITY, l_run = 0.f;
-        attn_key_blocks<T, 0, NT16, ATT_BT>(sK, sV, qf, a.N, c2, lane, g, li, m_run, l_run, ot);
+        attn_key_blocks<T, 0, NT16, ATT_BT, NFULL>(sK, sV, qf, a.N, c2, lane, g, li, m_run, l_run, ot);
         const int q = qt * 16 + li;
         if (q < a.N) {
           const float inv = 1.0f / l_run;
@@ -392,8 +401,9 @@ __global__ __launch_bounds__(512) void k_attn_bwd_dq(AttnArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float p = __builtin_amdgcn_exp2f(c[e] * c2 - lse2);
-          if (t * 16 + 16 > a.N && t * 16 + g * 4 + e >= a.N) p = 0.f;
+          // padded keys need no mask here: their K rows are zero in LDS, so their (finite) ds only ever multiplies zeros in
+          // dq += ds . K (masking cost two compares / selects per score on every tile)
+          const float p = __builtin_amdgcn_exp2f(c[e] * c2 - lse2);
           ds[u][e] = p * ((dp[e] - dl) * a.scale);
         }
       }
@@ -497,9 +507,17 @@ template <typename T, int NT16> int launch(const AttnArgs& a, int which, hipStre
   hipError_t e = hipSuccess;
   if (which == 0) {
     const int fgrid = (sizeof(T) == 2 && grid > 512) ? 512 : grid;      // bf16: two persistent workgroups per CU
-    if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-    k_attn_fwd<T, NT16><<<fgrid, sizeof(T) == 2 ? 512 : 256, sh, st>>>(a);
+    // DeiT's N = 197 / 198: twelve full key tiles, a partial one and a tile of padding -- known at compile time (see attn_key_block)
+    constexpr int NF = NT16 == 14 ? 12 : -1;
+    if (NF >= 0 && a.N / 16 == NF) {
+      if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16, 8, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+      k_attn_fwd<T, NT16, 8, NF><<<fgrid, sizeof(T) == 2 ? 512 : 256, sh, st>>>(a);
+    } else {
+      if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+      k_attn_fwd<T, NT16><<<fgrid, sizeof(T) == 2 ? 512 : 256, sh, st>>>(a);
+    }
   } else if (which == 1) {
     if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_bwd_dq<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);

@@ -588,7 +588,8 @@ def test_fused_training_mlp(M, F_, gated):
     assert all(torch.equal(p[:100], q) for p, q in zip((out, h, mean, rstd, gp, u), part)), "rows depend on the batch"
     o_inf = torch.empty(M, D, device=dev())                                              # the inference form computes the same output
     ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, o_inf, x_prev=xp if gated else None, gate=gate)
-    assert torch.equal(o_inf, out)
+    # (the inference form is its own kernel since r2d -- biases as initial accumulators, another summation order: same math, not bits)
+    torch.testing.assert_close(o_inf, out, rtol=2e-3, atol=6e-3)
 
 
 # ---- patch-gating Gumbel top-k at the production shape

@@ -29,6 +29,8 @@
 // The training form (stores for the backward) runs 276 us against 221 us for LayerNorm + fc1 + fc2 and is NOT wired into the engine.
 #include "common.h"
 #include "../../include/uvc_kernels.h"
+#include <utility>
+#include <cstdlib>
 
 namespace {
 
@@ -293,6 +295,302 @@ __global__ __launch_bounds__(NTH, 2) void k_mlp_fused(uvc_mlp_args a) {
   }
 }
 
+// ---- inference kernel, second generation (r2d): two independent 4-wave workgroups per CU ------------------------------------------
+// Same arithmetic as k_mlp_fused<false> up to where the fc1 bias enters (here it is the initial accumulator), different shape.
+// What the probes of round 2 showed (tools/probe/*.hip, s_memtime traces of the kernel itself):
+//   * one wave issues v_mfma_f32_16x16x32_bf16 every 18.3 cycles; two waves on a SIMD reach 12.3 together;
+//   * a dense VALU stream (the GELU) on one wave of a SIMD stalls the other wave's MFMAs almost completely -- matrix and VALU
+//     phases of the two waves of a SIMD ADD, whatever s_setprio says; only memory waits overlap with either;
+//   * k_mlp_fused's 8 waves run in lockstep (one barrier per chunk), so its row loads / stores (232 MB per layer, 40-50 us at the
+//     ~5 TB/s a mixed stream gets) are exposed before and after a chunk loop that runs at 38 cycles per MFMA.
+// So: a workgroup is FOUR waves (one per SIMD) x 32 rows, two workgroups per CU (256 VGPRs each, 65 KB of LDS each).  They drift
+// apart, so one normalises / stores its rows while the other owns the matrix pipes, and the 788 passes spread over 512 slots
+// without the 394-on-256 tail.  Hidden chunks of 32 units, both weight chunks double-buffered, brought in by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers) one chunk ahead and waited for just before the chunk's one barrier.  The matrix
+// phases are spelled out: fragment reads by inline ds_read_b128 a few MFMAs ahead, counted lgkmcnt waits tied to the registers they
+// cover, a scheduling fence per unit; fc2's first fragments are requested before the GELU so they arrive under it.
+constexpr int V3_NW = 4, V3_NTH = 64 * V3_NW, V3_ROWS = V3_NW * RW * 16, V3_FC = 32;
+constexpr int V3_W2S = V3_FC * 2 + 32;                       // 96 B rows: 24 words, conflict-free for ds_read_b128 with row = lane & 15
+constexpr int V3_W1B = V3_FC * W1S, V3_W2B = D * V3_W2S;     // 13312 + 18432
+constexpr int V3_BUF = V3_W1B + V3_W2B;
+constexpr int V3_OFF_B1 = 2 * V3_BUF;
+constexpr int V3_N1 = V3_FC * 26 / 64, V3_N2 = D * 6 / 64;    // DMA wave-instructions per chunk: 13 + 18
+static_assert(V3_FC * 26 % 64 == 0 && D * 6 % 64 == 0, "whole DMA instructions");
+constexpr int V3_OFF_DUMMY = V3_OFF_B1 + 4096, V3_OFF_GB = V3_OFF_DUMMY + 1024, V3_LDS = V3_OFF_GB + 3 * D * 4;
+constexpr int V3_XS = 50, V3_NXI = (16 * V3_XS + 63) / 64, V3_XTILE = V3_NXI * 1024;     // a wave's 16-row x tile in LDS: 13 KB
+static_assert(V3_NW * V3_XTILE <= 2 * V3_BUF, "row tiles fit the weight buffers");
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_PTR(char))(char*)p; }
+template <int OFF> __device__ __forceinline__ u32x4 ds_rd(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void wait_tie2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int... Is, class Fn> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class Fn> __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+__global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nch = a.F / V3_FC;
+  // b1, b2, gamma, beta -> LDS (behind the weight buffers); they are read by compiler-visible LDS loads in the prologue only
+  float* const sB1 = reinterpret_cast<float*>(smem + V3_OFF_B1);
+  float* const sG = reinterpret_cast<float*>(smem + V3_OFF_GB);
+  float* const sBt = sG + D;
+  float* const sB2 = sBt + D;
+  for (int i = tid; i < a.F; i += V3_NTH) sB1[i] = a.b1[i];
+  if (tid < D) { sG[tid] = a.gamma[tid]; sBt[tid] = a.beta[tid]; sB2[tid] = a.b2[tid]; }
+  float d0 = 0.f, d1 = 1.f;
+  if (a.gate) { d0 = a.gate[0]; d1 = a.gate[1]; }
+  const unsigned s0 = lds_addr(smem);
+  const int m0 = blockIdx.x * V3_ROWS + w * (RW * 16);
+
+  // ---- rows.  A wave's 16-row tile of x goes HBM -> LDS by DMA into the (still empty) weight buffers -- 800-byte rows (48 + 2 slots:
+  //      conflict-free ds_read_b128 with row = lane & 15), 13 instructions, no staging registers -- and is read from there TWICE: in
+  //      the MFMA B-operand layout for the LayerNorm (lane (row, g): columns (ks*4 + g)*8 .. +7) and in the accumulator layout
+  //      (columns j*16 + g*4 .. +3), because fc2's accumulator starts as x1 + b2: the epilogue is stores only and x is read from
+  //      HBM once.  (Through registers -- 48 per tile for the LayerNorm, loaded again for the residual -- hipcc spilled 90-190
+  //      VGPRs around the loads and a row tile took 8-20 k ticks; k_mlp_fused re-reads x from HBM in its epilogue.)
+  bf16x8 hf[RW][KT];
+  f32x4 out[RW][D / 16];
+  {
+    char* const xreg = smem + w * V3_XTILE;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));                                   // per-tile lane addresses: hoisted out of the loop they cost 52 VGPRs for its whole life
+      const char* xb = reinterpret_cast<const char*>(a.x);
+#pragma unroll
+      for (int i = 0; i < V3_NXI; ++i) {
+        const int s = i * 64 + ln, row = s / V3_XS, pc = s % V3_XS;
+        int grow = m0 + r * 16 + (row < 16 ? row : 15);
+        grow = grow < a.M ? grow : a.M - 1;                          // rows past M: any valid row (masked below, never stored)
+        const unsigned off = (unsigned)grow * (unsigned)(D * 4) + (unsigned)((pc < 48 ? pc : 0) * 16);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(xb + (unsigned long long)off),
+                                         (void __attribute__((address_space(3)))*)(xreg + i * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (r == 0) __syncthreads();                                   // gamma / beta / b2 staged (rides on the first tile's wait)
+      const float okf = (m0 + r * 16 + li) < a.M ? 1.0f : 0.0f;
+      const char* xrow = xreg + li * (V3_XS * 16);
+      // the row tile in registers (48 VGPRs); gamma / beta / b2 by inline ds_read per k-step: as ordinary loads hipcc keeps the first
+      // tile's 96 + 48 values alive for the second (common subexpressions) and spills around them
+      f32x4 xv[2 * KT];
+#pragma unroll
+      for (int ks = 0; ks < KT; ++ks) {
+        xv[2 * ks] = *reinterpret_cast<const f32x4*>(xrow + (ks * 4 + g) * 32);
+        xv[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xrow + (ks * 4 + g) * 32 + 16);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2 * KT; ++i) s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2 * KT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; q += d * d; }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = rsqrtf(q * (1.0f / D) + a.eps);
+      const unsigned ga = s0 + (unsigned)(V3_OFF_GB + g * 32), ba = ga + (unsigned)(D * 4);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<KT>([&](auto ksv) {
+        constexpr int ks = ksv.value;
+        u32x4 gq0 = ds_rd<ks * 128>(ga), gq1 = ds_rd<ks * 128 + 16>(ga), bq0 = ds_rd<ks * 128>(ba), bq1 = ds_rd<ks * 128 + 16>(ba);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(bq0), "+v"(bq1));
+        const f32x4 g0 = __builtin_bit_cast(f32x4, gq0), g1 = __builtin_bit_cast(f32x4, gq1);
+        const f32x4 b0 = __builtin_bit_cast(f32x4, bq0), b1 = __builtin_bit_cast(f32x4, bq1);
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y0[e] = ((xv[2 * ks][e] - mean) * rstd * g0[e] + b0[e]) * okf;        // rows past M: zero operands
+          y1[e] = ((xv[2 * ks + 1][e] - mean) * rstd * g1[e] + b1[e]) * okf;
+        }
+        hf[r][ks] = pack8(y0, y1);
+        asm volatile("" : "+v"(hf[r][ks]));            // materialise here: LLVM otherwise SINKS this arithmetic to the first use inside the
+                                                       // chunk loop and keeps (spills) the 24 loaded vectors until then
+        __builtin_amdgcn_sched_barrier(0);             // one k-step at a time: unfenced, the scheduler collects all 24 reads first
+      });
+      const unsigned b2a = s0 + (unsigned)(V3_OFF_GB + 2 * D * 4 + g * 16);
+      static_for<D / 16>([&](auto jv) {
+        constexpr int j = jv.value;
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(xrow + (j * 4 + g) * 16);
+        u32x4 bq = ds_rd<j * 64>(b2a);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq));
+        const f32x4 bv = __builtin_bit_cast(f32x4, bq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[r][j][e] = xr[e] + bv[e];
+        asm volatile("" : "+v"(out[r][j]));
+        if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();                                                  // every wave is done with its rows: the weight buffers may be filled
+  const unsigned w1lane = s0 + (unsigned)(li * W1S + g * 16);
+  const unsigned w2lane = s0 + (unsigned)(V3_W1B + li * V3_W2S + g * 16);
+  const unsigned b1lane = s0 + (unsigned)(V3_OFF_B1 + g * 32);
+
+  // ---- LDS-DMA of a weight chunk: a wave-instruction fills 64 consecutive 16-byte slots.  W1 rows are 24 + 2 slots (416 B), W2 rows
+  //      4 + 2 (96 B); pad slots fetch piece 0 again.  Instructions 0..12 = W1 image, 13..30 = W2 image; wave w issues w, w+4, ...
+  //      LDS row lr of the W1 image holds hidden unit (lr >> 2 & 3) * 8 + (lr >> 4) * 4 + (lr & 3) of the chunk, so that a lane of the
+  //      fc1 result holds 8 consecutive k indices of fc2 (its B operand) -- the permutation costs nothing, it is where the DMA aims.
+  // Eight instructions per wave and chunk, ALWAYS (the 32nd aims at a dummy KB): with a branch around an instruction hipcc
+  // puts s_waitcnt vmcnt(0) in front of every one of them and the eight L2 round trips serialise (4-6 k cycles per chunk).
+  unsigned doff[8];
+  const char* gsrc[8];                 // wave-uniform: source matrix, bytes per chunk, LDS offset inside the chunk buffer
+  unsigned gstep[8], ldst[8], lbuf[8];
+  bool isw1[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int j = w + 4 * q;
+    if (j < V3_N1) {
+      const int s = j * 64 + lane, lr = s / 26, pc = s % 26;
+      const int h = ((lr >> 2) & 3) * 8 + (lr >> 4) * 4 + (lr & 3);
+      doff[q] = (unsigned)(h * D * 2 + (pc < 24 ? pc : 0) * 16);
+      gsrc[q] = reinterpret_cast<const char*>(a.w1); gstep[q] = (unsigned)(V3_FC * D * 2);
+    } else {
+      const int s = ((j < V3_N1 + V3_N2 ? j : V3_N1) - V3_N1) * 64 + lane, r = s / 6, pc = s % 6;
+      doff[q] = (unsigned)(r * a.F * 2 + (pc < 4 ? pc : 0) * 16);
+      gsrc[q] = reinterpret_cast<const char*>(a.w2); gstep[q] = (unsigned)(V3_FC * 2);
+    }
+    isw1[q] = j < V3_N1;
+    const bool real = j < V3_N1 + V3_N2;
+    ldst[q] = real ? (unsigned)(j * 1024) : (unsigned)V3_OFF_DUMMY;           // dummy KB behind b1 (F <= 1024)
+    lbuf[q] = real ? (unsigned)V3_BUF : 0u;
+  }
+  // W1 of chunk c1 and W2 of chunk c2 (the loop is software-pipelined: fc2 runs one chunk behind fc1); a chunk index past the end
+  // sends the instruction to the dummy KB
+  auto dma = [&](int c1, int c2) {
+    // (chunk offset + lane offset) formed per issue and added to the SCALAR base (the other way round hipcc keeps a 64-bit pointer
+    // per instruction in spilled VGPRs)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cc = isw1[q] ? c1 : c2;
+      const bool ok = cc < nch && lbuf[q] != 0u;
+      const char* src = gsrc[q] + (unsigned long long)((unsigned)(ok ? cc : 0) * gstep[q] + doff[q]);
+      char* dst = smem + (ok ? ldst[q] + (unsigned)(cc & 1) * lbuf[q] : (unsigned)V3_OFF_DUMMY);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+  };
+
+  dma(0, nch);                                                      // W1 of chunk 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                                  // chunk 0 landed
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- chunk pipeline.  Iteration c: fc1 of chunk c (24 MFMAs), then fc2 of chunk c - 1 (24 MFMAs) with the GELU of chunk c issued
+  //      BETWEEN its MFMAs: inside one wave an MFMA leaves ~4 issue slots that independent VALU work fills for free, while the same
+  //      GELU as a separate phase (or on the other wave of the SIMD) costs its full issue time on top.  W1 of chunk c + 1
+  //      and W2 of chunk c arrive during iteration c.
+  bf16x8 uf[RW];
+  f32x4 acc[RW][2];
+  auto fc1 = [&](int c) {
+    const unsigned w1a = w1lane + (unsigned)((c & 1) * V3_BUF);
+    const unsigned ba = b1lane + (unsigned)(c * (V3_FC * 4));
+    // a^T = b1 + W1c . h^T: six k-steps of two fragments (hidden tiles t = 0, 1), each feeding the two row tiles; fragments of
+    // k-step ks + 2 are requested under the MFMAs of k-step ks
+    u32x4 bi[2], f1[3][2];
+    bi[0] = ds_rd<0>(ba); bi[1] = ds_rd<16>(ba);
+    f1[0][0] = ds_rd<0>(w1a); f1[0][1] = ds_rd<16 * W1S>(w1a);
+    f1[1][0] = ds_rd<64>(w1a); f1[1][1] = ds_rd<16 * W1S + 64>(w1a);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<KT>([&](auto ksv) {
+      constexpr int ks = ksv.value, cur = ks % 3, nxt = (ks + 2) % 3;
+      wait_tie2<(ks + 1 < KT) ? 2 : 0>(f1[cur][0], f1[cur][1]);
+      if constexpr (ks == 0) asm volatile("" : "+v"(bi[0]), "+v"(bi[1]));
+      static_for<2>([&](auto tv) {
+        constexpr int t = tv.value;
+        const bf16x8 af = __builtin_bit_cast(bf16x8, f1[cur][t]);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[r][t] = mma(af, hf[r][ks], ks == 0 ? __builtin_bit_cast(f32x4, bi[t]) : acc[r][t]);
+        if constexpr (ks + 2 < KT) f1[nxt][t] = ds_rd<t * 16 * W1S + (ks + 2 < KT ? ks + 2 : 0) * 64>(w1a);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+  // out^T += W2c . u^T (twelve output tiles, one k-step; fragment j + 6 is requested when fragment j has been used), FC2 = false:
+  // only the GELU.  GELU = true: units 0 .. 7 each carry the GELU of two values of `acc`; the packed result replaces `uf` at the end.
+  auto fc2_gelu = [&](auto fc2v, auto geluv, int cprev) {
+    constexpr bool FC2 = decltype(fc2v)::value, GELU = decltype(geluv)::value;
+    const unsigned w2a = w2lane + (unsigned)((cprev & 1) * V3_BUF);
+    u32x4 f2[6];
+    if constexpr (FC2) {
+      static_for<6>([&](auto jv) { f2[jv.value] = ds_rd<jv.value * 16 * V3_W2S>(w2a); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<12>([&](auto jv) {
+      constexpr int j = jv.value, slot = j % 6;
+      if constexpr (FC2) {
+        constexpr int younger = (j < 6) ? 5 : 11 - j;               // reads issued after fragment j's that may still be in flight
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f2[slot]) : "n"(younger));
+        const bf16x8 af = __builtin_bit_cast(bf16x8, f2[slot]);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) out[r][j] = mma(af, uf[r], out[r][j]);
+        if constexpr (j + 6 < 12) f2[slot] = ds_rd<(j + 6 < 12 ? j + 6 : 0) * 16 * V3_W2S>(w2a);
+      }
+      if constexpr (GELU && j < 8) {
+        constexpr int r = j >> 2, t = (j >> 1) & 1, e0 = (j & 1) * 2;
+        acc[r][t][e0] = Gelu<T>::f(acc[r][t][e0]);
+        acc[r][t][e0 + 1] = Gelu<T>::f(acc[r][t][e0 + 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (GELU) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r) uf[r] = pack8(acc[r][0], acc[r][1]);
+    }
+  };
+  auto end_iter = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's pieces of the next weights have landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    dma(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    fc1(0);
+    fc2_gelu(std::false_type{}, std::true_type{}, 0);
+    end_iter();
+  }
+  for (int c = 1; c < nch; ++c) {
+    dma(c + 1, c);
+    __builtin_amdgcn_sched_barrier(0);
+    fc1(c);
+    fc2_gelu(std::true_type{}, std::true_type{}, c - 1);
+    end_iter();
+  }
+  fc2_gelu(std::true_type{}, std::false_type{}, nch - 1);
+
+  // ---- out = d1 * ((x1 + b2) + mlp) + d0 * x_prev
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = m0 + r * 16 + li;
+    if (row < a.M) {
+      float* orow = a.out + (size_t)row * D;
+#pragma unroll
+      for (int j = 0; j < D / 16; ++j) {
+        const int col = j * 16 + g * 4;
+        f32x4 o = out[r][j];
+        if (a.gate) {
+          const f32x4 xp = *reinterpret_cast<const f32x4*>(a.x_prev + (size_t)row * D + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(d1, o[e], __builtin_fmaf(d0, xp[e], 0.0f));
+        }
+        *reinterpret_cast<f32x4*>(orow + col) = o;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 extern "C" int uvc_mlp_fused_supported(int32_t D_, int32_t F, int32_t dtype) { return D_ == D && F > 0 && F % FC == 0 && dtype == UVC_BF16; }
@@ -311,6 +609,18 @@ extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
   const int npass = ceil_div(p->M, ROWS);
   const int grid = npass < 256 ? npass : 256;
   hipStream_t st = (hipStream_t)stream;
+  static const bool old_kernel = getenv("UVC_MLP_OLD") != nullptr;
+  if (!train && !old_kernel && p->F % V3_FC == 0 && p->F <= 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      const hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused_v3, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+      if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+      attr_set = true;
+    }
+    k_mlp_fused_v3<<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p);
+    UVC_CHECK_LAUNCH();
+    return UVC_OK;
+  }
   if (train) {
     static const hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);

@@ -112,7 +112,9 @@ typedef struct uvc_vit_io {
   int32_t full_tail;                   /* 0 (default): the last block that runs computes everything behind its qkv projection on the class /
                                           distillation token rows only -- the only rows of it that reach the head (:507-526), so no output of the
                                           step changes (uvc_attention_tok_*); 1: all rows, as the reference executes it */
-  int32_t reserved0;
+  int32_t fused_train_mlp;             /* 1: the training forward runs LayerNorm2 + fc1 (+GELU, GELU') + fc2 (+residual, gate mix) as ONE kernel
+                                          (uvc_mlp_fused_fwd's training form, DeiT-Tiny width) instead of three; measured slower (218 us
+                                          against 187), so 0 is the default */
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

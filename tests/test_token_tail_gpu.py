@@ -186,3 +186,24 @@ def test_token_row_tail_with_hard_block_skip_fp32():
     torch.testing.assert_close(outs[False][0], outs[True][0], rtol=1e-4, atol=1e-5)
     scale = float(outs[True][1].abs().max())
     assert float((outs[False][1] - outs[True][1]).abs().max()) <= 2e-5 * scale
+
+
+def test_fused_training_mlp_in_the_engine_matches_the_three_kernels():
+    """uvc_vit_io.fused_train_mlp = 1 (opt-in): LayerNorm2 + fc1 + GELU / GELU' + fc2 + gate mix of every block as one kernel that also
+    stores the backward's operands -- same logits, loss and gradients as the three-kernel forward up to bf16 rounding order."""
+    B = 16
+    tr = _trainer("bf16", B)
+    tr.begin_epoch(tr.args.warmup_epochs + 1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, 3, 224, 224, device="cuda", generator=g)
+    y = torch.softmax(torch.randn(B, 1000, device="cuda", generator=g), -1)
+    tr.model.train()
+    res = {}
+    for fused in (False, True):
+        tr.model.fused_train_mlp = fused
+        res[fused] = _fwd_bwd(tr, x, y, False)
+    (lo_a, loss_a, g_a, _), (lo_b, loss_b, g_b, _) = res[False], res[True]
+    for a, b in zip(lo_a, lo_b):
+        torch.testing.assert_close(a, b, rtol=3e-2, atol=3e-2)
+    assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_a)
+    assert float((g_a - g_b).norm()) <= 3e-2 * float(g_a.norm()), float((g_a - g_b).norm()) / float(g_a.norm())

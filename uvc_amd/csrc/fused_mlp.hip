@@ -1,49 +1,26 @@
 // Fused MLP half of a DeiT block for gfx950 (embed_dim 192, bf16 MFMA, float32 residual stream):
 //     out = d1 * (x1 + fc2(GELU(fc1(LayerNorm(x1))))) + d0 * x_prev        UVC/models/model_distilled.py:107-124,199-204,241-247,493
-// Two instances:
+// Two instances of one kernel (k_mlp_fused_v3<TRAIN>):
 //   inference (teacher, utils/losses.py:47-49, and eval): nothing but `out` is written; the [M, 768] hidden activation never
 //     leaves the register file (154 MB of HBM traffic per layer at batch 512 instead of 620 MB for LayerNorm, fc1+GELU, fc2);
-//   training (the student's forward): the same pass also stores what the backward reads -- LayerNorm(x1) (bf16 [M, D], operand of
-//     dW1), its mean / rstd, GELU'(a) and GELU(a) (bf16 [M, F], the dgrad epilogue factor and the operand of dW2) -- straight from
-//     the accumulator registers, so LayerNorm2, fc1 and fc2 of the step become ONE kernel and h2 / u are never re-read.
-//
-// Geometry: a workgroup is 8 waves (two per SIMD, 256 VGPRs each) x 32 token rows (2 row tiles).  Every wave normalises its rows in
-// registers (a row is spread over the four 16-lane groups of the MFMA B-operand layout: mean / variance are two shuffles) and keeps
-// them as bf16 operand fragments; the hidden dimension is streamed in chunks of 64 units (12 chunks):
-//     a^T   = W1[chunk] . h^T       W1 rows from LDS as the MFMA A operand; lane (row li, group g) ends with hidden units
-//                                   g*16 + t*4 + {0..3} of tile t, i.e. SIXTEEN CONSECUTIVE units over the four tiles
-//     u^T   = GELU(a^T + b1)        in registers; tiles (2s, 2s+1) packed = the B operand of k-step s of the next MFMA
-//     out^T += W2[:, chunk] . u^T   W2 rows from LDS as the A operand
-// The unit order g*16 + t*4 + e is a permutation of the chunk, applied where the weight chunk is staged: W1 row h lands in LDS row
-// ((h >> 2) & 3) * 16 + (h >> 4) * 4 + (h & 3), W2's 16-byte piece (g, s) in slot s*4 + g -- the sources stay in their natural
-// layouts, every fragment read is one conflict-free ds_read_b128, and (training form) a lane's GELU'(a) / GELU(a) are 32 contiguous
-// bytes of the [M, F] row.  A chunk is three phases -- fc1 (48 MFMAs per wave), GELU (32 values per lane), fc2 (48 MFMAs) -- cut into
-// fenced regions of 8 MFMAs whose fragments are requested ONE REGION EARLIER (round 1 fenced every region and read its fragments
-// inside it, so every ds_read latency was exposed; unfenced, hipcc hoists the whole chunk's reads and spills).  Weight chunks
-// (48 KB) stream L2 -> registers -> LDS one chunk ahead in two halves that share 16 staging VGPRs (W1 under fc1, W2 under GELU /
-// fc2), with affine piece assignments: SGPR base + one VGPR byte offset per half.  Written as per-piece element offsets hipcc kept
-// six 64-bit addresses per half in spilled VGPRs and reloaded each behind s_waitcnt vmcnt(0), serialising the L2 round trips.
-// Measured at batch 512 (M = 100 864): 133 us per layer (round 1: 152-168 us; MFMA bound 24 us; the three unfused kernels 210 us).
-// A 4-wave x 64-row variant (one wave per SIMD, 512 registers, fragments feeding four MFMAs) was built and measured at 230-300 us:
-// alone on its SIMD a wave exposes every wait the compiler leaves, and hipcc split the file 256 VGPR / 256 AGPR with 300+ spills.
-// The training form (stores for the backward) runs 276 us against 221 us for LayerNorm + fc1 + fc2 and is NOT wired into the engine.
+//   training (the student's forward, opt-in: uvc_vit_io.fused_train_mlp): the same pass also stores what the backward reads --
+//     LayerNorm(x1) (bf16 [M, D], operand of dW1), its mean / rstd, GELU'(a) and GELU(a) (bf16 [M, F]) -- from the accumulator
+//     registers.  Measured 218 us against 187 us for LayerNorm + fc1 + fc2: its 64-byte row pieces of GELU / GELU' write badly.
+// History: round 1-2's kernel ran 8 waves x 32 rows in lockstep with the weights staged through registers
+// (133 us); the structure below is the result of the s_memtime traces and probes of round 2.
 #include "common.h"
 #include "../../include/uvc_kernels.h"
 #include <utility>
-#include <cstdlib>
 
 namespace {
 
 typedef bf16_t T;
-constexpr int D = 192, KT = 6, FC = 64, RW = 2, NW = 8, NTH = 64 * NW, ROWS = NW * RW * 16;
+constexpr int D = 192, KT = 6, RW = 2;
 constexpr int W1S = D * 2 + 32;   // 416 B: 104 words = 40 mod 64 -> conflict-free ds_read_b128 fragment reads of 16 consecutive rows
-constexpr int W2S = FC * 2 + 32;  // 160 B:  40 words
-constexpr int BUF = FC * W1S + D * W2S + FC * 4;   // W1 chunk | W2 chunk | b1 chunk
 
 __device__ __forceinline__ f32x4 mma(const bf16x8& a, const bf16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ bf16x8 frag(const char* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); }
 __device__ __forceinline__ u32x4 pack8u(const f32x4& lo, const f32x4& hi) {
   u32x4 r;
   r[0] = pack_bf16x2(lo[0], lo[1]); r[1] = pack_bf16x2(lo[2], lo[3]);
@@ -52,263 +29,19 @@ __device__ __forceinline__ u32x4 pack8u(const f32x4& lo, const f32x4& hi) {
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) { return __builtin_bit_cast(bf16x8, pack8u(lo, hi)); }
 
-template <bool TRAIN>
-__global__ __launch_bounds__(NTH, 2) void k_mlp_fused(uvc_mlp_args a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const buf0 = smem;
-  char* const buf1 = smem + BUF;
-  float* const sG = reinterpret_cast<float*>(smem + 2 * BUF);
-  float* const sBt = sG + D;
-  float* const sB2 = sBt + D;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
-  const T* __restrict__ W1 = reinterpret_cast<const T*>(a.w1);
-  const T* __restrict__ W2 = reinterpret_cast<const T*>(a.w2);
-  const int nch = a.F / FC;
-  for (int i = tid; i < D; i += NTH) { sG[i] = a.gamma[i]; sBt[i] = a.beta[i]; sB2[i] = a.b2[i]; }
-  float d0 = 0.f, d1 = 1.f;
-  if (a.gate) { d0 = a.gate[0]; d1 = a.gate[1]; }
-
-  // weight chunk staging through registers, one chunk ahead, in two halves that share the staging registers: the W1 pieces travel
-  // under the fc1 MFMAs, the W2 pieces under the GELU / fc2 phase.  Piece assignments are AFFINE in the unrolled index (one VGPR of
-  // source offset and one of LDS offset per half; everything else is an instruction immediate or a scalar): the first version spent
-  // 36 VGPRs on per-piece addresses and spilled.
-  //   W1 chunk [64 rows][24 pieces]: threads 0..383 = (r0 = tid / 24, ch = tid % 24), rows r0 + 16 i, i = 0..3
-  //   W2 chunk [192 rows][8 pieces]: all threads   = (r0 = tid / 8,  ch = tid % 8),  rows r0 + 64 i, i = 0..2
-  constexpr int NS1 = 4, NS2 = 3, T1 = 384;
-  u32x4 pw[NS1];
-  u32x4 pb;
-  const bool st1 = tid < T1;
-  const unsigned so1 = (unsigned)((tid / 24) * D + (tid % 24) * 8);                         // elements into the W1 chunk
-  // hidden unit h = r0 + 16 i = g*16 + t*4 + e with g = i, t = r0 >> 2, e = r0 & 3 -> A-operand row t*16 + g*4 + e
-  const unsigned ld1 = (unsigned)((((tid / 24) >> 2) * 16 + ((tid / 24) & 3)) * W1S + (tid % 24) * 16);
-  const unsigned so2 = (unsigned)((tid / 8) * a.F + (tid % 8) * 8);                          // elements from W2[0, c*FC]
-  const unsigned ld2 = (unsigned)(FC * W1S + (tid / 8) * W2S + (((tid % 8) & 1) * 4 + ((tid % 8) >> 1)) * 16);
-  // (scalar chunk / row-group base) + (one per-thread BYTE offset): the loads take the SGPR-base + 32-bit-VGPR-offset form.  Written as
-  // per-piece element offsets, hipcc kept six 64-bit addresses per half in (spilled) VGPRs and reloaded each behind an s_waitcnt
-  // vmcnt(0), which serialised the six L2 round trips of every half: 12 us per chunk.
-  const unsigned so1b = so1 * 2u, so2b = so2 * 2u;
-  auto gload1 = [&](int c) {
-    const char* base = reinterpret_cast<const char*>(W1 + (size_t)c * FC * D);
-    if (st1) {
-#pragma unroll
-      for (int i = 0; i < NS1; ++i) pw[i] = *reinterpret_cast<const u32x4*>((base + (size_t)(16 * i * D * 2)) + so1b);
-    } else if (tid < T1 + FC / 4) pb = *reinterpret_cast<const u32x4*>(a.b1 + c * FC + (tid - T1) * 4);
-  };
-  auto lstore1 = [&](char* buf) {
-    if (st1) {
-#pragma unroll
-      for (int i = 0; i < NS1; ++i) *reinterpret_cast<u32x4*>(buf + ld1 + (i * 4) * W1S) = pw[i];
-    } else if (tid < T1 + FC / 4) *reinterpret_cast<u32x4*>(buf + FC * W1S + D * W2S + (tid - T1) * 16) = pb;
-  };
-  auto gload2 = [&](int c) {
-    const char* base = reinterpret_cast<const char*>(W2 + c * FC);
-    const size_t rstep = (size_t)64 * (size_t)a.F * 2;
-#pragma unroll
-    for (int i = 0; i < NS2; ++i) pw[i] = *reinterpret_cast<const u32x4*>((base + i * rstep) + so2b);
-  };
-  auto lstore2 = [&](char* buf) {          // piece (g = ch >> 1, s = ch & 1) -> k-step slot s*4 + g
-#pragma unroll
-    for (int i = 0; i < NS2; ++i) *reinterpret_cast<u32x4*>(buf + ld2 + 64 * i * W2S) = pw[i];
-  };
-
-  // the weight stream is cyclic: chunk (c+1) % nch is always prefetched, so the last chunk of a pass stages chunk 0 of the
-  // next one and the chunk loop has no tail case
-  int par = 0;
-  gload1(0);
-  lstore1(buf0);
-  gload2(0);
-  lstore2(buf0);
-  __syncthreads();                                     // also covers sG / sBt / sB2
-
-  const int npass = (a.M + ROWS - 1) / ROWS;
-  for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
-    const int m0 = pass * ROWS + w * (RW * 16);
-    // ---- LayerNorm of this wave's 4 x 16 rows, straight into MFMA B-operand fragments (lane (li, g): columns (ks*4 + g)*8 .. +7)
-    bf16x8 hf[RW][KT];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      __builtin_amdgcn_sched_barrier(0);              // one row tile's 48 row registers at a time
-      const int row = m0 + r * 16 + li;
-      const bool ok = row < a.M;
-      const float okf = ok ? 1.0f : 0.0f;
-      const float* xr = a.x + (size_t)(ok ? row : 0) * D;
-      f32x4 xv[2 * KT];
-#pragma unroll
-      for (int ks = 0; ks < KT; ++ks) {
-        xv[2 * ks] = *reinterpret_cast<const f32x4*>(xr + (ks * 4 + g) * 8);
-        xv[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xr + (ks * 4 + g) * 8 + 4);
-      }
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2 * KT; ++i) s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      const float mean = s * (1.0f / D);
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2 * KT; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; q += d * d; }
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
-      const float rstd = rsqrtf(q * (1.0f / D) + a.eps);
-      if (TRAIN && ok && g == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
-#pragma unroll
-      for (int ks = 0; ks < KT; ++ks) {
-        const int c0 = (ks * 4 + g) * 8;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(sG + c0), g1 = *reinterpret_cast<const f32x4*>(sG + c0 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBt + c0), b1 = *reinterpret_cast<const f32x4*>(sBt + c0 + 4);
-        f32x4 y0, y1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          y0[e] = ((xv[2 * ks][e] - mean) * rstd * g0[e] + b0[e]) * okf;        // rows past M: zero operands
-          y1[e] = ((xv[2 * ks + 1][e] - mean) * rstd * g1[e] + b1[e]) * okf;
-        }
-        const u32x4 pk = pack8u(y0, y1);
-        hf[r][ks] = __builtin_bit_cast(bf16x8, pk);
-        if (TRAIN && ok) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.h) + (size_t)row * D + c0) = pk;
-      }
-    }
-
-    f32x4 out[RW][D / 16];
-#pragma unroll
-    for (int r = 0; r < RW; ++r)
-#pragma unroll
-      for (int j = 0; j < D / 16; ++j) out[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int c = 0; c < nch; ++c, par ^= 1) {
-      const char* buf = par ? buf1 : buf0;
-      char* nbuf = par ? buf0 : buf1;
-      const int cn = c + 1 < nch ? c + 1 : 0;
-      gload1(cn);
-      // ---- a^T = W1c . h^T.  One fenced region per k-step: the four W1 fragments of step ks+1 are requested first, then the 16
-      //      MFMAs of step ks (4 tiles x 4 row tiles, 256 cycles of matrix pipe) run on the fragments requested a region earlier, so
-      //      no ds_read latency is exposed although this wave is alone on its SIMD.  (Unfenced, the scheduler hoists the whole chunk's
-      //      reads and spills; fenced without the one-region-ahead requests every read is waited for: 2x slower than round 1's kernel.)
-      f32x4 acc[RW][FC / 16];
-#pragma unroll
-      for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int t = 0; t < FC / 16; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      bf16x8 wa[2][FC / 16];
-#pragma unroll
-      for (int t = 0; t < FC / 16; ++t) wa[0][t] = frag(buf + (t * 16 + li) * W1S + g * 16);
-#pragma unroll
-      for (int ks = 0; ks < KT; ++ks) {
-        if (ks + 1 < KT) {
-#pragma unroll
-          for (int t = 0; t < FC / 16; ++t) wa[(ks + 1) & 1][t] = frag(buf + (t * 16 + li) * W1S + ((ks + 1) * 4 + g) * 16);
-        }
-#pragma unroll
-        for (int t = 0; t < FC / 16; ++t)
-#pragma unroll
-          for (int r = 0; r < RW; ++r) acc[r][t] = mma(wa[ks & 1][t], hf[r][ks], acc[r][t]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      lstore1(nbuf);
-      gload2(cn);
-      // ---- u^T = GELU(a^T + b1) (and GELU' when training) for the four row tiles: 64 values per lane, packed as the next B operands;
-      //      the first W2 fragments are requested here so that they arrive under the VALU work
-      bf16x8 wc[2][4];
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const char* wp = buf + FC * W1S + (jj * 16 + li) * W2S + g * 16;
-        wc[0][2 * jj] = frag(wp); wc[0][2 * jj + 1] = frag(wp + 64);
-      }
-      const float* sb1 = reinterpret_cast<const float*>(buf + FC * W1S + D * W2S) + g * 16;
-      bf16x8 uf[RW][2];
-#pragma unroll
-      for (int r = 0; r < RW; ++r) {
-        f32x4 gpv[FC / 16];
-#pragma unroll
-        for (int t = 0; t < FC / 16; ++t) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + t * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float pre = acc[r][t][e] + bb[e];
-            if (TRAIN) { float fo, go; Gelu<T>::fg(pre, fo, go); acc[r][t][e] = fo; gpv[t][e] = go; }
-            else acc[r][t][e] = Gelu<T>::f(pre);
-          }
-        }
-        const u32x4 u0 = pack8u(acc[r][0], acc[r][1]), u1 = pack8u(acc[r][2], acc[r][3]);
-        uf[r][0] = __builtin_bit_cast(bf16x8, u0); uf[r][1] = __builtin_bit_cast(bf16x8, u1);
-        if (TRAIN) {
-          const int row = m0 + r * 16 + li;
-          if (row < a.M) {
-            const size_t o = (size_t)row * a.F + c * FC + g * 16;          // this lane's 16 consecutive hidden units
-            T* up = reinterpret_cast<T*>(a.u) + o;
-            T* gpp = reinterpret_cast<T*>(a.gp) + o;
-            *reinterpret_cast<u32x4*>(up) = u0; *reinterpret_cast<u32x4*>(up + 8) = u1;
-            *reinterpret_cast<u32x4*>(gpp) = pack8u(gpv[0], gpv[1]); *reinterpret_cast<u32x4*>(gpp + 8) = pack8u(gpv[2], gpv[3]);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- out^T += W2c . u^T.  Six fenced regions of two output tiles: four W2 fragments (requested a region earlier) x four row
-      //      tiles = 16 MFMAs; the two MFMAs on one accumulator sit four apart.
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        if (k + 1 < 6) {
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const char* wp = buf + FC * W1S + (((k + 1) * 2 + jj) * 16 + li) * W2S + g * 16;
-            wc[(k + 1) & 1][2 * jj] = frag(wp); wc[(k + 1) & 1][2 * jj + 1] = frag(wp + 64);
-          }
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-#pragma unroll
-          for (int r = 0; r < RW; ++r) out[r][k * 2 + jj] = mma(wc[k & 1][2 * jj], uf[r][0], out[r][k * 2 + jj]);
-#pragma unroll
-          for (int r = 0; r < RW; ++r) out[r][k * 2 + jj] = mma(wc[k & 1][2 * jj + 1], uf[r][1], out[r][k * 2 + jj]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      lstore2(nbuf);
-      __syncthreads();
-    }
-
-    // ---- out = d1 * ((mlp + b2) + x1) + d0 * x_prev: lane (row, g) holds columns j*16 + g*4 .. +3 of every 16-column group
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      const int row = m0 + r * 16 + li;
-      if (row < a.M) {
-        const float* xr = a.x + (size_t)row * D;
-        float* orow = a.out + (size_t)row * D;
-#pragma unroll
-        for (int j = 0; j < D / 16; ++j) {
-          const int col = j * 16 + g * 4;
-          const f32x4 xres = *reinterpret_cast<const f32x4*>(xr + col);
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + col);
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (out[r][j][e] + bv[e]) + xres[e];
-          if (a.gate) {
-            const f32x4 xp = *reinterpret_cast<const f32x4*>(a.x_prev + (size_t)row * D + col);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(d1, o[e], __builtin_fmaf(d0, xp[e], 0.0f));
-          }
-          *reinterpret_cast<f32x4*>(orow + col) = o;
-        }
-      }
-    }
-  }
-}
-
-// ---- inference kernel, second generation (r2d): two independent 4-wave workgroups per CU ------------------------------------------
-// Same arithmetic as k_mlp_fused<false> up to where the fc1 bias enters (here it is the initial accumulator), different shape.
-// What the probes of round 2 showed (tools/probe/*.hip, s_memtime traces of the kernel itself):
-//   * one wave issues v_mfma_f32_16x16x32_bf16 every 18.3 cycles; two waves on a SIMD reach 12.3 together;
+// What the probes of round 2 showed (tools/probe/*.hip, s_memtime traces of the kernel itself; DESIGN.md 5c):
+//   * one wave issues v_mfma_f32_16x16x32_bf16 every 18.3 ticks; two waves on a SIMD reach 12.3 together;
 //   * a dense VALU stream (the GELU) on one wave of a SIMD stalls the other wave's MFMAs almost completely -- matrix and VALU
-//     phases of the two waves of a SIMD ADD, whatever s_setprio says; only memory waits overlap with either;
-//   * k_mlp_fused's 8 waves run in lockstep (one barrier per chunk), so its row loads / stores (232 MB per layer, 40-50 us at the
-//     ~5 TB/s a mixed stream gets) are exposed before and after a chunk loop that runs at 38 cycles per MFMA.
-// So: a workgroup is FOUR waves (one per SIMD) x 32 rows, two workgroups per CU (256 VGPRs each, 65 KB of LDS each).  They drift
-// apart, so one normalises / stores its rows while the other owns the matrix pipes, and the 788 passes spread over 512 slots
-// without the 394-on-256 tail.  Hidden chunks of 32 units, both weight chunks double-buffered, brought in by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers) one chunk ahead and waited for just before the chunk's one barrier.  The matrix
-// phases are spelled out: fragment reads by inline ds_read_b128 a few MFMAs ahead, counted lgkmcnt waits tied to the registers they
-// cover, a scheduling fence per unit; fc2's first fragments are requested before the GELU so they arrive under it.
+//     phases of the two waves of a SIMD ADD, whatever s_setprio says; only memory waits overlap with either; inside ONE wave an
+//     MFMA leaves ~4 issue slots that independent VALU work fills;
+//   * 8 waves in lockstep (one barrier per chunk) expose their row loads / stores (232 MB per layer) before and after a chunk
+//     loop that runs at 38 ticks per MFMA.
+// So: a workgroup is FOUR waves (one per SIMD) x 32 rows, two workgroups per CU (<= 246 VGPRs, 70 KB of LDS each); 788 of them at
+// batch 512.  Hidden chunks of 32 units, both weight chunks double-buffered, brought in by LDS-DMA (global_load_lds_dwordx4: no
+// staging registers) and waited for just before the iteration's one barrier.  The matrix phases are spelled out: fragment reads by
+// inline ds_read_b128 a few MFMAs ahead, counted lgkmcnt waits tied to the registers they cover, a scheduling fence per unit.
+// Measured at batch 512: 105-115 us (inference form).  A lone round of 512 workgroups is [rows in: 12 us][chunks: 37][rows out: 12]
+// -- all workgroups start together, so the memory phases of one do not yet hide under the chunks of another: the next step.
 constexpr int V3_NW = 4, V3_NTH = 64 * V3_NW, V3_ROWS = V3_NW * RW * 16, V3_FC = 32;
 constexpr int V3_W2S = V3_FC * 2 + 32;                       // 96 B rows: 24 words, conflict-free for ds_read_b128 with row = lane & 15
 constexpr int V3_W1B = V3_FC * W1S, V3_W2B = D * V3_W2S;     // 13312 + 18432
@@ -332,6 +65,7 @@ template <int... Is, class Fn> __device__ __forceinline__ void static_for_impl(s
 }
 template <int N, class Fn> __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+template <bool TRAIN>
 __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
@@ -399,6 +133,8 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
       q += __shfl_xor(q, 16, 64);
       q += __shfl_xor(q, 32, 64);
       const float rstd = rsqrtf(q * (1.0f / D) + a.eps);
+      const int prow = m0 + r * 16 + li;
+      if (TRAIN && prow < a.M && g == 0) { a.mean[prow] = mean; a.rstd[prow] = rstd; }
       const unsigned ga = s0 + (unsigned)(V3_OFF_GB + g * 32), ba = ga + (unsigned)(D * 4);
       __builtin_amdgcn_sched_barrier(0);
       static_for<KT>([&](auto ksv) {
@@ -414,6 +150,7 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
           y1[e] = ((xv[2 * ks + 1][e] - mean) * rstd * g1[e] + b1[e]) * okf;
         }
         hf[r][ks] = pack8(y0, y1);
+        if (TRAIN && prow < a.M) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.h) + (size_t)prow * D + (ks * 4 + g) * 8) = __builtin_bit_cast(u32x4, hf[r][ks]);
         asm volatile("" : "+v"(hf[r][ks]));            // materialise here: LLVM otherwise SINKS this arithmetic to the first use inside the
                                                        // chunk loop and keeps (spills) the 24 loaded vectors until then
         __builtin_amdgcn_sched_barrier(0);             // one k-step at a time: unfenced, the scheduler collects all 24 reads first
@@ -491,7 +228,7 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
   //      GELU as a separate phase (or on the other wave of the SIMD) costs its full issue time on top.  W1 of chunk c + 1
   //      and W2 of chunk c arrive during iteration c.
   bf16x8 uf[RW];
-  f32x4 acc[RW][2];
+  f32x4 acc[RW][2], gpv[RW][2];
   auto fc1 = [&](int c) {
     const unsigned w1a = w1lane + (unsigned)((c & 1) * V3_BUF);
     const unsigned ba = b1lane + (unsigned)(c * (V3_FC * 4));
@@ -538,14 +275,31 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
       }
       if constexpr (GELU && j < 8) {
         constexpr int r = j >> 2, t = (j >> 1) & 1, e0 = (j & 1) * 2;
-        acc[r][t][e0] = Gelu<T>::f(acc[r][t][e0]);
-        acc[r][t][e0 + 1] = Gelu<T>::f(acc[r][t][e0 + 1]);
+        if constexpr (TRAIN) {
+          float f0, g0, f1, g1;
+          Gelu<T>::fg(acc[r][t][e0], f0, g0);
+          Gelu<T>::fg(acc[r][t][e0 + 1], f1, g1);
+          acc[r][t][e0] = f0; gpv[r][t][e0] = g0; acc[r][t][e0 + 1] = f1; gpv[r][t][e0 + 1] = g1;
+        } else {
+          acc[r][t][e0] = Gelu<T>::f(acc[r][t][e0]);
+          acc[r][t][e0 + 1] = Gelu<T>::f(acc[r][t][e0 + 1]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
     if constexpr (GELU) {
 #pragma unroll
-      for (int r = 0; r < RW; ++r) uf[r] = pack8(acc[r][0], acc[r][1]);
+      for (int r = 0; r < RW; ++r) {
+        uf[r] = pack8(acc[r][0], acc[r][1]);
+        if constexpr (TRAIN) {                          // what the backward reads: GELU(a) (operand of dW2) and GELU'(a); a lane holds 8 consecutive units
+          const int row = m0 + r * 16 + li;
+          if (row < a.M) {
+            const size_t o = (size_t)row * a.F + (size_t)(cprev + 1) * V3_FC + g * 8;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.u) + o) = __builtin_bit_cast(u32x4, uf[r]);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.gp) + o) = pack8u(gpv[r][0], gpv[r][1]);
+          }
+        }
+      }
     }
   };
   auto end_iter = [&]() {
@@ -557,7 +311,7 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
     dma(1, 0);
     __builtin_amdgcn_sched_barrier(0);
     fc1(0);
-    fc2_gelu(std::false_type{}, std::true_type{}, 0);
+    fc2_gelu(std::false_type{}, std::true_type{}, -1);
     end_iter();
   }
   for (int c = 1; c < nch; ++c) {
@@ -593,43 +347,30 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
 
 }  // namespace
 
-extern "C" int uvc_mlp_fused_supported(int32_t D_, int32_t F, int32_t dtype) { return D_ == D && F > 0 && F % FC == 0 && dtype == UVC_BF16; }
+extern "C" int uvc_mlp_fused_supported(int32_t D_, int32_t F, int32_t dtype) { return D_ == D && F > 0 && F % 64 == 0 && F <= 1024 && dtype == UVC_BF16; }
 
 extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
   if (!p || !p->x || !p->out || !p->gamma || !p->beta || !p->w1 || !p->b1 || !p->w2 || !p->b2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: null pointer");
   if (p->M <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: empty");
-  if (!uvc_mlp_fused_supported(p->D, p->F, UVC_BF16)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_mlp_fused_fwd: needs D == 192 and F % 64 == 0");
+  if (!uvc_mlp_fused_supported(p->D, p->F, UVC_BF16)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_mlp_fused_fwd: needs D == 192, F % 64 == 0 and F <= 1024");
   if ((((uintptr_t)p->x | (uintptr_t)p->out | (uintptr_t)p->w1 | (uintptr_t)p->w2 | (uintptr_t)p->b1 | (uintptr_t)p->x_prev | (uintptr_t)p->h |
         (uintptr_t)p->u | (uintptr_t)p->gp) & 15) != 0)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: buffers must be 16-byte aligned");
   const bool train = p->h || p->u || p->gp || p->mean || p->rstd;
   if (train && (!p->h || !p->u || !p->gp || !p->mean || !p->rstd)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: training needs h, mean, rstd, gp and u");
   if ((p->gate != nullptr) != (p->x_prev != nullptr)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: gate and x_prev come together");
-  const size_t sh = (size_t)2 * BUF + 3 * D * sizeof(float);
-  const int npass = ceil_div(p->M, ROWS);
-  const int grid = npass < 256 ? npass : 256;
   hipStream_t st = (hipStream_t)stream;
-  static const bool old_kernel = getenv("UVC_MLP_OLD") != nullptr;
-  if (!train && !old_kernel && p->F % V3_FC == 0 && p->F <= 1024) {
+  {
     static bool attr_set = false;
     if (!attr_set) {
-      const hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused_v3, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+      hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused_v3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_mlp_fused_v3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
       if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
       attr_set = true;
     }
-    k_mlp_fused_v3<<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p);
+    if (train) k_mlp_fused_v3<true><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p);
+    else k_mlp_fused_v3<false><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p);
     UVC_CHECK_LAUNCH();
     return UVC_OK;
   }
-  if (train) {
-    static const hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-    k_mlp_fused<true><<<grid, NTH, sh, st>>>(*p);
-  } else {
-    static const hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-    k_mlp_fused<false><<<grid, NTH, sh, st>>>(*p);
-  }
-  UVC_CHECK_LAUNCH();
-  return UVC_OK;
 }

@@ -53,7 +53,7 @@ class uvc_vit_io(C.Structure):
                 ("run_block", C.POINTER(C.c_int32)), ("patch_mask", C.c_void_p), ("d_patch_mask", C.c_void_p),
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
                 ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
-                ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("reserved0", C.c_int32)]
+                ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("fused_train_mlp", C.c_int32)]
 
 
 class uvc_mlp_compact(C.Structure):
@@ -65,6 +65,7 @@ class uvc_mlp_compact(C.Structure):
 # computes that block's tail on the token rows only (uvc_vit_io.full_tail = 0; identical outputs and gradients).  UVC_FULL_TAIL=1, or
 # model.full_tail = True, runs every row as the reference does (A/B measurements, tests).
 _FULL_TAIL_DEFAULT = os.environ.get("UVC_FULL_TAIL", "0") not in ("", "0")
+_FUSED_TRAIN_MLP_DEFAULT = os.environ.get("UVC_FUSED_TRAIN_MLP", "0") not in ("", "0")     # training forward: one MLP kernel instead of three (slower: opt-in)
 
 
 def _bind():
@@ -485,6 +486,7 @@ class DistilledVisionTransformer(nn.Module):
         io.mlp_compact = C.addressof(self._mlp_compact) if self._mlp_compact is not None else None
         io.head_keep = L.ptr(self._head_keep) if (self._head_keep is not None and not training) else None
         io.full_tail = int(getattr(self, "full_tail", _FULL_TAIL_DEFAULT))
+        io.fused_train_mlp = int(getattr(self, "fused_train_mlp", _FUSED_TRAIN_MLP_DEFAULT))
         return io
 
     def _ws_view(self, B, training, which):

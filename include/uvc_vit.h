@@ -115,6 +115,9 @@ typedef struct uvc_vit_io {
   int32_t fused_train_mlp;             /* 1: the training forward runs LayerNorm2 + fc1 (+GELU, GELU') + fc2 (+residual, gate mix) as ONE kernel
                                           (uvc_mlp_fused_fwd's training form, DeiT-Tiny width) instead of three; measured slower (218 us
                                           against 187), so 0 is the default */
+  const void* patches_in;              /* optional T [B * np, C * P * P]: the patch rows of `x` already laid out by uvc_patchify (same image size and
+                                          patch size).  The forward uses them instead of running uvc_patchify, the backward reads them for the
+                                          patch-embedding weight gradient.  Lets student and teacher share the one rearrangement of a batch. */
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

@@ -293,6 +293,7 @@ int setup(Ctx& c, const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream, bo
   TRY(uvc_vit_layout(cfg, &c.off, &c.soff));
   const int64_t need = carve(c.d, bwd ? 1 : io->training, (char*)io->workspace, c.w);
   if (io->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: workspace too small");
+  if (io->patches_in) c.w.patches = const_cast<void*>(io->patches_in);      // rearranged once for student and teacher
   return UVC_OK;
 }
 
@@ -418,7 +419,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
   const int fsb = io->stage_begin, fse = (io->stage_begin == 0 && io->stage_end == 0) ? 2 : io->stage_end;
   if (fsb < 0 || fse > 2 || fsb >= fse) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_forward: bad stage range");
   if (fsb == 0) {
-    TRY(uvc_patchify(io->x, w.patches, d.B, d.C, d.S, d.P, d.dtype, stream));
+    if (!io->patches_in) TRY(uvc_patchify(io->x, w.patches, d.B, d.C, d.S, d.P, d.dtype, stream));
     TRY(nt(c, w.patches, 0, wmat(c, o.patch_w, c.soff.patch_w), w.pe, 1, rows_p, d.D, d.K0, UVC_EPI_BIAS, P + o.patch_b));
   }
   if (fse < 2) return UVC_OK;

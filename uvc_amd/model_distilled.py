@@ -53,7 +53,7 @@ class uvc_vit_io(C.Structure):
                 ("run_block", C.POINTER(C.c_int32)), ("patch_mask", C.c_void_p), ("d_patch_mask", C.c_void_p),
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
                 ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
-                ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("fused_train_mlp", C.c_int32)]
+                ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("fused_train_mlp", C.c_int32), ("patches_in", C.c_void_p)]
 
 
 class uvc_mlp_compact(C.Structure):
@@ -66,6 +66,37 @@ class uvc_mlp_compact(C.Structure):
 # model.full_tail = True, runs every row as the reference does (A/B measurements, tests).
 _FULL_TAIL_DEFAULT = os.environ.get("UVC_FULL_TAIL", "0") not in ("", "0")
 _FUSED_TRAIN_MLP_DEFAULT = os.environ.get("UVC_FUSED_TRAIN_MLP", "0") not in ("", "0")     # training forward: one MLP kernel instead of three (slower: opt-in)
+
+
+# Student and teacher see the same batch and the same patch geometry: the [B*196, 768] rearrangement of the images (uvc_patchify,
+# 462 MB of traffic at batch 512) is done once per batch by whichever model runs first and handed to the other one through
+# uvc_vit_io.patches_in (ordered by an event when they run on different streams).  An entry is consumed once, so a loop that feeds
+# the same tensor again (bench.py) still rearranges it once per step.  UVC_SHARE_PATCHES=0 turns the sharing off.
+_SHARE_PATCHES = os.environ.get("UVC_SHARE_PATCHES", "1") not in ("", "0")
+_PATCH_SHARE = dict(key=None, buf=None, ev=None, owner=None)
+
+
+def _shared_patches(model, x):
+    cfg = model._cfg
+    key = (x.data_ptr(), x._version, tuple(x.shape), cfg.patch_size, model.precision)
+    c = _PATCH_SHARE
+    cur = torch.cuda.current_stream()
+    if _SHARE_PATCHES and c["key"] == key and c["owner"] != id(model):
+        buf, ev = c["buf"], c["ev"]
+        c.update(key=None, buf=None, ev=None, owner=None)
+        cur.wait_event(ev)
+        buf.record_stream(cur)
+        return buf
+    B = x.shape[0]
+    rows = B * (cfg.img_size // cfg.patch_size) ** 2
+    buf = torch.empty(rows, cfg.in_chans * cfg.patch_size * cfg.patch_size, device=x.device,
+                      dtype=torch.float32 if model.precision == "fp32" else torch.bfloat16)
+    ops.patchify(x, buf, cfg.patch_size, ops.UVC_F32 if model.precision == "fp32" else ops.UVC_BF16)
+    if _SHARE_PATCHES:
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        c.update(key=key, buf=buf, ev=ev, owner=id(model))
+    return buf
 
 
 def _bind():
@@ -550,8 +581,12 @@ class DistilledVisionTransformer(nn.Module):
         patch = None
         # a custom token embedding (T2T-ViT's tokens-to-token module) writes pe [B*P, D] into the workspace itself
         front = self._front_end_forward(x, B, training)
+        patches = None
         if front:
             io.stage_begin, io.stage_end = 1, 2
+        else:
+            patches = _shared_patches(self, x)          # the batch's patch rows, rearranged once for student and teacher
+            io.patches_in = L.ptr(patches)
         if mode1 or mode2:
             if not front:
                 io.stage_begin, io.stage_end = 0, 1
@@ -573,7 +608,7 @@ class DistilledVisionTransformer(nn.Module):
             ops.gate_distrib(self.block_skip_gating.data, e, gate_d, cfg.depth, mode, float(self.eps))
         io.gate_d = L.ptr(gate_d)
         L.check(lib.uvc_vit_forward(C.byref(cfg), C.byref(io), stream), "uvc_vit_forward")
-        self._last = dict(x=x, gate_d=gate_d, patch=patch, B=B, run_block=run_block, front=self._front_state) if training else None
+        self._last = dict(x=x, gate_d=gate_d, patch=patch, B=B, run_block=run_block, front=self._front_state, patches=patches) if training else None
         self.last_distrib = gate_d
         self.last_patch_mask = patch["mask"] if patch else None
         return logits, logits_dist
@@ -630,6 +665,7 @@ class DistilledVisionTransformer(nn.Module):
         patch = st["patch"]
         self.grad_views(patch_mode2=bool(patch and patch["mode"] == 2))
         io = self._io(st["B"], True)
+        io.patches_in = L.ptr(st.get("patches"))
         d_logits = d_logits.contiguous()
         io.d_logits = L.ptr(d_logits)
         if self.num_tokens == 2:

@@ -152,7 +152,7 @@ def test_gemm_nt_ksplit_streaming_kernel_matches_generic(K, M):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("M,N1,N2", [(1576, 576, 192), (403, 192, 768), (3001, 768, 192), (64, 1000, 192), (5000, 128, 128), (40, 8, 16)])
+@pytest.mark.parametrize("M,N1,N2", [(1576, 576, 192), (403, 192, 768), (3001, 768, 192), (64, 1000, 192), (5000, 128, 128), (40, 8, 16), (4133, 192, 192)])
 def test_gemm_tn(dtype, M, N1, N2):
     from uvc_amd import ops
     A, B = rnd(M, N1, seed=11), rnd(M, N2, seed=12)

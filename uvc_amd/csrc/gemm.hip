@@ -1966,17 +1966,19 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ par
   for (int e = 0; e < VEC; ++e) dst[e] = (beta != 0.f ? beta * dst[e] : 0.f) + alpha * s[e];
 }
 
-// 0 = generic 128x64 tiles; 1 = 192x256, 2 = 256x192, 3 = 192x192 (bf16 big tiles)
+// 0 = generic 128x64 tiles; 1 = 192x256, 2 = 256x192, 3 = 192x192, 4 = 96x192 (bf16 big tiles)
 static int tn_config(int N1, int N2) {
   if (N1 % 192 == 0 && N2 % 256 == 0) return 1;
   if (N1 % 256 == 0 && N2 % 192 == 0) return 2;
   if (N1 % 192 == 0 && N2 % 192 == 0 && (N1 / 192) * (N2 / 192) >= 2) return 3;   // a single 192x192 tile would need 256 splits
+  if (N1 == 192 && N2 == 192) return 4;       // dW_proj of DeiT-Tiny: two 96x192 tiles x 128 splits (the generic kernel ran it at 1.75 TB/s)
   return 0;
 }
+static void tn_tile(int cfg, int& b1, int& b2) { b1 = cfg == 2 ? 256 : cfg == 4 ? 96 : 192; b2 = cfg == 1 ? 256 : 192; }
 static int tn_splits(int M, int N1, int N2, int cfg) {
   int tiles, target;
   if (cfg == 0) { tiles = ceil_div(N1, TN_B1) * ceil_div(N2, TN_B2); target = 768; }
-  else { const int b1 = cfg == 2 ? 256 : 192, b2 = cfg == 1 ? 256 : 192; tiles = (N1 / b1) * (N2 / b2); target = 256; }   // one 8-wave group per CU
+  else { int b1, b2; tn_tile(cfg, b1, b2); tiles = (N1 / b1) * (N2 / b2); target = 256; }   // one 8-wave group per CU
   int splits = ceil_div(target, tiles);
   const int max_splits = ceil_div(M, TN_BM);
   if (splits > max_splits) splits = max_splits;
@@ -2001,7 +2003,8 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   int64_t need; int splits;
   uvc_gemm_tn_workspace_bytes(p->M, p->N1, p->N2, &need, &splits);
   if (p->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: workspace too small");
-  const int cfg = (p->dtype == UVC_BF16 && p->lda % 8 == 0 && p->ldb % 8 == 0) ? tn_config(p->N1, p->N2) : 0;
+  int cfg = (p->dtype == UVC_BF16 && p->lda % 8 == 0 && p->ldb % 8 == 0) ? tn_config(p->N1, p->N2) : 0;
+  if (cfg == 4 && p->a_is_f32) cfg = 0;                      // the 96x192 tile exists as an LDS-DMA (bf16 operands) kernel only
   splits = tn_splits(p->M, p->N1, p->N2, cfg);
   TnArgs a;
   a.A = p->A; a.B = p->B; a.part = (float*)p->workspace; a.M = p->M; a.N1 = p->N1; a.N2 = p->N2; a.lda = p->lda; a.ldb = p->ldb;
@@ -2021,7 +2024,8 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
       if (p->a_is_f32) k_gemm_tn<float, bf16_t><<<grid, 256, 0, st>>>(a);
       else k_gemm_tn<bf16_t, bf16_t><<<grid, 256, 0, st>>>(a);
     } else {
-      const int b1 = cfg == 2 ? 256 : 192, b2 = cfg == 1 ? 256 : 192;
+      int b1, b2;
+      tn_tile(cfg, b1, b2);
       dim3 grid(p->N1 / b1, p->N2 / b2, splits);
 #define TN_BIG(TA_) \
       if (cfg == 1) k_gemm_tn_big<TA_, 192, 256, 2, 4><<<grid, 512, 0, st>>>(a); \
@@ -2035,6 +2039,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
       if (p->a_is_f32) { TN_BIG(float) }           // float32 A (converted on load): register-staged kernel
       else if (cfg == 1) TN_DMA_ONE(192, 256, 2, 4)
       else if (cfg == 2) TN_DMA_ONE(256, 192, 4, 2)
+      else if (cfg == 4) TN_DMA_ONE(96, 192, 2, 4)
       else TN_DMA_ONE(192, 192, 2, 4)
 #undef TN_DMA_ONE
 #undef TN_BIG

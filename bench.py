@@ -34,11 +34,12 @@ GFLOP_PER_IMG = {"deit_tiny_patch16_224": 9.972, "deit_small_patch16_224": 36.67
 # TFLOP/s figures of the JSON line use the EXECUTED count; `--full_tail 1` runs every row as the reference does.
 def executed_gflop_per_img(model_type, full_tail):
     gf = GFLOP_PER_IMG.get(model_type)
-    dims = {"deit_tiny_patch16_224": (192, 197), "deit_small_patch16_224": (384, 197), "deit_base_patch16_224": (768, 197)}.get(model_type)
+    dims = {"deit_tiny_patch16_224": (192, 197, 768), "deit_small_patch16_224": (384, 197, 1536), "deit_base_patch16_224": (768, 197, 3072),
+            "t2t_vit_14": (384, 197, 1152)}.get(model_type)
     if gf is None or dims is None or full_tail:
         return gf
-    D, N = dims
-    saved_macs = 4.0 * (2.0 * N * N * D + N * D * D + 2.0 * N * D * 4 * D) * (1.0 - 1.0 / N)
+    D, N, F = dims
+    saved_macs = 4.0 * (2.0 * N * N * D + N * D * D + 2.0 * N * D * F) * (1.0 - 1.0 / N)
     return gf - 2.0 * saved_macs / 1e9
 
 
@@ -161,8 +162,11 @@ def kernel_table(args):
     the dominant kernel, not the most flattering one (VERDICT r1 weak #3); the ten largest go into `top_kernels`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_table as KT
-    D, H, L = {"deit_tiny_patch16_224": (192, 3, 12), "deit_small_patch16_224": (384, 6, 12), "deit_base_patch16_224": (768, 12, 12)}[args.model_type]
-    rows = KT.measure(KT.build(args.batch, D=D, H=H, L=L, tail=not args.full_tail), iters=20)
+    # T2T-ViT-14: the 14 blocks (D = 384, mlp_ratio 3) -- the tokens-to-token front end is not in the stand-alone table, its kernels
+    # are in the rocprofv3 tables under profiles/
+    D, H, L, F = {"deit_tiny_patch16_224": (192, 3, 12, 768), "deit_small_patch16_224": (384, 6, 12, 1536), "deit_base_patch16_224": (768, 12, 12, 3072),
+                  "t2t_vit_14": (384, 6, 14, 1152)}[args.model_type]
+    rows = KT.measure(KT.build(args.batch, D=D, H=H, L=L, F=F, tail=not args.full_tail), iters=20)
     rows.sort(key=lambda r: -r["us_per_step"])
     top = rows[0]
     ridge = PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS          # flop per byte where the two roofs meet (312)
@@ -353,7 +357,7 @@ def main():
                 tr.step(x, y)
             torch.cuda.synchronize()
             line["warmup_phase_images_per_sec"] = round(20 * args.batch / (time.perf_counter() - tw), 1)
-        if args.stage == 1 and args.precision == "bf16" and args.model_type in GFLOP_PER_IMG and "deit" in args.model_type:
+        if args.stage == 1 and args.precision == "bf16" and args.model_type in GFLOP_PER_IMG:
             del tr, out
             torch.cuda.empty_cache()
             roof, top, total_ms = kernel_table(args)

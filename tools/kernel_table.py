@@ -22,11 +22,11 @@ import torch  # noqa: E402
 from uvc_amd import ops  # noqa: E402
 
 
-def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True):
+def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
     """tail=True (the engine's default, uvc_vit_io.full_tail = 0): the last block runs everything behind its qkv projection on the
     B class-token rows only, so the full-row kernels of that part launch L - 1 times per pass and the token-query attention once;
     the proj / MLP GEMMs on B rows are a few microseconds each and are not listed."""
-    F, M = 4 * D, B * N
+    F, M = (F or 4 * D), B * N
     Lf = L - 1 if tail else L          # launches per pass of the full-row kernels behind the qkv projection
     dev = "cuda"
     bf = torch.bfloat16
@@ -116,7 +116,7 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True):
     add("dWproj (+reduce)", "k_gemm_tn<unsigned short", Lf, 2 * u, 2.0 * M * D * D, lambda: ops.gemm_tn(g16, xb, C3, ws, dtype=dt))
     add("dWqkv (+reduce)", "k_gemm_tn_dma<192, 192", L, 4 * u, 2.0 * M * D * 3 * D, lambda: ops.gemm_tn(q3, xb, C4, ws, dtype=dt))
     # ---- optimiser
-    n = 5717440 if tiny else 12 * (4 * D * D + 2 * D * F)
+    n = 5717440 if tiny else L * (4 * D * D + 2 * D * F)
     p, gr, m, v = (rn(n) for _ in range(4))
     v.abs_()
     pp, sq = torch.empty(1024, device=dev), torch.zeros(1, device=dev)

@@ -109,7 +109,7 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
     dl = torch.empty(B, H, N, device=dev)
     add("attn_bwd (dq + dkv)", "k_attn_bwd", Lf, 12 * u, afl * 2.5, lambda: ops.attention_bwd(qkv3, o, lse, do, dq, dl, B, N, H, dt))
     # ---- backward, weight-gradient stream (each entry = the split-M GEMM + its fixed-order reduction)
-    ws = torch.empty(max(ops.gemm_tn_workspace_bytes(M, F, D), ops.gemm_tn_workspace_bytes(M, D, F), ops.gemm_tn_workspace_bytes(M, 3 * D, D)) // 4, device=dev)
+    ws = torch.empty(max(ops.gemm_tn_workspace_bytes(M, F, D), ops.gemm_tn_workspace_bytes(M, D, F), ops.gemm_tn_workspace_bytes(M, 3 * D, D), ops.gemm_tn_workspace_bytes(M, D, D)) // 4, device=dev)
     C1, C2, C3, C4 = torch.empty(D, F, device=dev), torch.empty(F, D, device=dev), torch.empty(D, D, device=dev), torch.empty(3 * D, D, device=dev)
     add("dW2 (+reduce)", "k_gemm_tn_dma<192, 256", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(g16, hF, C1, ws, dtype=dt))
     add("dW1 (+reduce)", "k_gemm_tn_dma<256, 192", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(hF, xb, C2, ws, dtype=dt))

@@ -1979,7 +1979,7 @@ static int tn_splits(int M, int N1, int N2, int cfg) {
   int tiles, target;
   if (cfg == 0) { tiles = ceil_div(N1, TN_B1) * ceil_div(N2, TN_B2); target = 768; }
   else { int b1, b2; tn_tile(cfg, b1, b2); tiles = (N1 / b1) * (N2 / b2); target = 256; }   // one 8-wave group per CU
-  int splits = ceil_div(target, tiles);
+  int splits = cfg == 0 ? ceil_div(target, tiles) : target / tiles;       // big tiles: one workgroup per CU (LDS), so at most 256 of them -- one more is a second round
   const int max_splits = ceil_div(M, TN_BM);
   if (splits > max_splits) splits = max_splits;
   return splits < 1 ? 1 : splits;

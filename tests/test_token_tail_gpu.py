@@ -207,3 +207,37 @@ def test_fused_training_mlp_in_the_engine_matches_the_three_kernels():
         torch.testing.assert_close(a, b, rtol=3e-2, atol=3e-2)
     assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_a)
     assert float((g_a - g_b).norm()) <= 3e-2 * float(g_a.norm()), float((g_a - g_b).norm()) / float(g_a.norm())
+
+
+def test_shared_patch_rows_give_identical_results():
+    """Student and teacher take the batch's patch rows from one uvc_patchify (uvc_vit_io.patches_in, model_distilled._shared_patches):
+    bit-identical logits, loss, gradients and teacher output to each model rearranging the batch itself; an entry is consumed once."""
+    import uvc_amd.model_distilled as MD
+    B = 8
+    tr = _trainer("bf16", B)
+    tr.begin_epoch(tr.args.warmup_epochs + 1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, 3, 224, 224, device="cuda", generator=g)
+    y = torch.softmax(torch.randn(B, 1000, device="cuda", generator=g), -1)
+    tr.model.train()
+    res = {}
+    old = MD._SHARE_PATCHES
+    try:
+        for share in (False, True):
+            MD._SHARE_PATCHES = share
+            MD._PATCH_SHARE.update(key=None, buf=None, ev=None, owner=None)
+            m = tr.model
+            m._flat_grad.zero_()
+            e = torch.empty(m._cfg.depth, 2, device="cuda").exponential_(generator=torch.Generator(device="cuda").manual_seed(9))
+            m.exp_source = lambda shape, e=e: e.clone()
+            tr.criterion.prefetch(x)                                  # teacher first, on its side stream (as Stage1Trainer.step does)
+            outputs, _ = m(x, -1, tr.args.patch_ratio)
+            loss = tr.criterion(x, outputs, y)
+            loss.backward()
+            torch.cuda.synchronize()
+            if share:
+                assert MD._PATCH_SHARE["key"] is None                 # produced by the teacher, consumed by the student
+            res[share] = (outputs[0].detach().clone(), float(loss.detach()), m._flat_grad[:m._off.n_total].clone())
+    finally:
+        MD._SHARE_PATCHES = old
+    assert torch.equal(res[True][0], res[False][0]) and res[True][1] == res[False][1] and torch.equal(res[True][2], res[False][2])

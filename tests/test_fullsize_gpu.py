@@ -200,3 +200,26 @@ def test_forward_is_batch_independent_for_the_wider_models(model_type, big):
     a1 = fwd_bwd(tr, x, y)
     a2 = fwd_bwd(tr, x, y)
     assert torch.equal(a1[0], a2[0]) and a1[1] == a2[1] and torch.equal(a1[2], a2[2])
+
+
+def test_stage2_step_at_the_bench_shape_with_compacted_mlps():
+    """bench.py --stage 2 (per-GPU batch 512, half of the MLP units pruned, two blocks skipped): the compacted widths (512 of 768)
+    tile the weight gradients differently from the dense ones -- more M splits, a larger split-M workspace.  A workspace sized for
+    the dense shapes only made this step fail with 'uvc_gemm_tn: workspace too small' (r2f); it must run and give finite numbers."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from uvc_amd.post_train import Stage2Trainer, default_args
+    a = default_args(model_type="deit_tiny_patch16_224", precision="bf16", train_batch_size=B_FULL)
+    tr = Stage2Trainer(a, device="cuda", distributed=False, world_size=1)
+    bench.stage2_checkpoint_state(tr.model)
+    tr.mlp_widths = tr.model.set_mlp_compaction()
+    assert any(0 < w < 768 for w in tr.mlp_widths)
+    tr.begin_epoch(a.warmup_epochs + 1)
+    x, y = inputs(B_FULL)
+    out = None
+    for _ in range(2):
+        out = tr.step(x, y)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(out["loss"])) and np.isfinite(float(out["gnorm"]))

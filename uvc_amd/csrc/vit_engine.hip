@@ -71,6 +71,11 @@ int64_t max_tn_ws(const Dims& d) {
   int64_t best = 0, b; int s;
   const int shapes[6][3] = {{d.M, d.D, d.F}, {d.M, d.F, d.D}, {d.M, d.D, d.D}, {d.M, 3 * d.D, d.D}, {d.B, d.NC, d.D}, {d.B * d.np, d.D, d.K0}};
   for (auto& sh : shapes) { uvc_gemm_tn_workspace_bytes(sh[0], sh[1], sh[2], &b, &s); if (b > best) best = b; }
+  // compacted MLP widths (Stage-2: multiples of 256 below F) tile differently: fewer tiles, more M splits
+  for (int fe = 256; fe < d.F; fe += 256) {
+    uvc_gemm_tn_workspace_bytes(d.M, d.D, fe, &b, &s); if (b > best) best = b;
+    uvc_gemm_tn_workspace_bytes(d.M, fe, d.D, &b, &s); if (b > best) best = b;
+  }
   return best;
 }
 

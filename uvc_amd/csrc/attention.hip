@@ -510,21 +510,25 @@ template <typename T, int NT16> int launch(const AttnArgs& a, int which, hipStre
     // DeiT's N = 197 / 198: twelve full key tiles, a partial one and a tile of padding -- known at compile time (see attn_key_block)
     constexpr int NF = NT16 == 14 ? 12 : -1;
     if (NF >= 0 && a.N / 16 == NF) {
-      if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16, 8, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      static const hipError_t e0 = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16, 8, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);   // once: sh is a function of the instantiation
+      e = e0;
       if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
       k_attn_fwd<T, NT16, 8, NF><<<fgrid, sizeof(T) == 2 ? 512 : 256, sh, st>>>(a);
     } else {
-      if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      static const hipError_t e0 = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      e = e0;
       if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
       k_attn_fwd<T, NT16><<<fgrid, sizeof(T) == 2 ? 512 : 256, sh, st>>>(a);
     }
   } else if (which == 1) {
-    if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_bwd_dq<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static const hipError_t e0 = hipFuncSetAttribute((const void*)k_attn_bwd_dq<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    e = e0;
     if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
     k_attn_bwd_dq<T, NT16><<<grid, threads, sh, st>>>(a);
   } else {
     sh += (size_t)2 * NP * sizeof(float);
-    if (sh > 65536) e = hipFuncSetAttribute((const void*)k_attn_bwd_dkv<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static const hipError_t e0 = hipFuncSetAttribute((const void*)k_attn_bwd_dkv<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    e = e0;
     if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
     k_attn_bwd_dkv<T, NT16><<<grid, threads, sh, st>>>(a);
   }

@@ -840,7 +840,7 @@ static int launch_wsn16_kt(const NtArgs& a, int epi, hipStream_t st) {
   const int grid = ntiles < 256 ? ntiles : 256;
   const size_t sh = (size_t)2 * 16 * (KT * 64 + 32);
 #define WN_CASE(E) case E: { \
-    hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsn16<TC, E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    static const hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsn16<TC, E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
     k_gemm_wsn16<TC, E, KT><<<grid, 768, sh, st>>>(a); } break;
   switch (epi) {
@@ -862,7 +862,7 @@ static int launch_wsn_kt(const NtArgs& a, int epi, hipStream_t st) {
   const int grid = ntiles < 256 ? ntiles : 256;                 // one persistent workgroup per CU
   const size_t sh = (size_t)2 * WN_BM * (KT * 64 + 32);
 #define WN_CASE(E) case E: { \
-    hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsn<TC, E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    static const hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsn<TC, E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
     k_gemm_wsn<TC, E, KT><<<grid, 768, sh, st>>>(a); } break;
   switch (epi) {                       // bf16 outputs only (float32 outputs run k_gemm_wsn16; residual epilogues need float32 C)
@@ -2033,7 +2033,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
       else k_gemm_tn_big<TA_, 192, 192, 2, 4><<<grid, 512, 0, st>>>(a);
 #define TN_DMA_ONE(B1_, B2_, W1_, W2_) { \
         const int sh_ = TD_NST * (((TD_BM * (((B1_) * 2 + 32) / 16 + ((B2_) * 2 + 32) / 16) + 63) / 64) * 1024) + 1024; \
-        hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_tn_dma<B1_, B2_, W1_, W2_>, hipFuncAttributeMaxDynamicSharedMemorySize, sh_); \
+        static const hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_tn_dma<B1_, B2_, W1_, W2_>, hipFuncAttributeMaxDynamicSharedMemorySize, sh_); \
         if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
         k_gemm_tn_dma<B1_, B2_, W1_, W2_><<<grid, 512, sh_, st>>>(a); }
       if (p->a_is_f32) { TN_BIG(float) }           // float32 A (converted on load): register-staged kernel

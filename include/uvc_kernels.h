@@ -49,8 +49,14 @@ typedef struct uvc_gemm_nt_args {
   int32_t M, N, K, lda, ldb, ldc, ldr, ldaux;
   int32_t dtype, a_is_f32, c_is_f32, epilogue;
   int32_t force_generic;  /* tests/tuning: 1 = skip the weights-stationary streaming kernel */
+  /* optional second output of the residual epilogues where uvc_gemm_nt_ln_supported(): ln_out[M,N] (T) = LayerNorm(C rows; ln_gamma,
+   * ln_beta, ln_eps) -- norm1 of the next block on the rows fc2 + residual (+ gate mix) just produced (model_distilled.py:241-244) --
+   * and its float32 statistics ln_mean / ln_rstd [M] (both or neither).  Needs alpha == 1, contiguous A / R (lda == K, ldr == N). */
+  float ln_eps;
+  const float* ln_gamma; const float* ln_beta; void* ln_out; float* ln_mean; float* ln_rstd;
 } uvc_gemm_nt_args;
 int uvc_gemm_nt(const uvc_gemm_nt_args* args, void* stream);
+int uvc_gemm_nt_ln_supported(int32_t M, int32_t N, int32_t K, int32_t dtype, int32_t epilogue);
 
 /* C[N1,N2] = beta*C + alpha * A[M,N1]^T . B[M,N2]  (weight gradients; float32 C).
  * Deterministic: M is cut into slices reduced in a fixed order through `workspace`. */
@@ -174,6 +180,9 @@ typedef struct uvc_mlp_args {
   float eps;
   const float* x_prev; const float* gate;
   void* h; float* mean; float* rstd; void* gp; void* u;
+  /* optional: LayerNorm of the OUTPUT rows with the next block's norm1 parameters (model_distilled.py:241 of block l+1),
+   * written as compute-dtype rows next_h [M,D] (+ float32 next_mean / next_rstd [M] for a backward) */
+  const float* next_gamma; const float* next_beta; void* next_h; float* next_mean; float* next_rstd;
 } uvc_mlp_args;
 int uvc_mlp_fused_supported(int32_t D, int32_t F, int32_t dtype);
 int uvc_mlp_fused_fwd(const uvc_mlp_args* args, void* stream);

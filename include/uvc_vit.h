@@ -118,6 +118,10 @@ typedef struct uvc_vit_io {
   const void* patches_in;              /* optional T [B * np, C * P * P]: the patch rows of `x` already laid out by uvc_patchify (same image size and
                                           patch size).  The forward uses them instead of running uvc_patchify, the backward reads them for the
                                           patch-embedding weight gradient.  Lets student and teacher share the one rearrangement of a batch. */
+  int32_t fuse_next_ln;                /* 1: a kernel that produces a block's output rows (uvc_mlp_fused_fwd; fc2 + residual + gate mix) also writes
+                                          norm1 of the NEXT block that runs (model_distilled.py:241) from the rows it holds, and that block skips its
+                                          stand-alone LayerNorm pass.  0: every LayerNorm is its own pass. */
+  int32_t reserved0;
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

@@ -592,6 +592,107 @@ def test_fused_training_mlp(M, F_, gated):
     torch.testing.assert_close(o_inf, out, rtol=2e-3, atol=6e-3)
 
 
+@pytest.mark.parametrize("M,gated,train", [(1576, False, False), (4096 + 37, True, True), (300, False, True), (515, True, False)])
+def test_fused_mlp_writes_the_next_blocks_norm1(M, gated, train):
+    """uvc_mlp_fused_fwd with next_h: the rows it produces leave a second time as LayerNorm(out; next_gamma, next_beta) in bf16 (the
+    next block's norm1, model_distilled.py:241) with their statistics -- against float64 LayerNorm of the kernel's own output rows
+    and against uvc_layernorm_fwd on them; `out` itself must not change by a bit when the extra output is requested."""
+    from uvc_amd import ops
+    D, F_ = 192, 768
+    x = rnd(M, D, seed=121) * 1.5 + 0.2
+    xp = rnd(M, D, seed=128)
+    gamma, beta = rnd(D, seed=122) * 0.2 + 1.0, rnd(D, seed=123) * 0.1
+    g2, b2n = rnd(D, seed=129) * 0.3 + 1.0, rnd(D, seed=130) * 0.2
+    W1, b1 = rnd(F_, D, seed=124, scale=0.06).bfloat16(), rnd(F_, seed=125) * 0.1
+    W2, b2 = rnd(D, F_, seed=126, scale=0.04).bfloat16(), rnd(D, seed=127) * 0.1
+    gate = torch.tensor([0.3, 0.7], device=dev()) if gated else None
+    kw = dict(x_prev=xp if gated else None, gate=gate)
+    if train:
+        kw.update(h=torch.empty(M, D, device=dev(), dtype=torch.bfloat16), mean=torch.empty(M, device=dev()), rstd=torch.empty(M, device=dev()),
+                  gp=torch.empty(M, F_, device=dev(), dtype=torch.bfloat16), u=torch.empty(M, F_, device=dev(), dtype=torch.bfloat16))
+    plain = torch.empty(M, D, device=dev())
+    ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, plain, **kw)
+    out = torch.full((M, D), float("nan"), device=dev())
+    nh = torch.full((M, D), float("nan"), device=dev(), dtype=torch.bfloat16)
+    nm, nr = torch.full((M,), float("nan"), device=dev()), torch.full((M,), float("nan"), device=dev())
+    ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, out, next_gamma=g2, next_beta=b2n, next_h=nh, next_mean=nm, next_rstd=nr, **kw)
+    assert torch.equal(out, plain)
+    od = out.double()
+    ref = F.layer_norm(od, (D,), g2.double(), b2n.double(), 1e-6)
+    torch.testing.assert_close(nh.double(), ref, rtol=8e-3, atol=8e-3)                     # bf16 rounding of the result
+    torch.testing.assert_close(nm.double(), od.mean(1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(nr.double(), torch.rsqrt(od.var(1, unbiased=False) + 1e-6), rtol=1e-5, atol=0)
+    hb = torch.empty(M, D, device=dev(), dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.layernorm_fwd(out, g2, b2n, hb, mean, rstd, M, D, BF16)
+    torch.testing.assert_close(nm, mean, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(nr, rstd, rtol=2e-6, atol=0)
+    # same float32 formula, possibly another summation order inside a row: at most one bf16 ulp apart, and almost nowhere
+    diff = (nh.float() - hb.float()).abs()
+    assert float(diff.max()) <= 2.0 ** -7 * float(hb.float().abs().max()) + 1e-6
+    assert float((diff > 0).float().mean()) < 0.02
+    nh2 = torch.empty_like(nh)                                                              # statistics optional
+    ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, torch.empty_like(out), next_gamma=g2, next_beta=b2n, next_h=nh2, **kw)
+    assert torch.equal(nh2, nh)
+
+
+@pytest.mark.parametrize("M,gated,stats,K", [(4096, False, True, 768), (4096 + 16 * 37, True, True, 768), (100864, True, False, 768),
+                                             (4096 + 16 * 5, False, True, 192), (100864, False, True, 192), (4096, False, False, 192),
+                                             (1576, True, True, 768), (197, False, True, 192), (16, False, True, 768), (8 * 197 + 3, False, True, 192)])
+def test_fc2_residual_epilogue_writes_the_next_blocks_norm1(M, gated, stats, K):
+    """uvc_gemm_nt with ln_out (fc2 + bias + residual [+ gate mix] at K = 768 -> N = 192 writing the next block's norm1; attn.proj + bias +
+    residual at K = 192 writing norm2, same kernel on a seven-stage ring): C must not change by a bit, ln_out =
+    LayerNorm(C rows) in bf16 with the row statistics combined across the 12 column-slice waves -- against float64 LayerNorm of C and
+    against uvc_layernorm_fwd on C; deterministic; refused (UVC_ERR_UNSUPPORTED) where the kernel does not run."""
+    from uvc_amd import ops, _lib as L
+    D = 192
+    A = (rnd(M, K, seed=141) * 0.5).bfloat16()
+    W, bias = rnd(D, K, seed=142, scale=0.05).bfloat16(), rnd(D, seed=143) * 0.1
+    R, R2 = rnd(M, D, seed=144) * 1.5 + 0.3, rnd(M, D, seed=145)
+    R[5] += 40.0                                                                            # a row far from zero mean: centred statistics
+    g2, b2n = rnd(D, seed=146) * 0.3 + 1.0, rnd(D, seed=147) * 0.2
+    gate = torch.tensor([0.25, 0.75], device=dev()) if gated else None
+    epi = ops.EPI_BIAS_RESID_GATE if gated else ops.EPI_BIAS_RESID
+    kw = dict(dtype=BF16, epilogue=epi, bias=bias, R=R, R2=R2 if gated else None, gate=gate)
+    assert L.lib().uvc_gemm_nt_ln_supported(M, D, K, BF16, epi) == 1
+    plain = torch.empty(M, D, device=dev())
+    ops.gemm_nt(A, W, plain, **kw)
+    out = torch.full((M, D), float("nan"), device=dev())
+    nh = torch.full((M, D), float("nan"), device=dev(), dtype=torch.bfloat16)
+    nm = torch.full((M,), float("nan"), device=dev()) if stats else None
+    nr = torch.full((M,), float("nan"), device=dev()) if stats else None
+    ops.gemm_nt(A, W, out, ln_gamma=g2, ln_beta=b2n, ln_out=nh, ln_mean=nm, ln_rstd=nr, **kw)
+    assert torch.equal(out, plain)
+    od = out.double()
+    ref = F.layer_norm(od, (D,), g2.double(), b2n.double(), 1e-6)
+    torch.testing.assert_close(nh.double(), ref, rtol=8e-3, atol=8e-3)
+    hb = torch.empty(M, D, device=dev(), dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.layernorm_fwd(out, g2, b2n, hb, mean, rstd, M, D, BF16)
+    if stats:
+        torch.testing.assert_close(nm.double(), od.mean(1), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(nr.double(), torch.rsqrt(od.var(1, unbiased=False) + 1e-6), rtol=1e-5, atol=0)
+        torch.testing.assert_close(nm, mean, rtol=2e-6, atol=1e-6)
+        torch.testing.assert_close(nr, rstd, rtol=2e-6, atol=0)
+    diff = (nh.float() - hb.float()).abs()
+    assert float(diff.max()) <= 2.0 ** -7 * float(hb.float().abs().max()) + 1e-6
+    assert float((diff > 0).float().mean()) < 0.02
+    nh2 = torch.empty_like(nh)
+    ops.gemm_nt(A, W, torch.empty_like(out), ln_gamma=g2, ln_beta=b2n, ln_out=nh2, **kw)
+    assert torch.equal(nh2, nh)
+    # rows do not depend on how many rows there are (any M from 16 up runs this kernel; a ragged last tile overlaps its neighbour)
+    m2 = max(16, M // 3 + 5)
+    kw2 = dict(kw, R=R[:m2].contiguous(), R2=R2[:m2].contiguous() if gated else None)
+    o3, nh3 = torch.empty(m2, D, device=dev()), torch.empty(m2, D, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(A[:m2].contiguous(), W, o3, ln_gamma=g2, ln_beta=b2n, ln_out=nh3, **kw2)
+    assert torch.equal(o3, out[:m2]) and torch.equal(nh3, nh[:m2])
+    # not this kernel's shape: refused, nothing silently skipped
+    assert L.lib().uvc_gemm_nt_ln_supported(M, D, 576, BF16, epi) == 0
+    if K == 768:
+        with pytest.raises(RuntimeError):
+            ops.gemm_nt(A[:, :576].contiguous(), W[:, :576].contiguous(), out, ln_gamma=g2, ln_beta=b2n, ln_out=nh2, **kw)
+
+
 # ---- patch-gating Gumbel top-k at the production shape (SURVEY 8 row a8; VERDICT r1 weak #1)
 @pytest.mark.parametrize("B,P,k,tau", [(64, 196, 176, 0.7), (512, 196, 176, 0.1), (96, 196, 176, 10.0), (3, 16, 14, 1.0)])
 def test_patch_topk_mask_production_shape_bit_exact_indices(B, P, k, tau):

@@ -241,3 +241,31 @@ def test_shared_patch_rows_give_identical_results():
     finally:
         MD._SHARE_PATCHES = old
     assert torch.equal(res[True][0], res[False][0]) and res[True][1] == res[False][1] and torch.equal(res[True][2], res[False][2])
+
+
+@pytest.mark.parametrize("fused_train", [False, True])
+def test_norm1_written_by_the_producer_of_its_rows_matches_the_stand_alone_pass(fused_train):
+    """uvc_vit_io.fuse_next_ln (default 1): the kernel that produces a block's output rows -- uvc_mlp_fused_fwd in the teacher / eval forward
+    and in the opt-in fused training forward, the fc2 + residual + gate-mix GEMM in the default training forward -- also writes norm1 of
+    the next block (and its statistics for the backward) and that block's stand-alone LayerNorm pass is skipped.  Same float32 formula on
+    the same rows (another summation order inside a row): logits, loss, gradients and the teacher's output agree with fuse_next_ln = 0
+    to bf16 rounding."""
+    B = 16
+    tr = _trainer("bf16", B)
+    tr.begin_epoch(tr.args.warmup_epochs + 1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, 3, 224, 224, device="cuda", generator=g)
+    y = torch.softmax(torch.randn(B, 1000, device="cuda", generator=g), -1)
+    tr.model.train()
+    tr.model.fused_train_mlp = fused_train
+    res = {}
+    for fuse in (False, True):
+        tr.model.fuse_next_ln = fuse
+        tr.teacher.fuse_next_ln = fuse
+        res[fuse] = _fwd_bwd(tr, x, y, False)
+    (lo_a, loss_a, g_a, t_a), (lo_b, loss_b, g_b, t_b) = res[False], res[True]
+    for a, b in zip(lo_a, lo_b):
+        torch.testing.assert_close(a, b, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(t_a, t_b, rtol=3e-2, atol=3e-2)
+    assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_a)
+    assert float((g_a - g_b).norm()) <= 3e-2 * float(g_a.norm()), float((g_a - g_b).norm()) / float(g_a.norm())

@@ -56,7 +56,11 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
     # ---- forward (student; the teacher repeats LayerNorm1, qkv, attention, proj and runs the fused MLP)
     y = torch.empty(M, D, device=dev, dtype=bf)
     m_, r_ = torch.empty(M, device=dev), torch.empty(M, device=dev)
-    add("ln_fwd", "k_ln_fwd_v", (1 + T) * L + Lf, 3 * u, 0, lambda: ops.layernorm_fwd(x32, gam, bet, y, m_, r_, M, D, dt))
+    # DeiT-Tiny width (uvc_vit_io.fuse_next_ln): norm1 of blocks 1 .. L-1 is written by the kernel that produces their input rows
+    # (fc2 + residual + gate mix of the student, the fused MLP of the teacher), so only block 0's norm1 is a pass of its own
+    fuse_ln = tiny
+    n_ln1 = 1 if fuse_ln else L
+    add("ln_fwd", "k_ln_fwd_v", (1 + T) * n_ln1 + Lf, 3 * u, 0, lambda: ops.layernorm_fwd(x32, gam, bet, y, m_, r_, M, D, dt))
     qkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
     add("qkv", "k_gemm_ws<unsigned short, unsigned short, 1" if tiny else "k_gemm", (1 + T) * L, 4 * u, 2.0 * M * D * 3 * D,
         lambda: ops.gemm_nt(xb, Wqkv, qkv, dtype=dt, epilogue=ops.EPI_BIAS, bias=b3))
@@ -76,10 +80,16 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
     aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
     add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
         lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu))
-    add("fc2+resid+gate", "k_gemm_wsn16_dma<4" if tiny else "k_gemm", Lf, 10 * u, 2.0 * M * D * F,
-        lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate))
+    if fuse_ln:
+        add("fc2+resid+gate+norm1", "k_gemm_wsn16_dma<4", Lf, 11 * u, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate,
+                                ln_gamma=gam, ln_beta=bet, ln_out=y, ln_mean=m_, ln_rstd=r_))
+    else:
+        add("fc2+resid+gate", "k_gemm", Lf, 10 * u, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate))
     if tiny and with_teacher:
-        add("teacher mlp_fused", "k_mlp_fused", Lf, 4 * u, 4.0 * M * D * F, lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32))
+        add("teacher mlp_fused+norm1", "k_mlp_fused", Lf, 5 * u, 4.0 * M * D * F,
+            lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32, next_gamma=gam, next_beta=bet, next_h=y))
     # ---- backward, main stream
     dA = torch.empty(M, F, device=dev, dtype=bf)
     add("dfc2 x gelu'", "k_gemm_ws<unsigned short, unsigned short, 8" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,

@@ -23,8 +23,8 @@ NAMES = {
     "attn_fwd": ["k_attn_fwd"],
     "proj+resid": ["k_gemm_ws<unsigned short, float, 3"],
     "fc1+gelu,gelu'": ["k_gemm_ws<unsigned short, unsigned short, 7"],
-    "fc2+resid+gate": ["k_gemm_wsn16_dma<4"],
-    "teacher mlp_fused": ["k_mlp_fused"],
+    "fc2+resid+gate+norm1": ["k_gemm_wsn16_dma<4"],
+    "teacher mlp_fused+norm1": ["k_mlp_fused"],
     "dfc2 x gelu'": ["k_gemm_ws<unsigned short, unsigned short, 8"],
     "dfc1+ln2_bwd": ["k_gemm_wsn_lnbwd_dma<24"],
     "dqkv+ln1_bwd": ["k_gemm_wsn_lnbwd_dma<18"],

@@ -43,7 +43,8 @@ class uvc_gemm_nt_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("A", "B", "C", "C2", "bias", "R", "R2", "aux", "gate", "alpha_ptr")] + \
                [("alpha", C.c_float)] + \
                [(n, C.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldr", "ldaux", "dtype", "a_is_f32",
-                                         "c_is_f32", "epilogue", "force_generic")]
+                                         "c_is_f32", "epilogue", "force_generic")] + \
+               [("ln_eps", C.c_float)] + [(n, C.c_void_p) for n in ("ln_gamma", "ln_beta", "ln_out", "ln_mean", "ln_rstd")]
 
 
 class uvc_gemm_tn_args(C.Structure):
@@ -83,7 +84,8 @@ class uvc_gemm_lnbwd_args(C.Structure):
 class uvc_mlp_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "gamma", "beta", "w1", "b1", "w2", "b2", "out")] + \
                [(n, C.c_int32) for n in ("M", "D", "F")] + [("eps", C.c_float)] + \
-               [(n, C.c_void_p) for n in ("x_prev", "gate", "h", "mean", "rstd", "gp", "u")]
+               [(n, C.c_void_p) for n in ("x_prev", "gate", "h", "mean", "rstd", "gp", "u",
+                                          "next_gamma", "next_beta", "next_h", "next_mean", "next_rstd")]
 
 
 class uvc_loss_args(C.Structure):
@@ -128,6 +130,7 @@ _SIGNATURES = {
     "uvc_write_masks": [VP, VP, VP, uvc_dims, VP, VP, VP, VP, VP, VP],
     # include/uvc_kernels.h
     "uvc_gemm_nt": [C.POINTER(uvc_gemm_nt_args), VP],
+    "uvc_gemm_nt_ln_supported": [I32, I32, I32, I32, I32],
     "uvc_gemm_tn": [C.POINTER(uvc_gemm_tn_args), VP],
     "uvc_gemm_tn_workspace_bytes": [I32, I32, I32, C.POINTER(I64), C.POINTER(I32)],
     "uvc_attention_fwd": [C.POINTER(uvc_attn_args), VP],

@@ -63,6 +63,17 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// v + (lanes ^16, ^32, ^48): the sum over the four 16-lane rows of a wave, in every lane, by the gfx950 row-swap VALU instructions
+// (v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute round trips through the LDS crossbar.  Same additions in the
+// same order as  v += shfl_xor(v, 16); v += shfl_xor(v, 32)  -> same bits.
+__device__ __forceinline__ float sum_rows4(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned c = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 // exact-erf GELU and its derivative (nn.GELU default, model_distilled.py:108,118) -- float32 parity mode
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

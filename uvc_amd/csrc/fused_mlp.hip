@@ -122,16 +122,14 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 2 * KT; ++i) s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
+      s = sum_rows4(s);
       const float mean = s * (1.0f / D);
       float q = 0.f;
 #pragma unroll
       for (int i = 0; i < 2 * KT; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; q += d * d; }
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
+      q = sum_rows4(q);
       const float rstd = rsqrtf(q * (1.0f / D) + a.eps);
       const int prow = m0 + r * 16 + li;
       if (TRAIN && prow < a.M && g == 0) { a.mean[prow] = mean; a.rstd[prow] = rstd; }
@@ -337,8 +335,45 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
           const f32x4 xp = *reinterpret_cast<const f32x4*>(a.x_prev + (size_t)row * D + col);
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(d1, o[e], __builtin_fmaf(d0, xp[e], 0.0f));
+          out[r][j] = o;
         }
         *reinterpret_cast<f32x4*>(orow + col) = o;
+      }
+    }
+  }
+  // ---- the NEXT block's LayerNorm1 of the rows just produced (they are whole rows in this wave's registers: lane (row, g) holds
+  //      48 of the 192 columns, the other three lanes of the row the rest): next_h = LN(out; next_gamma, next_beta) as bf16, so the
+  //      consumer's qkv GEMM starts from it and the stand-alone pass (read 77 MB, write 39 MB per block) disappears.  Two-pass
+  //      statistics, same arithmetic as k_ln_fwd_v (mean, then centred squares).
+  if (a.next_h) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int row = m0 + r * 16 + li;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < D / 16; ++j) s += (out[r][j][0] + out[r][j][1]) + (out[r][j][2] + out[r][j][3]);
+      s = sum_rows4(s);
+      const float mean = s * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < D / 16; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float dd = out[r][j][e] - mean; q += dd * dd; }
+      q = sum_rows4(q);
+      const float rstd = rsqrtf(q * (1.0f / D) + a.eps);
+      if (row < a.M) {
+        if (a.next_mean && g == 0) { a.next_mean[row] = mean; a.next_rstd[row] = rstd; }
+        T* hrow = reinterpret_cast<T*>(a.next_h) + (size_t)row * D;
+#pragma unroll
+        for (int j = 0; j < D / 16; ++j) {
+          const int col = j * 16 + g * 4;
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(a.next_gamma + col), bt = *reinterpret_cast<const f32x4*>(a.next_beta + col);
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (out[r][j][e] - mean) * rstd * gm[e] + bt[e];
+          u32x2 pk; pk[0] = pack_bf16x2(y[0], y[1]); pk[1] = pack_bf16x2(y[2], y[3]);
+          *reinterpret_cast<u32x2*>(hrow + col) = pk;
+        }
       }
     }
   }
@@ -359,6 +394,10 @@ extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
   const bool train = p->h || p->u || p->gp || p->mean || p->rstd;
   if (train && (!p->h || !p->u || !p->gp || !p->mean || !p->rstd)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: training needs h, mean, rstd, gp and u");
   if ((p->gate != nullptr) != (p->x_prev != nullptr)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: gate and x_prev come together");
+  if (p->next_h && (!p->next_gamma || !p->next_beta || (((uintptr_t)p->next_h | (uintptr_t)p->next_gamma | (uintptr_t)p->next_beta) & 15) != 0))
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: next_h needs 16-byte aligned next_gamma, next_beta");
+  if ((p->next_mean != nullptr) != (p->next_rstd != nullptr) || (p->next_mean && !p->next_h))
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: next_mean and next_rstd come together, with next_h");
   hipStream_t st = (hipStream_t)stream;
   {
     static bool attr_set = false;

@@ -87,6 +87,8 @@ struct NtArgs {
   int M, N, K, lda, ldb, ldc, ldr, ldaux;
   float alpha;
   const float* alpha_ptr;   // optional device scalar multiplied into alpha
+  // optional second output of the N == 192 residual epilogues: LayerNorm of the output rows (uvc_gemm_nt_args.ln_*)
+  const float* ln_gamma; const float* ln_beta; void* ln_out; float* ln_mean; float* ln_rstd; float ln_eps;
 };
 
 // vector of VN consecutive outputs in the coalesced epilogue layout
@@ -815,27 +817,35 @@ static bool wsn_ok(const NtArgs& a, int epi, bool a_f32) {
   return !a_f32 && a.N == 192 && (a.K == 768 || a.K == 576 || a.K == 512 || a.K == 256) && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % 4 == 0 && a.ldr % 4 == 0 && a.M >= 4096 &&
          (epi == UVC_EPI_NONE || epi == UVC_EPI_BIAS || epi == UVC_EPI_BIAS_RESID || epi == UVC_EPI_BIAS_RESID_GATE);
 }
-template <int EPI, int KT> __global__ void k_gemm_wsn16_dma(NtArgs g);
-template <int EPI, int KT>
+template <int EPI, int KT, bool LN, int NST> __global__ void k_gemm_wsn16_dma(NtArgs g);
+template <int EPI, int KT, bool LN, int NST = 3>
 static int launch_wsn16_dma(const NtArgs& a, hipStream_t st) {
   constexpr int NA_ = (16 * (KT * 4 + 2) + 63) / 64, NI_ = NA_ + 13 + (EPI == UVC_EPI_BIAS_RESID_GATE ? 13 : 0);
-  const int sh = 3 * NI_ * 1024;
-  static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn16_dma<EPI, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
+  const int sh = NST * NI_ * 1024 + (LN ? 2 * 16 * 12 * 8 + 2 * 192 * 4 : 0);
+  static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn16_dma<EPI, KT, LN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
   if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__);
-  const int ntiles = a.M / 16;
-  k_gemm_wsn16_dma<EPI, KT><<<ntiles < 256 ? ntiles : 256, 768, sh, st>>>(a);
+  const int ntiles = ceil_div(a.M, 16);
+  k_gemm_wsn16_dma<EPI, KT, LN, NST><<<ntiles < 256 ? ntiles : 256, 768, sh, st>>>(a);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
+}
+// the shapes whose residual epilogue can also write LayerNorm(output rows): what k_gemm_wsn16_dma takes
+static bool wsn16_dma_ok(const NtArgs& a) {
+  return a.M >= 16 && a.lda == a.K && a.ldr == 192 && a.ldc % 4 == 0 && (((uintptr_t)a.R | (uintptr_t)a.R2 | (uintptr_t)a.A) & 15) == 0;
 }
 template <typename TC, int KT>
 static int launch_wsn16_kt(const NtArgs& a, int epi, hipStream_t st) {
   if constexpr (sizeof(TC) == 4 && KT == 24) {       // fc2 of DeiT-Tiny: LDS-DMA ring (UVC_FC2_DMA=0 keeps the register-staged kernel)
     static const bool use_dma = [] { const char* v = getenv("UVC_FC2_DMA"); return v ? atoi(v) != 0 : true; }();
-    const bool ok = use_dma && a.M % 16 == 0 && a.lda == a.K && a.ldr == 192 && a.ldc % 4 == 0 &&
-                    (((uintptr_t)a.R | (uintptr_t)a.R2 | (uintptr_t)a.A) & 15) == 0;
-    if (ok && epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT>(a, st);
-    if (ok && epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT>(a, st);
+    const bool ok = (use_dma || a.ln_out) && wsn16_dma_ok(a) && (a.ln_out || a.M % 16 == 0);
+    if (ok && a.ln_out) {
+      if (epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, true>(a, st);
+      if (epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, true>(a, st);
+    }
+    if (ok && epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, false>(a, st);
+    if (ok && epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, false>(a, st);
   }
+  if (a.ln_out) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: ln_out is not available for this problem (uvc_gemm_nt_ln_supported)");
   const int ntiles = ceil_div(a.M, 16);
   const int grid = ntiles < 256 ? ntiles : 256;
   const size_t sh = (size_t)2 * 16 * (KT * 64 + 32);
@@ -898,6 +908,11 @@ static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
   return UVC_OK;
 }
 
+extern "C" int uvc_gemm_nt_ln_supported(int32_t M, int32_t N, int32_t K, int32_t dtype, int32_t epilogue) {
+  if (dtype != UVC_BF16 || N != 192 || M < 16) return 0;      // any row count from 16 up: whether norm is fused must not depend on the batch
+  return (K == 768 && (epilogue == UVC_EPI_BIAS_RESID || epilogue == UVC_EPI_BIAS_RESID_GATE)) || (K == 192 && epilogue == UVC_EPI_BIAS_RESID);
+}
+
 extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   if (!p || !p->A || !p->B || !p->C) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: null pointer");
   if (p->M <= 0 || p->N <= 0 || p->K <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: empty problem");
@@ -916,7 +931,20 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   a.A = p->A; a.B = p->B; a.C = p->C; a.C2 = p->C2; a.bias = p->bias; a.R = p->R; a.R2 = p->R2; a.aux = p->aux;
   a.dptr = p->gate; a.M = p->M; a.N = p->N; a.K = p->K; a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
   a.ldr = p->ldr ? p->ldr : p->ldc; a.ldaux = p->ldaux ? p->ldaux : p->ldc; a.alpha = p->alpha; a.alpha_ptr = p->alpha_ptr;
+  a.ln_gamma = p->ln_gamma; a.ln_beta = p->ln_beta; a.ln_out = p->ln_out; a.ln_mean = p->ln_mean; a.ln_rstd = p->ln_rstd; a.ln_eps = p->ln_eps;
   hipStream_t st = (hipStream_t)stream;
+  if (p->ln_out) {
+    if (!p->ln_gamma || !p->ln_beta || (p->ln_mean != nullptr) != (p->ln_rstd != nullptr))
+      return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: ln_out needs ln_gamma, ln_beta (and ln_mean, ln_rstd together)");
+    if (!uvc_gemm_nt_ln_supported(p->M, p->N, p->K, p->dtype, e) || p->force_generic || p->a_is_f32 || !p->c_is_f32 || p->alpha != 1.0f || p->alpha_ptr ||
+        a.ldb != a.K || !wsn16_dma_ok(a) || ((uintptr_t)p->ln_out & 7) != 0)
+      return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: ln_out is not available for this problem (uvc_gemm_nt_ln_supported)");
+    if (p->M % 16 != 0 && (p->C == (const void*)p->R || p->C == (const void*)p->R2))
+      return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: with ln_out and M % 16 != 0 the last row tile is computed twice: C must not alias R / R2");
+    // attn.proj + residual -> norm2 (K = 192): 20-KB stages, seven of them, six in flight
+    if (p->K == 192) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, true, 7>(a, st);
+    return launch_wsn<float>(a, e, st);
+  }
   if (p->dtype == UVC_F32) {
     if (!p->a_is_f32 || !p->c_is_f32) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: float32 mode needs float32 A and C");
     return launch_nt_epi<float, float, float>(a, e, st);
@@ -1050,8 +1078,8 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd(LnbArgs g) {
         p1 += gy;
         p2 += gy * xh;
       }
-      p1 += __shfl_xor(p1, 16, 64); p1 += __shfl_xor(p1, 32, 64);
-      p2 += __shfl_xor(p2, 16, 64); p2 += __shfl_xor(p2, 32, 64);
+      p1 = sum_rows4(p1);
+      p2 = sum_rows4(p2);
       if (gq == 0) *reinterpret_cast<f32x2*>(red + (li * NWV + w) * 2) = f32x2{p1, p2};
     }
     if (next < ntiles) lstore(par ? sA0 : sA1);
@@ -1283,8 +1311,8 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
         p1 += gy;
         p2 += gy * xh;
       }
-      p1 += __shfl_xor(p1, 16, 64); p1 += __shfl_xor(p1, 32, 64);
-      p2 += __shfl_xor(p2, 16, 64); p2 += __shfl_xor(p2, 32, 64);
+      p1 = sum_rows4(p1);
+      p2 = sum_rows4(p2);
       if (gq == 0) ds_write64_a(redr + (unsigned)(par * 16 * NWV * 8 + w * 8), f32x2{p1, p2});
 #pragma unroll
       for (int e = 0; e < 4; ++e) c0[e] *= gam[e];
@@ -1361,7 +1389,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
 // (R = x1, R2 = x_l) go HBM -> LDS by global_load_lds_dwordx4 into three stages, two in flight; one barrier per tile; the epilogue
 // runs from registers after it.  The accumulation is the single k-ordered chain and the epilogue the same fmaf sequence as every other
 // NT kernel, so the output bits do not depend on which kernel a problem size selects (tests/test_fullsize_gpu.py).  M % 16 == 0.
-template <int EPI, int KT>
+template <int EPI, int KT, bool LN, int NST>
 __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   typedef bf16_t T;
   typedef Mma<T> MM;
@@ -1372,14 +1400,25 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   constexpr bool GATE = EPI == UVC_EPI_BIAS_RESID_GATE;
   constexpr int I_R = NA, I_R2 = I_R + NX, NI = I_R2 + (GATE ? NX : 0);
   constexpr int STAGE = NI * 1024;
-  static_assert(NI <= 5 * NWV && 3 * STAGE <= 160 * 1024, "ring does not fit");
+  constexpr int NPW = (NI + NWV - 1) / NWV;                   // DMA instructions per wave and stage (surplus ones repeat the wave's first)
+  // LN: behind the ring, the row-statistics table [2][16 rows][12 waves][2] and gamma / beta of the LayerNorm that follows
+  constexpr int LN_BYTES = LN ? 2 * 16 * NWV * 8 + 2 * D * 4 : 0;
+  static_assert(NST >= 3 && NPW <= 5 && NST * STAGE + LN_BYTES <= 160 * 1024, "ring does not fit");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, gq = lane >> 4, li = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T* __restrict__ W = reinterpret_cast<const T*>(g.B);
   float* __restrict__ C = reinterpret_cast<float*>(g.C);
-  const int ntiles = g.M / 16;
+  const int ntiles = (g.M + 15) / 16;                         // M >= 16; a ragged last tile is the LAST 16 rows (it overlaps its neighbour:
+                                                              // those rows are computed twice from the same operands, same bits, same stores)
   const int n = w * 16 + gq * 4;
+  float* const sRed = reinterpret_cast<float*>(smem + NST * STAGE);
+  float* const sGB = sRed + 2 * 16 * NWV * 2;
+  if (LN) {
+    if (tid < D) { sGB[tid] = g.ln_gamma[tid]; sGB[D + tid] = g.ln_beta[tid]; }      // before the first DMA is issued (see k_gemm_wsn_lnbwd_dma)
+  }
+  const unsigned gaddr = lds_addr(sGB) + (unsigned)n * 4u;
+  const unsigned redr = lds_addr(sRed) + (unsigned)(li * NWV * 8);
   typename MM::Frag bf[KT];
 #pragma unroll
   for (int ks = 0; ks < KT; ++ks)
@@ -1390,28 +1429,29 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   if (GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
 
-  const char* rb[5]; unsigned rstride[5], rdst[5], loff[5];
+  const char* rb[NPW]; unsigned rstride[NPW], rdst[NPW], loff[NPW];
 #pragma unroll
-  for (int q = 0; q < 5; ++q) {
+  for (int q = 0; q < NPW; ++q) {
     int I = q * NWV + w;
-    if (I >= NI) I = w;                               // duplicate of this wave's first A instruction: uniform count of five
+    if (I >= NI) I = w;                               // duplicate of this wave's first A instruction: uniform count per wave
     const int sl = (I - (I < I_R ? 0 : I < I_R2 ? I_R : I_R2)) * 64 + lane;
     rdst[q] = (unsigned)I * 1024u;
     if (I < I_R) {
       const int row = sl / SA, c = sl % SA;
-      rb[q] = reinterpret_cast<const char*>(g.A); rstride[q] = 16u * K * 2u;
+      rb[q] = reinterpret_cast<const char*>(g.A); rstride[q] = K * 2u;
       loff[q] = row < 16 ? (unsigned)(row * K * 2 + (c < K / 8 ? c : 0) * 16) : 0u;
     } else {
       const int row = sl / XS, c = sl % XS;
-      rb[q] = reinterpret_cast<const char*>(I < I_R2 ? g.R : g.R2); rstride[q] = 16u * D * 4u;
+      rb[q] = reinterpret_cast<const char*>(I < I_R2 ? g.R : g.R2); rstride[q] = D * 4u;
       loff[q] = row < 16 ? (unsigned)(row * D * 4 + (c < 48 ? c : 0) * 16) : 0u;
     }
   }
   auto issue = [&](int tile, int st) {
     const int t = tile < ntiles ? tile : ntiles - 1;
+    const unsigned r0 = (unsigned)min(t * 16, g.M - 16);          // first row of the tile
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const char* src = rb[q] + ((unsigned long long)(unsigned)t * (unsigned long long)rstride[q] + (unsigned long long)loff[q]);
+    for (int q = 0; q < NPW; ++q) {
+      const char* src = rb[q] + ((unsigned long long)r0 * (unsigned long long)rstride[q] + (unsigned long long)loff[q]);
       char* dst = smem + st * STAGE + rdst[q];
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
     }
@@ -1419,14 +1459,15 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   const unsigned s0 = lds_addr(smem);
   const unsigned fragoff = (unsigned)(li * ROWB + gq * 16), roff = (unsigned)(I_R * 1024 + li * XB + n * 4);
 
+  // NST stages, NST - 1 in flight: stage t + NST - 1 is requested at the top of iteration t into the image iteration t - 1 read
   int tile = blockIdx.x;
-  issue(tile, 0);
-  issue(tile + gridDim.x, 1);
-  wait_vm<5>();
+#pragma unroll
+  for (int q = 0; q < NST - 1; ++q) issue(tile + q * gridDim.x, q);
+  wait_vm<(NST - 2) * NPW>();
   __builtin_amdgcn_s_barrier();
-  int st = 0;
+  int st = 0, par = 0;
   for (; tile < ntiles; tile += gridDim.x) {
-    issue(tile + 2 * gridDim.x, st == 0 ? 2 : st - 1);
+    issue(tile + (NST - 1) * gridDim.x, st == 0 ? NST - 1 : st - 1);
     const unsigned sb = s0 + (unsigned)(st * STAGE);
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
     u32x4 fa[2], fb[2];
@@ -1445,11 +1486,11 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
 #undef RD2
     u32x4 rr = ds_read128<0>(sb + roff), rr2 = rr;
     if (GATE) rr2 = ds_read128<NX * 1024>(sb + roff);
-    wait_vm<5>();                                               // own part of the next stage has landed
-    wait_lgkm<0>();
-    asm volatile("" : "+v"(rr), "+v"(rr2));
-    __builtin_amdgcn_s_barrier();
-    {
+    if constexpr (!LN) {
+      wait_vm<(NST - 2) * NPW>();                                 // own part of the next stage has landed
+      wait_lgkm<0>();
+      asm volatile("" : "+v"(rr), "+v"(rr2));
+      __builtin_amdgcn_s_barrier();
       const f32x4 r = __builtin_bit_cast(f32x4, rr), r2 = __builtin_bit_cast(f32x4, rr2);
       float o[4];
 #pragma unroll
@@ -1458,9 +1499,78 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
         o[e] += r[e];
         if (GATE) o[e] = epi_gate_mix(o[e], r2[e], d0, d1);
       }
-      *reinterpret_cast<f32x4*>(C + ((size_t)(tile * 16 + li) * g.ldc + n)) = f32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(C + ((size_t)(min(tile * 16, g.M - 16) + li) * g.ldc + n)) = f32x4{o[0], o[1], o[2], o[3]};
+    } else {
+      // The output row is spread over the 12 waves (16 columns each).  Every wave leaves (mean, centred sum of squares) of its 16
+      // columns in the table BEFORE the tile's one barrier and picks up the 12 pairs after it; they combine exactly (Chan et al.):
+      // mean = sum m_w / 12, M2 = sum M2_w + 16 sum (m_w - mean)^2 -- the two-pass variance of k_ln_fwd_v without a second exchange.
+      wait_lgkm<0>();
+      asm volatile("" : "+v"(rr), "+v"(rr2));
+      const f32x4 r = __builtin_bit_cast(f32x4, rr), r2 = __builtin_bit_cast(f32x4, rr2);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = epi_scale_bias(c0[e], alpha, bias4[e]);
+        o[e] += r[e];
+        if (GATE) o[e] = epi_gate_mix(o[e], r2[e], d0, d1);
+      }
+      {
+        const float sm = sum_rows4((o[0] + o[1]) + (o[2] + o[3]));
+        const float mw = sm * (1.0f / 16.0f);
+        float qw = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float dd = o[e] - mw; qw += dd * dd; }
+        qw = sum_rows4(qw);
+        if (gq == 0) ds_write64_a(redr + (unsigned)(par * 16 * NWV * 8 + w * 8), f32x2{mw, qw});
+      }
+      wait_vm<(NST - 2) * NPW>();                                 // own part of the next stage has landed
+      wait_lgkm<0>();
+      __builtin_amdgcn_s_barrier();
+      // the 12 (m_w, M2_w) pairs of this row in wave order, two 16-byte reads at a time (8 VGPRs in flight: W^T takes 96 of the 168), ONE
+      // pass: with the first wave's mean as pivot p,  sum (m_w - mean)^2 = sum (m_w - p)^2 - 12 (mean - p)^2  loses nothing to a
+      // large common offset of the row (the pivot removes it), and the table is read once
+      const unsigned ra = redr + (unsigned)(par * 16 * NWV * 8);
+      float m2 = 0.f, s1 = 0.f, s2 = 0.f, pv;
+      u32x4 gr, br;
+      {
+        u32x4 t0 = ds_read128<0>(ra), t1 = ds_read128<16>(ra);
+        wait_lgkm<0>(); asm volatile("" : "+v"(t0), "+v"(t1));
+        const f32x4 a0 = __builtin_bit_cast(f32x4, t0), a1 = __builtin_bit_cast(f32x4, t1);
+        pv = a0[0];
+        float dd;
+        m2 += a0[1]; dd = a0[2] - pv; s1 += dd; s2 += dd * dd; m2 += a0[3];
+        dd = a1[0] - pv; s1 += dd; s2 += dd * dd; m2 += a1[1]; dd = a1[2] - pv; s1 += dd; s2 += dd * dd; m2 += a1[3];
+        asm volatile("" : "+v"(m2), "+v"(s1), "+v"(s2), "+v"(pv)); __builtin_amdgcn_sched_barrier(0);
+      }
+#define LN_ACC(OFF, EXTRA) { u32x4 t0 = ds_read128<OFF>(ra), t1 = ds_read128<OFF + 16>(ra); EXTRA wait_lgkm<0>(); asm volatile("" : "+v"(t0), "+v"(t1)); \
+        const f32x4 a0 = __builtin_bit_cast(f32x4, t0), a1 = __builtin_bit_cast(f32x4, t1); float dd; \
+        dd = a0[0] - pv; s1 += dd; s2 += dd * dd; m2 += a0[1]; dd = a0[2] - pv; s1 += dd; s2 += dd * dd; m2 += a0[3]; \
+        dd = a1[0] - pv; s1 += dd; s2 += dd * dd; m2 += a1[1]; dd = a1[2] - pv; s1 += dd; s2 += dd * dd; m2 += a1[3]; \
+        asm volatile("" : "+v"(m2), "+v"(s1), "+v"(s2)); __builtin_amdgcn_sched_barrier(0); }
+      LN_ACC(32, )
+      LN_ACC(64, gr = ds_read128<0>(gaddr); br = ds_read128<D * 4>(gaddr);)
+#undef LN_ACC
+      asm volatile("" : "+v"(gr), "+v"(br));
+      const float dm = s1 * (1.0f / 12.0f);                       // mean - pivot
+      const float mean = pv + dm;
+      const float dv = s2 - 12.0f * dm * dm;
+      const float rstd = rsqrtf((m2 + 16.0f * dv) * (1.0f / (float)D) + g.ln_eps);
+      const f32x4 gam = __builtin_bit_cast(f32x4, gr), bet = __builtin_bit_cast(f32x4, br);
+      // stores as (scalar tile base) + (32-bit lane offset): one VGPR of address each instead of hoisted 64-bit lane pointers
+      const size_t trow = (size_t)min(tile * 16, g.M - 16);
+      *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(C + trow * g.ldc) + (unsigned)((li * g.ldc + n) * 4)) = f32x4{o[0], o[1], o[2], o[3]};
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (o[e] - mean) * rstd * gam[e] + bet[e];
+      u32x2 q; q[0] = pack_bf16x2(y[0], y[1]); q[1] = pack_bf16x2(y[2], y[3]);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(reinterpret_cast<T*>(g.ln_out) + trow * D) + (unsigned)((li * D + n) * 2)) = q;
+      if (g.ln_mean && w == 0 && gq == 0) {
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(g.ln_mean + trow) + (unsigned)(li * 4)) = mean;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(g.ln_rstd + trow) + (unsigned)(li * 4)) = rstd;
+      }
+      par ^= 1;
     }
-    st = st == 2 ? 0 : st + 1;
+    st = st == NST - 1 ? 0 : st + 1;
   }
   wait_vm<0>();
 }
@@ -1550,7 +1660,7 @@ template <> struct TrFrag<float> {
 
 struct TnArgs {
   const void* A; const void* B; float* part; float* bpart;   // bpart: [splits][N1] column sums of A (bias gradient) or null
-  int M, N1, N2, lda, ldb, rows_per_split;
+  int M, N1, N2, lda, ldb, rows_per_split, xcd_remap;
 };
 
 template <typename T> struct ChunkSum;    // add the CH elements of a staged chunk into float accumulators
@@ -1831,10 +1941,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
   const char* __restrict__ B = reinterpret_cast<const char*>(g.B);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int w1 = w / W2, w2 = w % W2;
-  const int n10 = blockIdx.x * B1, n20 = blockIdx.y * B2;
-  const int mbeg = blockIdx.z * g.rows_per_split;
+  // Workgroup -> (output tile, M split).  The dispatcher deals workgroups to the 8 XCDs round-robin; with at most one workgroup per
+  // CU (grid <= 256) the tiles of one split are renumbered onto ONE XCD, adjacent in its sequence, so the operand rows the tiles
+  // share are fetched from HBM once per L2 instead of once per tile (fetch traffic 271 -> 194 MB for dW2).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int tiles = gridDim.x * gridDim.y, total = tiles * gridDim.z;
+    if (g.xcd_remap && tiles > 1 && total <= 256) {
+      const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
+      const int L = xcd * q + (xcd < r ? xcd : r) + slot;       // position in the XCD-major order
+      const int t = L % tiles;
+      bz = L / tiles; bx = t % gridDim.x; by = t / gridDim.x;
+    }
+  }
+  const int n10 = bx * B1, n20 = by * B2;
+  const int mbeg = bz * g.rows_per_split;
   const int mend = min(g.M, mbeg + g.rows_per_split);
-  const bool do_cs = g.bpart != nullptr && blockIdx.y == 0 && w2 == 0;
+  const bool do_cs = g.bpart != nullptr && by == 0 && w2 == 0;
 
   // this lane's source of DMA instruction q of a stage: byte offset at row 0 of the stage, bytes per row, row inside the stage
   int64_t goff[PER];
@@ -1917,9 +2041,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
   }
   if (do_cs && (lane >> 4) == 0) {
 #pragma unroll
-    for (int i = 0; i < TI; ++i) g.bpart[(size_t)blockIdx.z * g.N1 + n10 + w1 * (B1 / W1) + i * 16 + (lane & 15)] = cs[i][0];
+    for (int i = 0; i < TI; ++i) g.bpart[(size_t)bz * g.N1 + n10 + w1 * (B1 / W1) + i * 16 + (lane & 15)] = cs[i][0];
   }
-  float* P = g.part + (size_t)blockIdx.z * g.N1 * g.N2;
+  float* P = g.part + (size_t)bz * g.N1 * g.N2;
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int n1 = n10 + w1 * (B1 / W1) + i * 16 + (lane & 15);
@@ -2012,6 +2136,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   rps = ceil_div(rps, TN_BM) * TN_BM;
   splits = ceil_div(p->M, rps);
   a.rows_per_split = rps;
+  { static const int remap_ = [] { const char* e = getenv("UVC_TN_XCD"); return e ? atoi(e) : 1; }(); a.xcd_remap = remap_; }
   a.bpart = p->colsum_out ? a.part + (size_t)splits * p->N1 * p->N2 : nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (p->dtype == UVC_F32) {

@@ -172,11 +172,14 @@ const void* sh(const Ctx& c, int64_t off) { return (const char*)c.io->shadow + o
 // GEMM B operand [out,in]: float32 mode reads the master weights directly
 const void* wmat(const Ctx& c, int64_t poff, int64_t soff) { return c.d.dtype == UVC_F32 ? (const void*)(c.io->params + poff) : sh(c, soff); }
 
+// norm1 of the next block that runs, written by the kernel that produces its input rows (uvc_vit_io.fuse_next_ln)
+struct NextLn { const float* gamma; const float* beta; void* h; float* mean; float* rstd; };
 int nt(const Ctx& c, const void* A, int a_f32, const void* B, void* C, int c_f32, int M, int N, int K, int epi, const float* bias = nullptr,
        const float* R = nullptr, const float* R2 = nullptr, const void* aux = nullptr, const float* gate = nullptr, void* C2 = nullptr,
-       const float* alpha_ptr = nullptr, int lda = 0, int ldc = 0) {
+       const float* alpha_ptr = nullptr, int lda = 0, int ldc = 0, const NextLn* ln = nullptr) {
   uvc_gemm_nt_args a;
   memset(&a, 0, sizeof(a));
+  if (ln) { a.ln_gamma = ln->gamma; a.ln_beta = ln->beta; a.ln_out = ln->h; a.ln_mean = ln->mean; a.ln_rstd = ln->rstd; a.ln_eps = c.d.eps; }
   a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.R = R; a.R2 = R2; a.aux = aux; a.gate = gate; a.alpha_ptr = alpha_ptr;
   a.alpha = 1.0f; a.M = M; a.N = N; a.K = K; a.lda = lda ? lda : K; a.ldb = K; a.ldc = ldc ? ldc : N; a.ldr = a.ldc; a.ldaux = a.ldc;
   a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32; a.c_is_f32 = c_f32 || c.d.dtype == UVC_F32; a.epilogue = epi;
@@ -443,13 +446,16 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
   const int tl = tail_block(c);
   const TailBufs& t = w.tail;
   const int Rt = d.B * d.ntok;
+  bool h1_ready = false;                     // norm1 of the coming block already in its h1 (epilogue of the producer of its input)
+  auto next_running = [&](int l) { for (int j = l + 1; j < d.L; ++j) if (runs(j)) return j; return -1; };
   for (int l = 0; l < d.L; ++l) {
     if (!runs(l)) continue;
     const bool tail = l == tl;
     float* xout = tail ? t.xoutc : io->training ? next_in(l + 1) : (xin == w.blk[0].x ? w.xL : w.blk[0].x);
     const BlockBufs& b = w.blk[l];
     const int64_t* q = o.blk[l];
-    TRY(ln_fwd(c, xin, q[0], q[1], b.h1, b.mean1, b.rstd1, d.M, 1, d.D));
+    if (!h1_ready) TRY(ln_fwd(c, xin, q[0], q[1], b.h1, b.mean1, b.rstd1, d.M, 1, d.D));      // else: written by the previous block's MLP kernel
+    h1_ready = false;
     TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, d.qkv_bias ? UVC_EPI_BIAS : UVC_EPI_NONE, d.qkv_bias ? P + q[3] : nullptr));
     // From here on the last block works on its token rows only (rows = B * ntok, compact buffers): nothing else of it reaches the head
     const int rows = tail ? Rt : d.M;
@@ -465,14 +471,23 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     } else {
       TRY(attn(c, b, false, l));
     }
-    TRY(nt(c, tail ? t.oc : b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), x1, 1, rows, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xres));
     // Stage-2 compaction: pruned hidden units are skipped (compact weights gathered by the host, uvc_mlp_compact)
     const uvc_mlp_compact* mc = (io->mlp_compact && io->mlp_compact[l].width > 0 && io->mlp_compact[l].width < d.F) ? &io->mlp_compact[l] : nullptr;
     const int Fe = mc ? mc->width : d.F;
     const void* w1 = mc ? mc->w1 : wmat(c, q[8], c.soff.blk_w[l][2]);
     const void* w2 = mc ? mc->w2 : wmat(c, q[10], c.soff.blk_w[l][3]);
     const float* b1 = mc ? mc->b1 : P + q[9];
-    if (uvc_mlp_fused_supported(d.D, Fe, d.dtype) && (io->training ? io->fused_train_mlp != 0 : !io->gate_d)) {
+    const bool mlp_one_kernel = uvc_mlp_fused_supported(d.D, Fe, d.dtype) && (io->training ? io->fused_train_mlp != 0 : !io->gate_d);
+    // norm2 as a second output of attn.proj + residual (the MLP kernel, where it runs, normalises its rows itself)
+    // (not on the compact token rows of a `tail` block: B * ntok may be below the kernel's 16 rows, and whether a norm is fused must
+    // not depend on the batch -- the two forms round differently in the last bit)
+    const bool ln2_in_proj = !tail && !mlp_one_kernel && io->fuse_next_ln != 0 && uvc_gemm_nt_ln_supported(rows, d.D, d.D, d.dtype, UVC_EPI_BIAS_RESID);
+    {
+      const NextLn n2 = {P + q[6], P + q[7], h2, io->training ? mean2 : nullptr, io->training ? rstd2 : nullptr};
+      TRY(nt(c, tail ? t.oc : b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), x1, 1, rows, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xres, nullptr, nullptr, nullptr, nullptr,
+             nullptr, 0, 0, ln2_in_proj ? &n2 : nullptr));
+    }
+    if (mlp_one_kernel) {
       // LayerNorm + fc1 + GELU + fc2 + residual (+ gate mix) in one kernel, hidden activation in registers.  No-grad forwards
       // (teacher / eval) write nothing but the output.  The training form also stores what the backward reads -- LayerNorm2(x1), its
       // mean / rstd, GELU'(a), GELU(a) -- from the same registers; at 218 us against 187 us for the three kernels it replaces
@@ -485,20 +500,38 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
         m.h = h2; m.mean = mean2; m.rstd = rstd2; m.gp = ga; m.u = gu;
         if (io->gate_d) { m.x_prev = xres; m.gate = io->gate_d + 2 * l; }
       }
+      const int ln = tail ? -1 : next_running(l);
+      if (ln >= 0 && io->fuse_next_ln != 0) {      // norm1 of block ln on the rows this kernel holds (all M rows: `tail` blocks stop at their token rows)
+        m.next_gamma = P + o.blk[ln][0]; m.next_beta = P + o.blk[ln][1]; m.next_h = w.blk[ln].h1;
+        if (io->training) { m.next_mean = w.blk[ln].mean1; m.next_rstd = w.blk[ln].rstd1; }
+        h1_ready = true;
+      }
       TRY(uvc_mlp_fused_fwd(&m, c.st));
       xin = xout;
       continue;
     }
-    TRY(ln_fwd(c, x1, q[6], q[7], h2, mean2, rstd2, rows, 1, d.D));
+    if (!ln2_in_proj) TRY(ln_fwd(c, x1, q[6], q[7], h2, mean2, rstd2, rows, 1, d.D));
     if (io->training)
       // `ga` receives GELU'(pre-activation): that is all the backward needs of it (one multiply in the dgrad epilogue)
       TRY(nt(c, h2, 0, w1, ga, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_GRAD, b1, nullptr, nullptr, nullptr, nullptr, gu));
     else   // inference (teacher / eval): the pre-activation is not needed, write GELU(a) only
       TRY(nt(c, h2, 0, w1, gu, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_OUT, b1));
+    NextLn nl;
+    const NextLn* pnl = nullptr;
+    {
+      const int ln = tail ? -1 : next_running(l);
+      const int epi = io->gate_d ? UVC_EPI_BIAS_RESID_GATE : UVC_EPI_BIAS_RESID;
+      if (ln >= 0 && io->fuse_next_ln != 0 && uvc_gemm_nt_ln_supported(rows, d.D, Fe, d.dtype, epi)) {
+        nl.gamma = P + o.blk[ln][0]; nl.beta = P + o.blk[ln][1]; nl.h = w.blk[ln].h1;
+        nl.mean = io->training ? w.blk[ln].mean1 : nullptr; nl.rstd = io->training ? w.blk[ln].rstd1 : nullptr;
+        pnl = &nl;
+        h1_ready = true;
+      }
+    }
     if (io->gate_d)
-      TRY(nt(c, gu, 0, w2, xout, 1, rows, d.D, Fe, UVC_EPI_BIAS_RESID_GATE, P + q[11], x1, xres, nullptr, io->gate_d + 2 * l));
+      TRY(nt(c, gu, 0, w2, xout, 1, rows, d.D, Fe, UVC_EPI_BIAS_RESID_GATE, P + q[11], x1, xres, nullptr, io->gate_d + 2 * l, nullptr, nullptr, 0, 0, pnl));
     else
-      TRY(nt(c, gu, 0, w2, xout, 1, rows, d.D, Fe, UVC_EPI_BIAS_RESID, P + q[11], x1));
+      TRY(nt(c, gu, 0, w2, xout, 1, rows, d.D, Fe, UVC_EPI_BIAS_RESID, P + q[11], x1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, pnl));
     xin = xout;
   }
   if (io->training && tl < 0 && xin != w.xL) return uvc_set_error_msg(UVC_ERR_LAUNCH, "uvc_vit_forward: internal buffer chain broken");

@@ -53,7 +53,8 @@ class uvc_vit_io(C.Structure):
                 ("run_block", C.POINTER(C.c_int32)), ("patch_mask", C.c_void_p), ("d_patch_mask", C.c_void_p),
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
                 ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
-                ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("fused_train_mlp", C.c_int32), ("patches_in", C.c_void_p)]
+                ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("fused_train_mlp", C.c_int32), ("patches_in", C.c_void_p),
+                ("fuse_next_ln", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class uvc_mlp_compact(C.Structure):
@@ -65,6 +66,7 @@ class uvc_mlp_compact(C.Structure):
 # computes that block's tail on the token rows only (uvc_vit_io.full_tail = 0; identical outputs and gradients).  UVC_FULL_TAIL=1, or
 # model.full_tail = True, runs every row as the reference does (A/B measurements, tests).
 _FULL_TAIL_DEFAULT = os.environ.get("UVC_FULL_TAIL", "0") not in ("", "0")
+_FUSE_NEXT_LN_DEFAULT = os.environ.get("UVC_FUSE_NEXT_LN", "1") not in ("", "0")       # norm1 of block l+1 written by the kernel that produces its input rows
 _FUSED_TRAIN_MLP_DEFAULT = os.environ.get("UVC_FUSED_TRAIN_MLP", "0") not in ("", "0")     # training forward: one MLP kernel instead of three (slower: opt-in)
 
 
@@ -518,6 +520,7 @@ class DistilledVisionTransformer(nn.Module):
         io.head_keep = L.ptr(self._head_keep) if (self._head_keep is not None and not training) else None
         io.full_tail = int(getattr(self, "full_tail", _FULL_TAIL_DEFAULT))
         io.fused_train_mlp = int(getattr(self, "fused_train_mlp", _FUSED_TRAIN_MLP_DEFAULT))
+        io.fuse_next_ln = int(getattr(self, "fuse_next_ln", _FUSE_NEXT_LN_DEFAULT))
         return io
 
     def _ws_view(self, B, training, which):

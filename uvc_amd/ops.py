@@ -34,10 +34,13 @@ def _is_f32(t) -> int:
 
 
 def gemm_nt(A, B, C_, *, dtype, epilogue=EPI_NONE, bias=None, R=None, R2=None, aux=None, gate=None, C2=None, alpha=1.0,
-            alpha_ptr=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ldr=None, ldaux=None, force_generic=False):
-    """C[M,N] = epi(A[M,K] . B[N,K]^T)."""
-    _chk(A, B, C_, bias, R, R2, aux, gate, C2, alpha_ptr)
+            alpha_ptr=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ldr=None, ldaux=None, force_generic=False,
+            ln_gamma=None, ln_beta=None, ln_out=None, ln_mean=None, ln_rstd=None, ln_eps=1e-6):
+    """C[M,N] = epi(A[M,K] . B[N,K]^T).  ln_out (where uvc_gemm_nt_ln_supported): also LayerNorm(C rows; ln_gamma, ln_beta) in the
+    compute dtype, with ln_mean / ln_rstd."""
+    _chk(A, B, C_, bias, R, R2, aux, gate, C2, alpha_ptr, ln_gamma, ln_beta, ln_out, ln_mean, ln_rstd)
     a = L.uvc_gemm_nt_args()
+    a.ln_gamma, a.ln_beta, a.ln_out, a.ln_mean, a.ln_rstd, a.ln_eps = L.ptr(ln_gamma), L.ptr(ln_beta), L.ptr(ln_out), L.ptr(ln_mean), L.ptr(ln_rstd), ln_eps
     a.A, a.B, a.C, a.C2 = L.ptr(A), L.ptr(B), L.ptr(C_), L.ptr(C2)
     a.bias, a.R, a.R2, a.aux, a.gate, a.alpha_ptr = L.ptr(bias), L.ptr(R), L.ptr(R2), L.ptr(aux), L.ptr(gate), L.ptr(alpha_ptr)
     a.alpha = alpha
@@ -187,11 +190,15 @@ def gemm_nt_lnbwd(A, Wt, x, mean, rstd, gamma, dx, partial, dgamma, dbeta, *, ad
     L.check(L.lib().uvc_layernorm_bwd_reduce_batch(item, 1, a.D, beta_acc, L.cur_stream()), "uvc_layernorm_bwd_reduce_batch")
 
 
-def mlp_fused_fwd(x, gamma, beta, w1, b1, w2, b2, out, eps=1e-6, *, x_prev=None, gate=None, h=None, mean=None, rstd=None, gp=None, u=None):
+def mlp_fused_fwd(x, gamma, beta, w1, b1, w2, b2, out, eps=1e-6, *, x_prev=None, gate=None, h=None, mean=None, rstd=None, gp=None, u=None,
+                  next_gamma=None, next_beta=None, next_h=None, next_mean=None, next_rstd=None):
     """out = d1 * (x + fc2(GELU(fc1(LayerNorm(x))))) + d0 * x_prev for [M, 192] float32 rows; w1 [F,192] / w2 [192,F] bf16.
-    Training form: h / mean / rstd / gp / u receive LayerNorm(x), its statistics, GELU'(a) and GELU(a)."""
-    _chk(x, gamma, beta, w1, b1, w2, b2, out, x_prev, gate, h, mean, rstd, gp, u)
+    Training form: h / mean / rstd / gp / u receive LayerNorm(x), its statistics, GELU'(a) and GELU(a).
+    next_h (bf16 [M,192], optional): LayerNorm(out; next_gamma, next_beta) -- the next block's norm1 -- with its statistics in
+    next_mean / next_rstd when given."""
+    _chk(x, gamma, beta, w1, b1, w2, b2, out, x_prev, gate, h, mean, rstd, gp, u, next_gamma, next_beta, next_h, next_mean, next_rstd)
     a = L.uvc_mlp_args()
+    a.next_gamma, a.next_beta, a.next_h, a.next_mean, a.next_rstd = (L.ptr(t) for t in (next_gamma, next_beta, next_h, next_mean, next_rstd))
     a.x, a.gamma, a.beta, a.w1, a.b1, a.w2, a.b2, a.out = (L.ptr(t) for t in (x, gamma, beta, w1, b1, w2, b2, out))
     a.x_prev, a.gate, a.h, a.mean, a.rstd, a.gp, a.u = (L.ptr(t) for t in (x_prev, gate, h, mean, rstd, gp, u))
     a.M, a.D, a.F, a.eps = x.shape[0], x.shape[1], w1.shape[0], eps

@@ -10,6 +10,7 @@
 // Operands are swapped in the MFMA (a = B-fragment, b = A-fragment) so every lane ends up with 4
 // CONSECUTIVE output columns of one row -> 16-byte (fp32) / 8-byte (bf16) epilogue accesses.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/uvc_kernels.h"
 
@@ -821,7 +822,7 @@ template <int EPI, int KT, bool LN, int NST> __global__ void k_gemm_wsn16_dma(Nt
 template <int EPI, int KT, bool LN, int NST = 3>
 static int launch_wsn16_dma(const NtArgs& a, hipStream_t st) {
   constexpr int NA_ = (16 * (KT * 4 + 2) + 63) / 64, NI_ = NA_ + 13 + (EPI == UVC_EPI_BIAS_RESID_GATE ? 13 : 0);
-  const int sh = NST * NI_ * 1024 + (LN ? 2 * 16 * 12 * 8 + 2 * 192 * 4 : 0);
+  const int sh = NST * NI_ * 1024 + (LN ? 2 * 16 * 12 * 8 + 3 * 192 * 4 : 0);
   static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn16_dma<EPI, KT, LN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
   if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__);
   const int ntiles = ceil_div(a.M, 16);
@@ -1402,7 +1403,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   constexpr int STAGE = NI * 1024;
   constexpr int NPW = (NI + NWV - 1) / NWV;                   // DMA instructions per wave and stage (surplus ones repeat the wave's first)
   // LN: behind the ring, the row-statistics table [2][16 rows][12 waves][2] and gamma / beta of the LayerNorm that follows
-  constexpr int LN_BYTES = LN ? 2 * 16 * NWV * 8 + 2 * D * 4 : 0;
+  constexpr int LN_BYTES = LN ? 2 * 16 * NWV * 8 + 3 * D * 4 : 0;      // + gamma, beta, bias
   static_assert(NST >= 3 && NPW <= 5 && NST * STAGE + LN_BYTES <= 160 * 1024, "ring does not fit");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, gq = lane >> 4, li = lane & 15;
@@ -1415,7 +1416,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   float* const sRed = reinterpret_cast<float*>(smem + NST * STAGE);
   float* const sGB = sRed + 2 * 16 * NWV * 2;
   if (LN) {
-    if (tid < D) { sGB[tid] = g.ln_gamma[tid]; sGB[D + tid] = g.ln_beta[tid]; }      // before the first DMA is issued (see k_gemm_wsn_lnbwd_dma)
+    if (tid < D) { sGB[tid] = g.ln_gamma[tid]; sGB[D + tid] = g.ln_beta[tid]; sGB[2 * D + tid] = g.bias[tid]; }      // before the first DMA is issued (see k_gemm_wsn_lnbwd_dma)
   }
   const unsigned gaddr = lds_addr(sGB) + (unsigned)n * 4u;
   const unsigned redr = lds_addr(sRed) + (unsigned)(li * NWV * 8);
@@ -1427,7 +1428,8 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   if (g.alpha_ptr) alpha *= *g.alpha_ptr;
   float d0 = 0.f, d1 = 1.f;
   if (GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
-  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (!LN) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);      // LN: re-read from LDS per tile (four VGPRs less across the MFMA chain)
 
   const char* rb[NPW]; unsigned rstride[NPW], rdst[NPW], loff[NPW];
 #pragma unroll
@@ -1466,12 +1468,62 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   wait_vm<(NST - 2) * NPW>();
   __builtin_amdgcn_s_barrier();
   int st = 0, par = 0;
+  // LN: the normalisation of tile t is DEFERRED into iteration t + 1.  Its operands (the 12 pairs of the statistics table, gamma, beta)
+  // are requested in three small batches between the first k-step groups of tile t + 1 and consumed under its MFMAs (inside one wave the
+  // VALU work fills the matrix pipe's issue gaps); as a chain of LDS round trips behind the barrier it cost 20 us of 100.
+  bool have_prev = false;
+  float po[4] = {0.f, 0.f, 0.f, 0.f};
+  int prow0 = 0;
+  float lm2 = 0.f, ls1 = 0.f, ls2 = 0.f, lpv = 0.f;
+  u32x4 tq0, tq1, lgr, lbr;
+  auto ln_issue = [&](auto offv) {
+    constexpr int OFF = decltype(offv)::value;
+    const unsigned ra = redr + (unsigned)((par ^ 1) * 16 * NWV * 8);
+    tq0 = ds_read128<OFF>(ra); tq1 = ds_read128<OFF + 16>(ra);
+  };
+  auto ln_first = [&]() {
+    asm volatile("" : "+v"(tq0), "+v"(tq1));
+    const f32x4 a0 = __builtin_bit_cast(f32x4, tq0), a1 = __builtin_bit_cast(f32x4, tq1);
+    lpv = a0[0];
+    float dd;
+    lm2 = a0[1]; dd = a0[2] - lpv; ls1 = dd; ls2 = dd * dd; lm2 += a0[3];
+    dd = a1[0] - lpv; ls1 += dd; ls2 += dd * dd; lm2 += a1[1]; dd = a1[2] - lpv; ls1 += dd; ls2 += dd * dd; lm2 += a1[3];
+    asm volatile("" : "+v"(lm2), "+v"(ls1), "+v"(ls2), "+v"(lpv));
+  };
+  auto ln_acc = [&]() {
+    asm volatile("" : "+v"(tq0), "+v"(tq1));
+    const f32x4 a0 = __builtin_bit_cast(f32x4, tq0), a1 = __builtin_bit_cast(f32x4, tq1);
+    float dd;
+    dd = a0[0] - lpv; ls1 += dd; ls2 += dd * dd; lm2 += a0[1]; dd = a0[2] - lpv; ls1 += dd; ls2 += dd * dd; lm2 += a0[3];
+    dd = a1[0] - lpv; ls1 += dd; ls2 += dd * dd; lm2 += a1[1]; dd = a1[2] - lpv; ls1 += dd; ls2 += dd * dd; lm2 += a1[3];
+    asm volatile("" : "+v"(lm2), "+v"(ls1), "+v"(ls2));
+  };
+  // mean = pivot + s1/12;  sum (m_w - mean)^2 = s2 - 12 (s1/12)^2;  var = (sum M2_w + 16 * that) / D  (Chan et al.; see the epilogue)
+  auto ln_finish = [&]() {
+    asm volatile("" : "+v"(lgr), "+v"(lbr));
+    const float dm = ls1 * (1.0f / 12.0f);
+    const float mean = lpv + dm;
+    const float dv = ls2 - 12.0f * dm * dm;
+    const float rstd = rsqrtf((lm2 + 16.0f * dv) * (1.0f / (float)D) + g.ln_eps);
+    const f32x4 gam = __builtin_bit_cast(f32x4, lgr), bet = __builtin_bit_cast(f32x4, lbr);
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (po[e] - mean) * rstd * gam[e] + bet[e];
+    u32x2 q; q[0] = pack_bf16x2(y[0], y[1]); q[1] = pack_bf16x2(y[2], y[3]);
+    const size_t trow = (size_t)prow0;
+    *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(reinterpret_cast<T*>(g.ln_out) + trow * D) + (unsigned)((li * D + n) * 2)) = q;
+    if (g.ln_mean && w == 0 && gq == 0) {
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(g.ln_mean + trow) + (unsigned)(li * 4)) = mean;
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(g.ln_rstd + trow) + (unsigned)(li * 4)) = rstd;
+    }
+  };
   for (; tile < ntiles; tile += gridDim.x) {
     issue(tile + (NST - 1) * gridDim.x, st == 0 ? NST - 1 : st - 1);
     const unsigned sb = s0 + (unsigned)(st * STAGE);
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
     u32x4 fa[2], fb[2];
     const unsigned fr = sb + fragoff;
+    if (LN && have_prev) ln_issue(std::integral_constant<int, 0>{});
 #define RD2(dst, ks0) dst[0] = ds_read128<(ks0) * 64>(fr); dst[1] = ds_read128<(ks0) * 64 + 64>(fr);
 #define GROUP(gk, cur, nxt) if ((gk) < KT / 2) { \
       if ((gk) + 1 < KT / 2) { RD2(nxt, ((gk) + 1) * 2) wait_lgkm<2>(); } else wait_lgkm<0>(); \
@@ -1480,7 +1532,19 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
       c0 = MM::mma(bf[(gk) * 2 + 1], __builtin_bit_cast(typename MM::Frag, cur[1]), c0); }
     static_assert(KT % 2 == 0 && KT <= 24, "pairs of k-steps");
     RD2(fa, 0)
-    GROUP(0, fa, fb) GROUP(1, fb, fa) GROUP(2, fa, fb) GROUP(3, fb, fa) GROUP(4, fa, fb) GROUP(5, fb, fa)
+    GROUP(0, fa, fb)                       // its wait (two youngest reads may be out) covers the older table reads
+    if (LN && have_prev) { ln_first(); ln_issue(std::integral_constant<int, 32>{}); }
+    GROUP(1, fb, fa)
+    if (LN && have_prev) { ln_acc(); ln_issue(std::integral_constant<int, 64>{}); }
+    GROUP(2, fa, fb)
+    if (LN && have_prev) {
+      ln_acc();
+      if constexpr (KT / 2 > 3) { lgr = ds_read128<0>(gaddr); lbr = ds_read128<D * 4>(gaddr); }      // gamma, beta: consumed one group on (registers)
+      else { lgr = ds_read128<0>(gaddr); lbr = ds_read128<D * 4>(gaddr); wait_lgkm<0>(); ln_finish(); }
+    }
+    GROUP(3, fb, fa)
+    if (LN && have_prev && KT / 2 > 3) ln_finish();
+    GROUP(4, fa, fb) GROUP(5, fb, fa)
     GROUP(6, fa, fb) GROUP(7, fb, fa) GROUP(8, fa, fb) GROUP(9, fb, fa) GROUP(10, fa, fb) GROUP(11, fb, fa)
 #undef GROUP
 #undef RD2
@@ -1504,13 +1568,14 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
       // The output row is spread over the 12 waves (16 columns each).  Every wave leaves (mean, centred sum of squares) of its 16
       // columns in the table BEFORE the tile's one barrier and picks up the 12 pairs after it; they combine exactly (Chan et al.):
       // mean = sum m_w / 12, M2 = sum M2_w + 16 sum (m_w - mean)^2 -- the two-pass variance of k_ln_fwd_v without a second exchange.
+      u32x4 bq = ds_read128<2 * D * 4>(gaddr);
       wait_lgkm<0>();
-      asm volatile("" : "+v"(rr), "+v"(rr2));
-      const f32x4 r = __builtin_bit_cast(f32x4, rr), r2 = __builtin_bit_cast(f32x4, rr2);
+      asm volatile("" : "+v"(rr), "+v"(rr2), "+v"(bq));
+      const f32x4 r = __builtin_bit_cast(f32x4, rr), r2 = __builtin_bit_cast(f32x4, rr2), bv = __builtin_bit_cast(f32x4, bq);
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = epi_scale_bias(c0[e], alpha, bias4[e]);
+        o[e] = epi_scale_bias(c0[e], alpha, bv[e]);
         o[e] += r[e];
         if (GATE) o[e] = epi_gate_mix(o[e], r2[e], d0, d1);
       }
@@ -1523,54 +1588,26 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
         qw = sum_rows4(qw);
         if (gq == 0) ds_write64_a(redr + (unsigned)(par * 16 * NWV * 8 + w * 8), f32x2{mw, qw});
       }
+      // the output rows leave now; their normalisation follows inside the next iteration (or behind the loop)
+      prow0 = min(tile * 16, g.M - 16);
+      *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(C + (size_t)prow0 * g.ldc) + (unsigned)((li * g.ldc + n) * 4)) = f32x4{o[0], o[1], o[2], o[3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) po[e] = o[e];
+      have_prev = true;
       wait_vm<(NST - 2) * NPW>();                                 // own part of the next stage has landed
       wait_lgkm<0>();
       __builtin_amdgcn_s_barrier();
-      // the 12 (m_w, M2_w) pairs of this row in wave order, two 16-byte reads at a time (8 VGPRs in flight: W^T takes 96 of the 168), ONE
-      // pass: with the first wave's mean as pivot p,  sum (m_w - mean)^2 = sum (m_w - p)^2 - 12 (mean - p)^2  loses nothing to a
-      // large common offset of the row (the pivot removes it), and the table is read once
-      const unsigned ra = redr + (unsigned)(par * 16 * NWV * 8);
-      float m2 = 0.f, s1 = 0.f, s2 = 0.f, pv;
-      u32x4 gr, br;
-      {
-        u32x4 t0 = ds_read128<0>(ra), t1 = ds_read128<16>(ra);
-        wait_lgkm<0>(); asm volatile("" : "+v"(t0), "+v"(t1));
-        const f32x4 a0 = __builtin_bit_cast(f32x4, t0), a1 = __builtin_bit_cast(f32x4, t1);
-        pv = a0[0];
-        float dd;
-        m2 += a0[1]; dd = a0[2] - pv; s1 += dd; s2 += dd * dd; m2 += a0[3];
-        dd = a1[0] - pv; s1 += dd; s2 += dd * dd; m2 += a1[1]; dd = a1[2] - pv; s1 += dd; s2 += dd * dd; m2 += a1[3];
-        asm volatile("" : "+v"(m2), "+v"(s1), "+v"(s2), "+v"(pv)); __builtin_amdgcn_sched_barrier(0);
-      }
-#define LN_ACC(OFF, EXTRA) { u32x4 t0 = ds_read128<OFF>(ra), t1 = ds_read128<OFF + 16>(ra); EXTRA wait_lgkm<0>(); asm volatile("" : "+v"(t0), "+v"(t1)); \
-        const f32x4 a0 = __builtin_bit_cast(f32x4, t0), a1 = __builtin_bit_cast(f32x4, t1); float dd; \
-        dd = a0[0] - pv; s1 += dd; s2 += dd * dd; m2 += a0[1]; dd = a0[2] - pv; s1 += dd; s2 += dd * dd; m2 += a0[3]; \
-        dd = a1[0] - pv; s1 += dd; s2 += dd * dd; m2 += a1[1]; dd = a1[2] - pv; s1 += dd; s2 += dd * dd; m2 += a1[3]; \
-        asm volatile("" : "+v"(m2), "+v"(s1), "+v"(s2)); __builtin_amdgcn_sched_barrier(0); }
-      LN_ACC(32, )
-      LN_ACC(64, gr = ds_read128<0>(gaddr); br = ds_read128<D * 4>(gaddr);)
-#undef LN_ACC
-      asm volatile("" : "+v"(gr), "+v"(br));
-      const float dm = s1 * (1.0f / 12.0f);                       // mean - pivot
-      const float mean = pv + dm;
-      const float dv = s2 - 12.0f * dm * dm;
-      const float rstd = rsqrtf((m2 + 16.0f * dv) * (1.0f / (float)D) + g.ln_eps);
-      const f32x4 gam = __builtin_bit_cast(f32x4, gr), bet = __builtin_bit_cast(f32x4, br);
-      // stores as (scalar tile base) + (32-bit lane offset): one VGPR of address each instead of hoisted 64-bit lane pointers
-      const size_t trow = (size_t)min(tile * 16, g.M - 16);
-      *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(C + trow * g.ldc) + (unsigned)((li * g.ldc + n) * 4)) = f32x4{o[0], o[1], o[2], o[3]};
-      float y[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) y[e] = (o[e] - mean) * rstd * gam[e] + bet[e];
-      u32x2 q; q[0] = pack_bf16x2(y[0], y[1]); q[1] = pack_bf16x2(y[2], y[3]);
-      *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(reinterpret_cast<T*>(g.ln_out) + trow * D) + (unsigned)((li * D + n) * 2)) = q;
-      if (g.ln_mean && w == 0 && gq == 0) {
-        *reinterpret_cast<float*>(reinterpret_cast<char*>(g.ln_mean + trow) + (unsigned)(li * 4)) = mean;
-        *reinterpret_cast<float*>(reinterpret_cast<char*>(g.ln_rstd + trow) + (unsigned)(li * 4)) = rstd;
-      }
       par ^= 1;
     }
     st = st == NST - 1 ? 0 : st + 1;
+  }
+  if (LN && have_prev) {                                         // the last tile of this workgroup
+    ln_issue(std::integral_constant<int, 0>{});
+    wait_lgkm<0>(); ln_first();
+    ln_issue(std::integral_constant<int, 32>{});
+    wait_lgkm<0>(); ln_acc();
+    ln_issue(std::integral_constant<int, 64>{}); lgr = ds_read128<0>(gaddr); lbr = ds_read128<D * 4>(gaddr);
+    wait_lgkm<0>(); ln_acc(); ln_finish();
   }
   wait_vm<0>();
 }

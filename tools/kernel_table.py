@@ -57,10 +57,11 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
     y = torch.empty(M, D, device=dev, dtype=bf)
     m_, r_ = torch.empty(M, device=dev), torch.empty(M, device=dev)
     # DeiT-Tiny width (uvc_vit_io.fuse_next_ln): norm1 of blocks 1 .. L-1 is written by the kernel that produces their input rows
-    # (fc2 + residual + gate mix of the student, the fused MLP of the teacher), so only block 0's norm1 is a pass of its own
+    # (fc2 + residual + gate mix of the student, the fused MLP of the teacher) and the student's norm2 by attn.proj + residual, so only
+    # block 0's norm1 is a pass of its own (the final norms and the last block's token-row norm2 run on B rows: not listed)
     fuse_ln = tiny
     n_ln1 = 1 if fuse_ln else L
-    add("ln_fwd", "k_ln_fwd_v", (1 + T) * n_ln1 + Lf, 3 * u, 0, lambda: ops.layernorm_fwd(x32, gam, bet, y, m_, r_, M, D, dt))
+    add("ln_fwd", "k_ln_fwd_v", (1 + T) * n_ln1 + (0 if fuse_ln else Lf), 3 * u, 0, lambda: ops.layernorm_fwd(x32, gam, bet, y, m_, r_, M, D, dt))
     qkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
     add("qkv", "k_gemm_ws<unsigned short, unsigned short, 1" if tiny else "k_gemm", (1 + T) * L, 4 * u, 2.0 * M * D * 3 * D,
         lambda: ops.gemm_nt(xb, Wqkv, qkv, dtype=dt, epilogue=ops.EPI_BIAS, bias=b3))
@@ -75,8 +76,13 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
         add("attn_tok_fwd (last block)", "k_attn_tok_fwd", 1 + T, 2 * u, 0, lambda: ops.attention_tok_fwd(qkv3, oc, B, N, H, 1, dt))
         add("attn_tok_bwd (last block)", "k_attn_tok_bwd", 1, 5 * u, 0, lambda: ops.attention_tok_bwd(qkv3, oc, doc, dq_t, B, N, H, 1, dt))
     o32 = torch.empty(M, D, device=dev)
-    add("proj+resid", "k_gemm_ws<unsigned short, float, 3" if tiny else "k_gemm", (1 + T) * Lf, 5 * u, 2.0 * M * D * D,
-        lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=x32))
+    # student at DeiT-Tiny width: norm2 leaves with attn.proj's rows (the teacher's fused MLP normalises its rows itself)
+    if fuse_ln:
+        add("proj+resid+norm2", "k_gemm_wsn16_dma<3, 6", Lf, 6 * u, 2.0 * M * D * D,
+            lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=x32, ln_gamma=gam, ln_beta=bet, ln_out=y, ln_mean=m_, ln_rstd=r_))
+    if not fuse_ln or T:
+        add("proj+resid", "k_gemm_ws<unsigned short, float, 3" if tiny else "k_gemm", (T if fuse_ln else 1 + T) * Lf, 5 * u, 2.0 * M * D * D,
+            lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=x32))
     aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
     add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
         lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu))

@@ -638,7 +638,8 @@ def test_fused_mlp_writes_the_next_blocks_norm1(M, gated, train):
 
 @pytest.mark.parametrize("M,gated,stats,K", [(4096, False, True, 768), (4096 + 16 * 37, True, True, 768), (100864, True, False, 768),
                                              (4096 + 16 * 5, False, True, 192), (100864, False, True, 192), (4096, False, False, 192),
-                                             (1576, True, True, 768), (197, False, True, 192), (16, False, True, 768), (8 * 197 + 3, False, True, 192)])
+                                             (1576, True, True, 768), (197, False, True, 192), (16, False, True, 768), (8 * 197 + 3, False, True, 192),
+                                             (4096 + 21, False, True, 512), (4096, True, True, 256), (1576, False, False, 256)])
 def test_fc2_residual_epilogue_writes_the_next_blocks_norm1(M, gated, stats, K):
     """uvc_gemm_nt with ln_out (fc2 + bias + residual [+ gate mix] at K = 768 -> N = 192 writing the next block's norm1; attn.proj + bias +
     residual at K = 192 writing norm2, same kernel on a seven-stage ring): C must not change by a bit, ln_out =

@@ -213,8 +213,7 @@ __device__ __forceinline__ void attn_key_block(const char* sK, const char* sV, c
     mx = fmaxf(mx, fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
     st[t] = c;
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  mx = max_rows4(mx);
   const float m_new = fmaxf(m_run, mx);
   // p = exp(scale*(s - max)) = exp2(s*c2 - max*c2): one FMA + one v_exp_f32 per score (scale > 0)
   const float mb = m_new * c2;
@@ -223,8 +222,7 @@ __device__ __forceinline__ void attn_key_block(const char* sK, const char* sV, c
   for (int t = 0; t < NTB; ++t)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const float p = __builtin_amdgcn_exp2f(st[t][e] * c2 - mb); st[t][e] = p; sum += p; }
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
+  sum = sum_rows4(sum);
   if (T0 > 0) {                                     // rescale what the earlier blocks accumulated
     const float alpha = __builtin_amdgcn_exp2f(m_run * c2 - mb);
     l_run = l_run * alpha + sum;
@@ -379,8 +377,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_dq(AttnArgs a) {
       dof[ks] = row_frag_global<T>(dob, ldo, q, a.N, ks * 4 + g);
       dl += frag_dot<T>(dof[ks], row_frag_global<T>(ob, ldo, q, a.N, ks * 4 + g));
     }
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);
+    dl = sum_rows4(dl);
     const float c2 = a.scale * 1.44269504088896340736f;
     const float lse2 = (q < a.N ? a.lse[((size_t)b * a.H + h) * a.N + q] : 0.f) * 1.44269504088896340736f;
     if (q < a.N && g == 0) a.delta[((size_t)b * a.H + h) * a.N + q] = dl;

@@ -74,6 +74,14 @@ __device__ __forceinline__ float sum_rows4(float v) {
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+__device__ __forceinline__ float max_rows4(float v) {           // max over lanes l, l^16, l^32, l^48, in every lane
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned c = __float_as_uint(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+  const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+
 // exact-erf GELU and its derivative (nn.GELU default, model_distilled.py:108,118) -- float32 parity mode
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

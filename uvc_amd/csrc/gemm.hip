@@ -836,15 +836,20 @@ static bool wsn16_dma_ok(const NtArgs& a) {
 }
 template <typename TC, int KT>
 static int launch_wsn16_kt(const NtArgs& a, int epi, hipStream_t st) {
-  if constexpr (sizeof(TC) == 4 && KT == 24) {       // fc2 of DeiT-Tiny: LDS-DMA ring (UVC_FC2_DMA=0 keeps the register-staged kernel)
+  if constexpr (sizeof(TC) == 4 && (KT == 24 || KT == 16 || KT == 8)) {
+    // fc2 of DeiT-Tiny on the LDS-DMA ring (UVC_FC2_DMA=0 keeps the register-staged kernel); with ln_out also the compacted Stage-2
+    // widths (K = 512 / 256: more stages of the smaller images fit)
     static const bool use_dma = [] { const char* v = getenv("UVC_FC2_DMA"); return v ? atoi(v) != 0 : true; }();
     const bool ok = (use_dma || a.ln_out) && wsn16_dma_ok(a) && (a.ln_out || a.M % 16 == 0);
+    constexpr int NST_ = KT == 8 ? 4 : 3;
     if (ok && a.ln_out) {
-      if (epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, true>(a, st);
-      if (epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, true>(a, st);
+      if (epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, true, NST_>(a, st);
+      if (epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, true, NST_>(a, st);
     }
-    if (ok && epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, false>(a, st);
-    if (ok && epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, false>(a, st);
+    if constexpr (KT == 24) {
+      if (ok && epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, false>(a, st);
+      if (ok && epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, false>(a, st);
+    }
   }
   if (a.ln_out) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: ln_out is not available for this problem (uvc_gemm_nt_ln_supported)");
   const int ntiles = ceil_div(a.M, 16);
@@ -911,7 +916,7 @@ static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
 
 extern "C" int uvc_gemm_nt_ln_supported(int32_t M, int32_t N, int32_t K, int32_t dtype, int32_t epilogue) {
   if (dtype != UVC_BF16 || N != 192 || M < 16) return 0;      // any row count from 16 up: whether norm is fused must not depend on the batch
-  return (K == 768 && (epilogue == UVC_EPI_BIAS_RESID || epilogue == UVC_EPI_BIAS_RESID_GATE)) || (K == 192 && epilogue == UVC_EPI_BIAS_RESID);
+  return ((K == 768 || K == 512 || K == 256) && (epilogue == UVC_EPI_BIAS_RESID || epilogue == UVC_EPI_BIAS_RESID_GATE)) || (K == 192 && epilogue == UVC_EPI_BIAS_RESID);
 }
 
 extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {

@@ -81,7 +81,7 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
         add("proj+resid+norm2", "k_gemm_wsn16_dma<3, 6", Lf, 6 * u, 2.0 * M * D * D,
             lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=x32, ln_gamma=gam, ln_beta=bet, ln_out=y, ln_mean=m_, ln_rstd=r_))
     if not fuse_ln or T:
-        add("proj+resid", "k_gemm_ws<unsigned short, float, 3" if tiny else "k_gemm", (T if fuse_ln else 1 + T) * Lf, 5 * u, 2.0 * M * D * D,
+        add("proj+resid", "k_gemm_wsn16_dma<3, 6, false" if tiny else "k_gemm", (T if fuse_ln else 1 + T) * Lf, 5 * u, 2.0 * M * D * D,
             lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=x32))
     aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
     add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,

@@ -21,8 +21,8 @@ NAMES = {
     "ln_fwd": ["k_ln_fwd_v"],
     "qkv": ["k_gemm_ws<unsigned short, unsigned short, 1"],
     "attn_fwd": ["k_attn_fwd"],
-    "proj+resid": ["k_gemm_ws<unsigned short, float, 3"],
-    "proj+resid+norm2": ["k_gemm_wsn16_dma<3, 6"],
+    "proj+resid": ["k_gemm_wsn16_dma<3, 6, false"],
+    "proj+resid+norm2": ["k_gemm_wsn16_dma<3, 6, true"],
     "fc1+gelu,gelu'": ["k_gemm_ws<unsigned short, unsigned short, 7"],
     "fc2+resid+gate+norm1": ["k_gemm_wsn16_dma<4"],
     "teacher mlp_fused+norm1": ["k_mlp_fused"],

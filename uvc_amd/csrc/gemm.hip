@@ -956,6 +956,13 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
     return launch_nt_epi<float, float, float>(a, e, st);
   }
   if (p->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dtype must be UVC_F32 or UVC_BF16");
+  {
+    // attn.proj + residual (K = N = 192) without ln_out: the same seven-stage ring (same k-ordered chain and epilogue: same bits)
+    static const bool proj_dma = [] { const char* v = getenv("UVC_PROJ_DMA"); return v ? atoi(v) != 0 : true; }();
+    if (proj_dma && !p->force_generic && !p->a_is_f32 && p->c_is_f32 && e == UVC_EPI_BIAS_RESID && p->K == 192 && p->N == 192 && a.ldb == 192 &&
+        p->M >= 4096 && p->M % 16 == 0 && p->alpha == 1.0f && !p->alpha_ptr && wsn16_dma_ok(a))
+      return launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, false, 7>(a, st);
+  }
   const bool ws = !p->force_generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
   if (!p->force_generic && ws384_ok(a, e, p->c_is_f32 ? 4 : 8, p->a_is_f32 != 0))
     return p->c_is_f32 ? launch_ws384<float>(a, e, st) : launch_ws384<bf16_t>(a, e, st);

@@ -181,7 +181,11 @@ def kernel_table(args):
             "traffic_source": (f"{tr['source']} @ {tr['commit']}" if tr else None), "algorithmic_bytes": top["bytes"],
             "launch_us": top["us"], "us_per_step": top["us_per_step"], "mfma_tflops": top["tflops"],
             "selection": "largest stand-alone launch time x launches per step among the step's kernels (tools/kernel_table.py)"}
-    keep = ("key", "calls", "us", "us_per_step", "bytes", "gbs", "tflops", "bound", "frac")
+    for r in rows:       # against what HBM delivers for the kernel's read : write mix beyond the Infinity Cache (profiles/r2h_hbm_mix_probe.txt)
+        r["frac_of_mix_ceiling"] = round(r["gbs"] / r["hbm_mix_ceiling_gbs"], 4) if r.get("hbm_mix_ceiling_gbs") and r["bound"] == "hbm" else None
+    roof["hbm_mix_ceiling"] = top.get("hbm_mix_ceiling_gbs")
+    roof["frac_of_mix_ceiling"] = top.get("frac_of_mix_ceiling")
+    keep = ("key", "calls", "us", "us_per_step", "bytes", "gbs", "tflops", "bound", "frac", "write_share", "hbm_mix_ceiling_gbs", "frac_of_mix_ceiling")
     return roof, [{k: r[k] for k in keep} for r in rows[:10]], round(sum(r["us_per_step"] for r in rows) / 1e3, 2)
 
 

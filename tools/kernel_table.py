@@ -35,8 +35,15 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
     tiny = D == 192
     rows = []
 
+    # share of the algorithmic bytes that are WRITES, by key prefix: what HBM delivers depends on the mix (hbm_ceiling_gbs below)
+    WFRAC = {"ln_fwd": 1 / 3, "qkv": 0.75, "attn_fwd": 0.25, "attn_tok_fwd": 0.0, "attn_tok_bwd": 0.6, "proj+resid+norm2": 0.5, "proj+resid": 0.4,
+             "fc1": 8 / 9, "fc2+resid+gate+norm1": 3 / 11, "fc2+resid+gate": 0.2, "teacher mlp_fused+norm1": 0.6, "teacher mlp_fused": 0.5,
+             "dfc2": 4 / 9, "dfc1+ln2_bwd": 1 / 8, "dqkv+ln1_bwd": 1 / 8, "dfc1": 0.2, "dqkv": 0.25, "ln_bwd": 0.2, "dproj": 0.5, "attn_bwd": 0.25,
+             "dW": 0.15, "clip+adamw": 0.45}
+
     def add(key, rocprof, calls, nbytes, flops, fn):
-        rows.append(dict(key=key, rocprof=rocprof, calls=calls, bytes=int(nbytes), flops=float(flops), fn=fn))
+        wf = next((v for k, v in WFRAC.items() if key.startswith(k)), None)
+        rows.append(dict(key=key, rocprof=rocprof, calls=calls, bytes=int(nbytes), flops=float(flops), fn=fn, wfrac=wf))
 
     g = torch.Generator(device=dev).manual_seed(1)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
@@ -153,13 +160,28 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
+# What HBM delivers by read : write mix on buffers beyond the Infinity Cache (tools/probe/hbm_mix_probe.hip, profiles/r2h_hbm_mix_probe.txt:
+# flat 16-byte streams): write share of the bytes -> GB/s, linear in between
+HBM_MIX_GBS = [(0.0, 5700.0), (0.2, 4850.0), (0.5, 5300.0), (0.8, 5050.0), (1.0, 4200.0)]
+
+
+def hbm_ceiling_gbs(wfrac):
+    if wfrac is None:
+        return None
+    for (x0, y0), (x1, y1) in zip(HBM_MIX_GBS, HBM_MIX_GBS[1:]):
+        if wfrac <= x1:
+            return round(y0 + (y1 - y0) * (wfrac - x0) / (x1 - x0), 0)
+    return HBM_MIX_GBS[-1][1]
+
+
 def measure(rows, iters=20):
     """HIP-event average launch time of every entry on the current stream (back-to-back launches)."""
     out = []
     for r in rows:
         ms = timeit(r["fn"], iters)
         out.append(dict(key=r["key"], rocprof=r["rocprof"], calls=r["calls"], us=round(ms * 1e3, 2), us_per_step=round(ms * 1e3 * r["calls"], 1),
-                        bytes=r["bytes"], gbs=round(r["bytes"] / ms / 1e6, 1), tflops=round(r["flops"] / ms / 1e9, 1)))
+                        bytes=r["bytes"], gbs=round(r["bytes"] / ms / 1e6, 1), tflops=round(r["flops"] / ms / 1e9, 1),
+                        write_share=None if r.get("wfrac") is None else round(r["wfrac"], 3), hbm_mix_ceiling_gbs=hbm_ceiling_gbs(r.get("wfrac"))))
     return out
 
 

@@ -244,10 +244,17 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    # One rank per GPU over RCCL ("nccl") is the contract.  UVC_BENCH_BACKEND=gloo with UVC_BENCH_SHARE_DEVICE=1 puts every rank on
+    # device 0 over gloo (RCCL refuses two ranks on one device): no scaling number, but the multi-rank branches of this file -- bucketed
+    # all-reduce overlapped with the backward, MAX over ranks, ranks_seen, exposed_allreduce_ms_per_step -- run on a one-GPU box
+    # (tests/test_ddp_gpu.py::test_bench_two_ranks_on_one_device).
+    backend = os.environ.get("UVC_BENCH_BACKEND", "nccl")
+    if os.environ.get("UVC_BENCH_SHARE_DEVICE", "0") not in ("", "0"):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     torch.manual_seed(730)
     if args.stage == 2:
         from uvc_amd.post_train import Stage2Trainer, default_args
@@ -315,7 +322,7 @@ def main():
         line = {"metric": metric, "value": round(imgs, 1), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                 "ms_per_step_device": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3)},
-                "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                 "config": {"workload": (f"{args.model_type} Stage-1 UVC-train step, budget 0.5, per-GPU batch {args.batch}, "

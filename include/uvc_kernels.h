@@ -48,7 +48,9 @@ typedef struct uvc_gemm_nt_args {
   float alpha;
   int32_t M, N, K, lda, ldb, ldc, ldr, ldaux;
   int32_t dtype, a_is_f32, c_is_f32, epilogue;
-  int32_t force_generic;  /* tests/tuning: 1 = skip the weights-stationary streaming kernel */
+  int32_t force_generic;  /* tests/tuning: 0 = pick the kernel by shape; 1 = the generic LDS-tiled kernel; 2 = the streaming kernels in their
+                             register-staged forms (no LDS-DMA ring).  Every choice computes the same bits (one k-ordered accumulation chain,
+                             the same epilogue arithmetic) */
   /* optional second output of the residual epilogues where uvc_gemm_nt_ln_supported(): ln_out[M,N] (T) = LayerNorm(C rows; ln_gamma,
    * ln_beta, ln_eps) -- norm1 of the next block on the rows fc2 + residual (+ gate mix) just produced (model_distilled.py:241-244) --
    * and its float32 statistics ln_mean / ln_rstd [M] (both or neither).  Needs alpha == 1, contiguous A / R (lda == K, ldr == N). */
@@ -161,6 +163,8 @@ typedef struct uvc_gemm_lnbwd_args {
   const void* add1; const float* a1; const void* add2; const float* a2;       /* optional bf16 addends, device scalars (NULL = 1) */
   void* dx; float* partial;
   int32_t M, D, K, dtype;
+  int32_t variant;      /* tests/tuning: 0 = LDS-DMA ring where the shape allows, 1 = the register-staged kernel */
+  int32_t reserved;
 } uvc_gemm_lnbwd_args;
 int uvc_gemm_lnbwd_supported(int32_t M, int32_t D, int32_t K, int32_t dtype);
 int uvc_gemm_lnbwd_nblocks(int32_t M);

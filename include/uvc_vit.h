@@ -121,7 +121,10 @@ typedef struct uvc_vit_io {
   int32_t fuse_next_ln;                /* 1: a kernel that produces a block's output rows (uvc_mlp_fused_fwd; fc2 + residual + gate mix) also writes
                                           norm1 of the NEXT block that runs (model_distilled.py:241) from the rows it holds, and that block skips its
                                           stand-alone LayerNorm pass.  0: every LayerNorm is its own pass. */
-  int32_t reserved0;
+  int32_t force_generic;               /* tests / A-B runs: passed to every uvc_gemm_nt of the pass (uvc_gemm_nt_args.force_generic: 1 = the generic
+                                          LDS-tiled kernel everywhere, 2 = register-staged streaming kernels instead of the LDS-DMA rings);
+                                          1 also runs every dgrad + LayerNorm backward as the unfused pair, 2 runs uvc_gemm_nt_lnbwd's
+                                          register-staged variant.  0 = kernels picked by shape */
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

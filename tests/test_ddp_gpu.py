@@ -37,6 +37,27 @@ def test_bench_contract_under_torchrun_single_rank():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0
 
 
+def test_bench_two_ranks_on_one_device():
+    """bench.py's world > 1 branches under the driver's launch line with TWO ranks: init_process_group, the bucketed all-reduce overlapped
+    with the backward (uvc_amd.ddp), MAX of the wall time over ranks, ranks_seen, exposed_allreduce_ms_per_step, the closing barrier.  The
+    box has one GPU and RCCL refuses two ranks per device, so the ranks share device 0 over gloo (UVC_BENCH_BACKEND / UVC_BENCH_SHARE_DEVICE);
+    on a multi-GPU node the same file runs one rank per GPU over RCCL.  No scaling number is read from this."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UVC_BENCH_BACKEND="gloo", UVC_BENCH_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29545", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                    # rank 0 prints, rank 1 does not
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["backend"] == "gloo"
+    assert j["config"]["global_batch"] == 64 and j["config"]["parallelism"] == "dp2"
+    assert "exposed_allreduce_ms_per_step" in j and j["exposed_allreduce_ms_per_step"] >= 0.0
+    assert j["value"] > 0 and j["scaling"] == "weak" and "cpu_baseline" not in j      # the CPU baseline is a rank-0, N = 1 leg
+
+
 @pytest.mark.parametrize("model", ["deit", "t2t"])
 def test_two_ranks_match_single_process(model):
     """Two ranks (gloo, both on the box's one GPU), half a batch each, against the single-process full-batch step."""

@@ -1,0 +1,161 @@
+"""GPU: one FULL DeiT-Tiny UVC-train step at a batch that selects the row-count-gated streaming kernels, against the oracle.
+
+The reference goldens run at M <= 1576 token rows (tiny8_*: 8 x 197), where the calls that bench.py times as k_gemm_ws (qkv,
+fc1 + GELU / GELU', dfc2 x GELU', dproj), k_gemm_wsn (K = 768 / 576 dgrads) and k_gemm_wsn_lnbwd_dma (dqkv + LN1', dfc1 + LN2')
+fall to the generic tiled kernel + the stand-alone LayerNorm backward: those kernels switch on at M >= 4096 only.  Here the batch
+is 32 (M = 6304): the SAME weights / primal-dual state / Exp(1) draws as the `tiny8_pruned` fixture (BASELINE config 1's model from
+the non-trivial state), inputs from the same frozen numpy stream, and the expected values from oracle.step.stage1_step on the host
+(float32; the oracle is pinned to the reference by tests/test_oracle_golden.py on exactly this scenario at batch 8).
+
+Checked per TENSOR (relative L2 error of every parameter's gradient against the oracle's autograd), so a regression names its
+kernel, plus loss / logits / clip norm / s r y p z / gate logits / resource, mask index sets bit-exact, and the same step with
+the engine forced onto the generic kernels (uvc_vit_io.force_generic = 1, every LayerNorm as its own pass) as an A/B.
+This batch also sits in the window 4096 <= M < 7.7 k where the LayerNorm-backward partial regions of round 2 were too small for
+the fused dgrad kernel: its symptoms -- wrong norm1 / norm2 dgamma, dbeta and gate-logit gradients -- are
+exactly what the per-tensor comparison looks at."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scenarios as SC
+from helpers import build_oracle_from_recipe, load_golden, split_draws
+from oracle import step as OS
+from stage1_driver import Stage1Run
+
+pytestmark = pytest.mark.gpu
+
+BATCH = 32
+
+
+def _recipe():
+    r = copy.deepcopy(SC.recipe("tiny8_pruned"))
+    r["batch"], r["steps"] = BATCH, 1
+    return r
+
+
+def _oracle_step():
+    r, S = build_oracle_from_recipe(_recipe())
+    gold = load_golden("tiny8_pruned")
+    x_all, y_all = SC.make_inputs(r)
+    md, e1, e2 = split_draws(r, gold, 0, S.cfg.depth)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    out = {}
+    OS.stage1_step(S, torch.from_numpy(x_all[0]), torch.from_numpy(y_all[0]), md, e1, e2, out)
+    return S, out
+
+
+def _hip_step(precision, force_generic=0, fuse_next_ln=True):
+    r = _recipe()
+    gold = load_golden("tiny8_pruned")
+    run = Stage1Run(r, precision=precision)
+    for m in (run.model, run.teacher):
+        m.force_generic = force_generic
+        m.fuse_next_ln = fuse_next_ln
+    x_all, y_all = SC.make_inputs(r)
+    md, e1, e2 = split_draws(r, gold, 0, run.cfg.depth)
+    run.inject_draws(md, e1, e2)
+    out = run.step(torch.from_numpy(x_all[0]).cuda(), torch.from_numpy(y_all[0]).cuda())
+    torch.cuda.synchronize()
+    grads = {n: (None if p.grad is None else p.grad.detach().float().cpu().clone()) for n, p in run.model.named_parameters()}
+    return run, out, grads
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return _oracle_step()
+
+
+def _check_against_oracle(run, out, grads, S, o, tol_grad, tol_out, tol_state, what):
+    loss, ref_loss = float(out["loss"]), float(o["loss"])
+    assert abs(loss - ref_loss) <= tol_out * abs(ref_loss), (what, loss, ref_loss)
+    lg, ref_lg = out["outputs"][0].detach().float().cpu(), o["logits"]
+    assert _rel(lg, ref_lg) <= tol_out, (what, "logits", _rel(lg, ref_lg))
+    gn, ref_gn = float(out["gnorm"]), float(o["grad_norm"])
+    assert abs(gn - ref_gn) <= tol_grad * ref_gn, (what, "clip norm", gn, ref_gn)
+    # the reference clips in place before anything reads .grad; the oracle's recorded gradients are the clipped ones
+    coef = min(1.0, run.r["max_grad_norm"] / (gn + 1e-6))
+    worst = {}
+    for n, g in grads.items():
+        ref = o["grads"].get(n)
+        assert (g is None) == (ref is None), (what, n)
+        if g is None:
+            continue
+        c = 1.0 if n == "block_skip_gating" else coef         # the gate's gradient is already clipped in place
+        worst[n] = _rel(g * c, ref)
+    bad = {k: round(v, 4) for k, v in worst.items() if v > (tol_grad if k != "block_skip_gating" else 4 * tol_grad)}
+    assert not bad, (what, "per-tensor gradient error above tolerance", bad)
+    mm = run.minimax
+    for k, ref in (("s", S.st.s), ("r", S.st.r), ("y", S.st.y), ("p", S.st.p)):
+        np.testing.assert_allclose(getattr(mm, k).data.cpu().numpy(), ref.numpy(), rtol=tol_state, atol=1e-6, err_msg=f"{what} {k}")
+    assert abs(float(mm.z) - float(S.st.z)) <= 1e-4 * abs(float(S.st.z)), (what, "z")
+    assert abs(float(out["cur"]) - float(o["cur_resource"])) <= 1e-4, (what, "cur_resource")
+    np.testing.assert_allclose(out["g"].numpy(), S.params["block_skip_gating"].numpy(), rtol=tol_state, atol=1e-6, err_msg=f"{what} gate logits")
+    return worst
+
+
+def _masks(run):
+    from uvc_amd.uvc_utils import prune_w_mask
+    prune_w_mask(run.minimax, run.optimizer)
+    return [(run.layers["W1"][l].mask[0].cpu().clone(), run.layers["W3"][l].mask[0].cpu().clone()) for l in range(run.cfg.depth)]
+
+
+def _oracle_keep(S):
+    """Index sets of oracle.uvc.prune_masks (uvc_utils.py:376-401): per layer (kept proj input columns, kept fc2 input columns)."""
+    from oracle import uvc as OU
+    return [(keep1, keep3) for _, _, _, keep1, keep3 in OU.prune_masks(S.st, S.w1(), S.w3())]
+
+
+def test_tiny_step_matches_oracle_at_streaming_batch(oracle):
+    """bf16 throughput mode, kernels picked by shape (M = 6304: every streaming / LDS-DMA kernel of the bench step runs)."""
+    S, o = oracle
+    run, out, grads = _hip_step("bf16")
+    worst = _check_against_oracle(run, out, grads, S, o, tol_grad=6e-2, tol_out=2e-2, tol_state=2e-2, what="bf16 streaming")
+    for l, ((k1, k3), (r1, r3)) in enumerate(zip(_masks(run), _oracle_keep(S))):
+        assert torch.equal(k1.bool(), r1.bool()) and torch.equal(k3.bool(), r3.bool()), f"mask index set of layer {l} differs from the oracle"
+    print("per-tensor gradient error vs oracle, bf16 streaming kernels: max %.4f (%s), median %.4f" %
+          (max(worst.values()), max(worst, key=worst.get), float(np.median(list(worst.values())))))
+
+
+def test_tiny_step_streaming_and_generic_kernels_agree_per_tensor(oracle):
+    """A/B inside the bf16 mode: the step on the streaming kernels against the same step with every GEMM on the generic tiled kernel,
+    the LayerNorm passes stand-alone and the dgrad + LayerNorm backward as the unfused pair.  Both against the oracle, and against
+    each other per tensor at a tolerance far below the bf16-vs-float32 distance: the two paths round the same quantities."""
+    S, o = oracle
+    run_s, out_s, g_s = _hip_step("bf16")
+    run_g, out_g, g_g = _hip_step("bf16", force_generic=1, fuse_next_ln=False)
+    _check_against_oracle(run_g, out_g, g_g, S, o, tol_grad=6e-2, tol_out=2e-2, tol_state=2e-2, what="bf16 generic")
+    diff = {n: _rel(g_s[n], g_g[n]) for n in g_s if g_s[n] is not None}
+    bad = {k: round(v, 5) for k, v in diff.items() if v > (2e-2 if k != "block_skip_gating" else 8e-2)}
+    assert not bad, ("streaming vs generic kernels", bad)
+    assert abs(float(out_s["loss"]) - float(out_g["loss"])) <= 2e-3 * abs(float(out_g["loss"]))
+    for (a1, a3), (b1, b3) in zip(_masks(run_s), _masks(run_g)):
+        assert torch.equal(a1, b1) and torch.equal(a3, b3)
+    print("streaming vs generic, per-tensor gradient difference: max %.5f (%s)" % (max(diff.values()), max(diff, key=diff.get)))
+
+
+def test_tiny_step_register_staged_streaming_kernels_match_the_rings(oracle):
+    """force_generic = 2: the streaming kernels in their register-staged forms (k_gemm_wsn16, k_gemm_wsn_lnbwd) instead of the LDS-DMA
+    rings.  Same accumulation order and epilogue arithmetic: the gradients agree to float32 summation order."""
+    run_s, out_s, g_s = _hip_step("bf16")
+    run_r, out_r, g_r = _hip_step("bf16", force_generic=2)
+    diff = {n: _rel(g_s[n], g_r[n]) for n in g_s if g_s[n] is not None}
+    assert max(diff.values()) <= 2e-3, {k: v for k, v in diff.items() if v > 2e-3}
+    assert float(out_s["loss"]) == float(out_r["loss"])
+
+
+def test_tiny_step_fp32_matches_oracle_at_streaming_batch(oracle):
+    """The float32-exact mode at the same batch (generic kernels by construction): the 1e-3 bar of north_star, masks bit-exact."""
+    S, o = oracle
+    run, out, grads = _hip_step("fp32")
+    worst = _check_against_oracle(run, out, grads, S, o, tol_grad=3e-3, tol_out=1e-3, tol_state=1e-3, what="fp32")
+    for l, ((k1, k3), (r1, r3)) in enumerate(zip(_masks(run), _oracle_keep(S))):
+        assert torch.equal(k1.bool(), r1.bool()) and torch.equal(k3.bool(), r3.bool()), f"mask index set of layer {l} differs from the oracle"
+    print("per-tensor gradient error vs oracle, fp32: max %.2e (%s)" % (max(worst.values()), max(worst, key=worst.get)))

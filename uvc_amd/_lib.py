@@ -78,7 +78,7 @@ class uvc_ln_args(C.Structure):
 
 class uvc_gemm_lnbwd_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("A", "W", "x", "mean", "rstd", "gamma", "add1", "a1", "add2", "a2", "dx", "partial")] + \
-               [(n, C.c_int32) for n in ("M", "D", "K", "dtype")]
+               [(n, C.c_int32) for n in ("M", "D", "K", "dtype", "variant", "reserved")]
 
 
 class uvc_mlp_args(C.Structure):

@@ -501,32 +501,23 @@ template <typename T, int NT16> int launch(const AttnArgs& a, int which, hipStre
   // forward: 4 waves per (image, head); backward: 8 (two workgroups per CU either way -- the LDS image is the limit --
   // so backward runs 4 waves per SIMD, which hides its longer dependent MFMA -> exp -> MFMA chains: 153 -> 135 us)
   const int threads = which == 0 ? (sizeof(T) == 2 ? 512 : 256) : 512;
-  hipError_t e = hipSuccess;
   if (which == 0) {
     const int fgrid = (sizeof(T) == 2 && grid > 512) ? 512 : grid;      // bf16: two persistent workgroups per CU
     // DeiT's N = 197 / 198: twelve full key tiles, a partial one and a tile of padding -- known at compile time (see attn_key_block)
     constexpr int NF = NT16 == 14 ? 12 : -1;
     if (NF >= 0 && a.N / 16 == NF) {
-      static const hipError_t e0 = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16, 8, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);   // once: sh is a function of the instantiation
-      e = e0;
-      if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+      UVC_MAX_LDS(sh, k_attn_fwd<T, NT16, 8, NF>);      // sh is a function of the instantiation
       k_attn_fwd<T, NT16, 8, NF><<<fgrid, sizeof(T) == 2 ? 512 : 256, sh, st>>>(a);
     } else {
-      static const hipError_t e0 = hipFuncSetAttribute((const void*)k_attn_fwd<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      e = e0;
-      if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+      UVC_MAX_LDS(sh, k_attn_fwd<T, NT16>);
       k_attn_fwd<T, NT16><<<fgrid, sizeof(T) == 2 ? 512 : 256, sh, st>>>(a);
     }
   } else if (which == 1) {
-    static const hipError_t e0 = hipFuncSetAttribute((const void*)k_attn_bwd_dq<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    e = e0;
-    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+    UVC_MAX_LDS(sh, k_attn_bwd_dq<T, NT16>);
     k_attn_bwd_dq<T, NT16><<<grid, threads, sh, st>>>(a);
   } else {
     sh += (size_t)2 * NP * sizeof(float);
-    static const hipError_t e0 = hipFuncSetAttribute((const void*)k_attn_bwd_dkv<T, NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    e = e0;
-    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+    UVC_MAX_LDS(sh, k_attn_bwd_dkv<T, NT16>);
     k_attn_bwd_dkv<T, NT16><<<grid, threads, sh, st>>>(a);
   }
   UVC_CHECK_LAUNCH();

@@ -17,6 +17,26 @@
 int uvc_set_error(hipError_t e, const char* file, int line);
 int uvc_set_error_msg(int code, const char* msg);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize applies per DEVICE: a kernel that needs more than 64 KB of dynamic LDS must get the
+// attribute on every device the process launches it on.  One bit per device ordinal and call site; usage (inside a function that
+// returns an int status):  UVC_MAX_LDS(bytes, kernel<template, arguments>);
+static inline hipError_t uvc_max_lds_once(uint64_t& mask, const void* func, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (mask & bit) return hipSuccess;
+  e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) mask |= bit;
+  return e;
+}
+#define UVC_MAX_LDS(bytes, ...)                                                              \
+  do {                                                                                       \
+    static uint64_t lds_mask__ = 0;                                                          \
+    const hipError_t lds_e__ = uvc_max_lds_once(lds_mask__, (const void*)(__VA_ARGS__), (int)(bytes)); \
+    if (lds_e__ != hipSuccess) return uvc_set_error(lds_e__, __FILE__, __LINE__);            \
+  } while (0)
+
 typedef uint16_t bf16_t;  // storage type: raw bfloat16 bits
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

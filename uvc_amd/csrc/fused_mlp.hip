@@ -400,15 +400,8 @@ extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: next_mean and next_rstd come together, with next_h");
   hipStream_t st = (hipStream_t)stream;
   {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused_v3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_mlp_fused_v3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-      if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-      attr_set = true;
-    }
-    if (train) k_mlp_fused_v3<true><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p);
-    else k_mlp_fused_v3<false><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p);
+    if (train) { UVC_MAX_LDS(V3_LDS, k_mlp_fused_v3<true>); k_mlp_fused_v3<true><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p); }
+    else { UVC_MAX_LDS(V3_LDS, k_mlp_fused_v3<false>); k_mlp_fused_v3<false><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p); }
     UVC_CHECK_LAUNCH();
     return UVC_OK;
   }

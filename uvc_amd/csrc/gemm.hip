@@ -9,7 +9,6 @@
 // or 32 B (TN) so ds_read_b128 / ds_read_b64_tr_b16 fragment reads are bank-conflict free.
 // Operands are swapped in the MFMA (a = B-fragment, b = A-fragment) so every lane ends up with 4
 // CONSECUTIVE output columns of one row -> 16-byte (fp32) / 8-byte (bf16) epilogue accesses.
-#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "../../include/uvc_kernels.h"
@@ -90,6 +89,7 @@ struct NtArgs {
   const float* alpha_ptr;   // optional device scalar multiplied into alpha
   // optional second output of the N == 192 residual epilogues: LayerNorm of the output rows (uvc_gemm_nt_args.ln_*)
   const float* ln_gamma; const float* ln_beta; void* ln_out; float* ln_mean; float* ln_rstd; float ln_eps;
+  int no_dma;               // uvc_gemm_nt_args.force_generic == 2: the register-staged streaming kernels instead of the LDS-DMA rings
 };
 
 // vector of VN consecutive outputs in the coalesced epilogue layout
@@ -548,8 +548,7 @@ static int launch_ws384(const NtArgs& a, int epi, hipStream_t st) {
   const int grid = nslots * ngroups;
   const int sh = 2 * WS_BM * (KT * 64 + 32) + NW * 16 * (16 * NJ + 4) * 4;
 #define WS_CASE(E) case E: { \
-    static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_ws<bf16_t, TC, E, KT, NW, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, sh); \
-    if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__); \
+    UVC_MAX_LDS(sh, k_gemm_ws<bf16_t, TC, E, KT, NW, NJ>); \
     k_gemm_ws<bf16_t, TC, E, KT, NW, NJ><<<grid, 64 * NW, sh, st>>>(a, ngroups, nslots); } break;
   switch (epi) {
     WS_CASE(UVC_EPI_BIAS) WS_CASE(UVC_EPI_BIAS_GELU) WS_CASE(UVC_EPI_BIAS_RESID)
@@ -823,8 +822,7 @@ template <int EPI, int KT, bool LN, int NST = 3>
 static int launch_wsn16_dma(const NtArgs& a, hipStream_t st) {
   constexpr int NA_ = (16 * (KT * 4 + 2) + 63) / 64, NI_ = NA_ + 13 + (EPI == UVC_EPI_BIAS_RESID_GATE ? 13 : 0);
   const int sh = NST * NI_ * 1024 + (LN ? 2 * 16 * 12 * 8 + 3 * 192 * 4 : 0);
-  static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn16_dma<EPI, KT, LN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
-  if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__);
+  UVC_MAX_LDS(sh, k_gemm_wsn16_dma<EPI, KT, LN, NST>);
   const int ntiles = ceil_div(a.M, 16);
   k_gemm_wsn16_dma<EPI, KT, LN, NST><<<ntiles < 256 ? ntiles : 256, 768, sh, st>>>(a);
   UVC_CHECK_LAUNCH();
@@ -837,10 +835,9 @@ static bool wsn16_dma_ok(const NtArgs& a) {
 template <typename TC, int KT>
 static int launch_wsn16_kt(const NtArgs& a, int epi, hipStream_t st) {
   if constexpr (sizeof(TC) == 4 && (KT == 24 || KT == 16 || KT == 8)) {
-    // fc2 of DeiT-Tiny on the LDS-DMA ring (UVC_FC2_DMA=0 keeps the register-staged kernel); with ln_out also the compacted Stage-2
+    // fc2 of DeiT-Tiny on the LDS-DMA ring (uvc_gemm_nt_args.force_generic = 2 keeps the register-staged kernel); with ln_out also the compacted Stage-2
     // widths (K = 512 / 256: more stages of the smaller images fit)
-    static const bool use_dma = [] { const char* v = getenv("UVC_FC2_DMA"); return v ? atoi(v) != 0 : true; }();
-    const bool ok = (use_dma || a.ln_out) && wsn16_dma_ok(a) && (a.ln_out || a.M % 16 == 0);
+    const bool ok = (!a.no_dma || a.ln_out) && wsn16_dma_ok(a) && (a.ln_out || a.M % 16 == 0);
     constexpr int NST_ = KT == 8 ? 4 : 3;
     if (ok && a.ln_out) {
       if (epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, true, NST_>(a, st);
@@ -856,8 +853,7 @@ static int launch_wsn16_kt(const NtArgs& a, int epi, hipStream_t st) {
   const int grid = ntiles < 256 ? ntiles : 256;
   const size_t sh = (size_t)2 * 16 * (KT * 64 + 32);
 #define WN_CASE(E) case E: { \
-    static const hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsn16<TC, E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-    if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
+    UVC_MAX_LDS(sh, k_gemm_wsn16<TC, E, KT>); \
     k_gemm_wsn16<TC, E, KT><<<grid, 768, sh, st>>>(a); } break;
   switch (epi) {
     WN_CASE(UVC_EPI_NONE) WN_CASE(UVC_EPI_BIAS) WN_CASE(UVC_EPI_BIAS_RESID) WN_CASE(UVC_EPI_BIAS_RESID_GATE)
@@ -878,8 +874,7 @@ static int launch_wsn_kt(const NtArgs& a, int epi, hipStream_t st) {
   const int grid = ntiles < 256 ? ntiles : 256;                 // one persistent workgroup per CU
   const size_t sh = (size_t)2 * WN_BM * (KT * 64 + 32);
 #define WN_CASE(E) case E: { \
-    static const hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_wsn<TC, E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-    if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
+    UVC_MAX_LDS(sh, k_gemm_wsn<TC, E, KT>); \
     k_gemm_wsn<TC, E, KT><<<grid, 768, sh, st>>>(a); } break;
   switch (epi) {                       // bf16 outputs only (float32 outputs run k_gemm_wsn16; residual epilogues need float32 C)
     WN_CASE(UVC_EPI_NONE) WN_CASE(UVC_EPI_BIAS)
@@ -938,11 +933,13 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   a.dptr = p->gate; a.M = p->M; a.N = p->N; a.K = p->K; a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
   a.ldr = p->ldr ? p->ldr : p->ldc; a.ldaux = p->ldaux ? p->ldaux : p->ldc; a.alpha = p->alpha; a.alpha_ptr = p->alpha_ptr;
   a.ln_gamma = p->ln_gamma; a.ln_beta = p->ln_beta; a.ln_out = p->ln_out; a.ln_mean = p->ln_mean; a.ln_rstd = p->ln_rstd; a.ln_eps = p->ln_eps;
+  a.no_dma = p->force_generic == 2;
+  const bool generic = p->force_generic == 1;
   hipStream_t st = (hipStream_t)stream;
   if (p->ln_out) {
     if (!p->ln_gamma || !p->ln_beta || (p->ln_mean != nullptr) != (p->ln_rstd != nullptr))
       return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: ln_out needs ln_gamma, ln_beta (and ln_mean, ln_rstd together)");
-    if (!uvc_gemm_nt_ln_supported(p->M, p->N, p->K, p->dtype, e) || p->force_generic || p->a_is_f32 || !p->c_is_f32 || p->alpha != 1.0f || p->alpha_ptr ||
+    if (!uvc_gemm_nt_ln_supported(p->M, p->N, p->K, p->dtype, e) || generic || p->a_is_f32 || !p->c_is_f32 || p->alpha != 1.0f || p->alpha_ptr ||
         a.ldb != a.K || !wsn16_dma_ok(a) || ((uintptr_t)p->ln_out & 7) != 0)
       return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: ln_out is not available for this problem (uvc_gemm_nt_ln_supported)");
     if (p->M % 16 != 0 && (p->C == (const void*)p->R || p->C == (const void*)p->R2))
@@ -958,15 +955,14 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   if (p->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dtype must be UVC_F32 or UVC_BF16");
   {
     // attn.proj + residual (K = N = 192) without ln_out: the same seven-stage ring (same k-ordered chain and epilogue: same bits)
-    static const bool proj_dma = [] { const char* v = getenv("UVC_PROJ_DMA"); return v ? atoi(v) != 0 : true; }();
-    if (proj_dma && !p->force_generic && !p->a_is_f32 && p->c_is_f32 && e == UVC_EPI_BIAS_RESID && p->K == 192 && p->N == 192 && a.ldb == 192 &&
+    if (!p->force_generic && !p->a_is_f32 && p->c_is_f32 && e == UVC_EPI_BIAS_RESID && p->K == 192 && p->N == 192 && a.ldb == 192 &&
         p->M >= 4096 && p->M % 16 == 0 && p->alpha == 1.0f && !p->alpha_ptr && wsn16_dma_ok(a))
       return launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, false, 7>(a, st);
   }
-  const bool ws = !p->force_generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
-  if (!p->force_generic && ws384_ok(a, e, p->c_is_f32 ? 4 : 8, p->a_is_f32 != 0))
+  const bool ws = !generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
+  if (!generic && ws384_ok(a, e, p->c_is_f32 ? 4 : 8, p->a_is_f32 != 0))
     return p->c_is_f32 ? launch_ws384<float>(a, e, st) : launch_ws384<bf16_t>(a, e, st);
-  if (!p->force_generic && wsn_ok(a, e, p->a_is_f32 != 0))
+  if (!generic && wsn_ok(a, e, p->a_is_f32 != 0))
     return p->c_is_f32 ? launch_wsn<float>(a, e, st) : launch_wsn<bf16_t>(a, e, st);
   if (p->a_is_f32) {
     if ((p->lda % 8) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: lda");
@@ -1643,21 +1639,18 @@ extern "C" int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
 #define LNB_LAUNCH(KT_) { \
     const size_t sh = (size_t)2 * 16 * (KT_ * 64 + 32) + (2 * 16 * 12 * 2 + 192) * sizeof(float); \
-    static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn_lnbwd<KT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-    if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__); \
+    UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd<KT_>); \
     k_gemm_wsn_lnbwd<KT_><<<grid, 768, sh, st>>>(a); }
-  static const bool use_dma = [] { const char* v = getenv("UVC_LNBWD_DMA"); return v ? atoi(v) != 0 : true; }();
+  const bool use_dma = p->variant != 1;
   const bool al16 = (((uintptr_t)p->add1 | (uintptr_t)p->add2 | (uintptr_t)p->mean | (uintptr_t)p->rstd) & 15) == 0;
 #define LNB_LAUNCH_DMA(KT_) { \
     constexpr int NA_ = (16 * (KT_ * 4 + 2) + 63) / 64, NI_ = NA_ + 13 + 7 + 7; \
     const size_t sh = (size_t)3 * NI_ * 1024 + (2 * 16 * 12 * 2 + 192) * sizeof(float); \
     if (p->add2) { \
-      static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn_lnbwd_dma<KT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-      if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__); \
+      UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd_dma<KT_, true>); \
       k_gemm_wsn_lnbwd_dma<KT_, true><<<grid, 768, sh, st>>>(a); \
     } else { \
-      static const hipError_t attr_ = hipFuncSetAttribute((const void*)k_gemm_wsn_lnbwd_dma<KT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-      if (attr_ != hipSuccess) return uvc_set_error(attr_, __FILE__, __LINE__); \
+      UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd_dma<KT_, false>); \
       k_gemm_wsn_lnbwd_dma<KT_, false><<<grid, 768, sh, st>>>(a); } }
   if (use_dma && al16 && p->M % 16 == 0) { if (p->K == 768) LNB_LAUNCH_DMA(24) else LNB_LAUNCH_DMA(18) }
   else if (p->K == 768) LNB_LAUNCH(24) else LNB_LAUNCH(18)
@@ -2185,7 +2178,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   rps = ceil_div(rps, TN_BM) * TN_BM;
   splits = ceil_div(p->M, rps);
   a.rows_per_split = rps;
-  { static const int remap_ = [] { const char* e = getenv("UVC_TN_XCD"); return e ? atoi(e) : 1; }(); a.xcd_remap = remap_; }
+  a.xcd_remap = 1;
   a.bpart = p->colsum_out ? a.part + (size_t)splits * p->N1 * p->N2 : nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (p->dtype == UVC_F32) {
@@ -2207,8 +2200,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
       else k_gemm_tn_big<TA_, 192, 192, 2, 4><<<grid, 512, 0, st>>>(a);
 #define TN_DMA_ONE(B1_, B2_, W1_, W2_) { \
         const int sh_ = TD_NST * (((TD_BM * (((B1_) * 2 + 32) / 16 + ((B2_) * 2 + 32) / 16) + 63) / 64) * 1024) + 1024; \
-        static const hipError_t e_ = hipFuncSetAttribute((const void*)k_gemm_tn_dma<B1_, B2_, W1_, W2_>, hipFuncAttributeMaxDynamicSharedMemorySize, sh_); \
-        if (e_ != hipSuccess) return uvc_set_error(e_, __FILE__, __LINE__); \
+        UVC_MAX_LDS(sh_, k_gemm_tn_dma<B1_, B2_, W1_, W2_>); \
         k_gemm_tn_dma<B1_, B2_, W1_, W2_><<<grid, 512, sh_, st>>>(a); }
       if (p->a_is_f32) { TN_BIG(float) }           // float32 A (converted on load): register-staged kernel
       else if (cfg == 1) TN_DMA_ONE(192, 256, 2, 4)

@@ -13,8 +13,6 @@ namespace {
 // backward: rows per workgroup (three workgroups fit a CU): enough workgroups to fill the chip several times over without
 // inflating the partial reduction.
 static int ln_rows_per_block(int rows) {
-  static const int forced = [] { const char* v = getenv("UVC_LN_RPB"); return v ? atoi(v) : 0; }();
-  if (forced == 32 || forced == 64 || forced == 128) return forced;
   return rows >= 48 * 1024 ? 64 : 32;     // stand-alone at 100 k rows: 56 / 67 us at 64 against 60 / 77 at 128 and 62 / 72 at 32; T2T-14 (25 k rows) +4 % step rate at 32
 }
 

@@ -230,10 +230,8 @@ template <typename T> int tok_launch(const uvc_attn_tok_args* p, bool bwd, hipSt
   a.qkv = p->qkv; a.o = p->o; a.dout = p->dout; a.dqkv = p->dqkv; a.head_keep = bwd ? nullptr : p->head_keep;
   a.B = p->B; a.N = p->N; a.H = p->H; a.ntok = p->ntok; a.scale = p->scale;
   const size_t sh = tok_lds<T>(bwd);
-  static const hipError_t ef = hipFuncSetAttribute((const void*)k_attn_tok_fwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tok_lds<T>(false));
-  static const hipError_t eb = hipFuncSetAttribute((const void*)k_attn_tok_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tok_lds<T>(true));
-  const hipError_t e = bwd ? eb : ef;
-  if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+  if (bwd) UVC_MAX_LDS(sh, k_attn_tok_bwd<T>);
+  else UVC_MAX_LDS(sh, k_attn_tok_fwd<T>);
   const dim3 grid(p->H, p->B);
   if (bwd) k_attn_tok_bwd<T><<<grid, NTH, sh, st>>>(a);
   else k_attn_tok_fwd<T><<<grid, NTH, sh, st>>>(a);

@@ -108,7 +108,13 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
     w.delta = (float*)c.take((int64_t)d.B * d.H * d.N * 4);
     // one private region of per-block dgamma/dbeta/dots partials per LayerNorm-backward call of a pass (2 per block + final norm):
     // the calls leave their partials there and ONE batched launch per backward call finishes them (49 tiny launches less per step)
-    w.ln_region = (int64_t)uvc_layernorm_bwd_blocks(d.M) * (2 * d.D + 2);
+    // (a region must hold the rows of WHICHEVER kernel uses it: the stand-alone backward writes uvc_layernorm_bwd_blocks(M) rows, the
+    // dgrad GEMM with the LayerNorm-backward epilogue uvc_gemm_lnbwd_nblocks(M) = min(ceil(M / 16), 256), which is the larger count for
+    // 4096 <= M < ~7.7 k -- sized for one only, the fused call of such a batch wrote past its region into the next call's)
+    {
+      const int64_t r1 = uvc_layernorm_bwd_blocks(d.M), r2 = uvc_gemm_lnbwd_nblocks(d.M);
+      w.ln_region = (r1 > r2 ? r1 : r2) * (2 * d.D + 2);
+    }
     w.ln_partial = (float*)c.take(w.ln_region * 4 * (2 * d.L + 1));
     const int maxN = d.F > 3 * d.D ? d.F : 3 * d.D;
     w.cs_partial = (float*)c.take((int64_t)uvc_colsum_blocks(d.M) * (maxN > d.NC ? maxN : d.NC) * 4);
@@ -183,6 +189,7 @@ int nt(const Ctx& c, const void* A, int a_f32, const void* B, void* C, int c_f32
   a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.R = R; a.R2 = R2; a.aux = aux; a.gate = gate; a.alpha_ptr = alpha_ptr;
   a.alpha = 1.0f; a.M = M; a.N = N; a.K = K; a.lda = lda ? lda : K; a.ldb = K; a.ldc = ldc ? ldc : N; a.ldr = a.ldc; a.ldaux = a.ldc;
   a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32; a.c_is_f32 = c_f32 || c.d.dtype == UVC_F32; a.epilogue = epi;
+  a.force_generic = ln ? 0 : c.io->force_generic;      // (a producer that also writes the next LayerNorm exists in one form only)
   return uvc_gemm_nt(&a, c.st);
 }
 // weight gradient + (same pass over A) bias gradient.  With a side stream the launch goes there: it waits for
@@ -242,7 +249,7 @@ int ln_bwd(Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const
 }
 // dgrad GEMM + LayerNorm backward in one kernel (uvc_gemm_nt_lnbwd) where the shape allows; registers the call's partial
 // region with the batched finish exactly like ln_bwd
-bool lnb_fused_ok(const Ctx& c, int K) { return uvc_gemm_lnbwd_supported(c.d.M, c.d.D, K, c.d.dtype) != 0; }
+bool lnb_fused_ok(const Ctx& c, int K) { return c.io->force_generic != 1 && uvc_gemm_lnbwd_supported(c.d.M, c.d.D, K, c.d.dtype) != 0; }
 int dgrad_ln_bwd(Ctx& c, const void* A, const void* Wt, int K, const float* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, void* dx,
                  const void* add1, const float* a1, const void* add2, const float* a2, float* dots) {
   if (c.n_ln >= 2 * c.d.L + 1) { if (int e = flush_ln(c)) return e; }
@@ -250,6 +257,7 @@ int dgrad_ln_bwd(Ctx& c, const void* A, const void* Wt, int K, const float* x, i
   memset(&a, 0, sizeof(a));
   a.A = A; a.W = Wt; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = c.io->params + pw; a.add1 = add1; a.a1 = a1; a.add2 = add2; a.a2 = a2;
   a.dx = dx; a.partial = c.w.ln_partial + c.w.ln_region * c.n_ln; a.M = c.d.M; a.D = c.d.D; a.K = K; a.dtype = c.d.dtype;
+  a.variant = c.io->force_generic == 2 ? 1 : 0;
   uvc_ln_reduce_item& it = c.ln_items[c.n_ln++];
   it.partial = a.partial; it.dgamma = c.io->grads + pw; it.dbeta = c.io->grads + pb; it.dots = dots; it.nblocks = uvc_gemm_lnbwd_nblocks(c.d.M); it.reserved = 0;
   return uvc_gemm_nt_lnbwd(&a, c.st);
@@ -280,7 +288,7 @@ int scatter_tok(const Ctx& c, const void* compact, void* full, size_t esz) {
 }
 // the last block that runs: its tail is computed on the token rows only (unless the caller asks for the reference's full rows)
 int tail_block(const Ctx& c) {
-  if (c.io->full_tail) return -1;
+  if (c.io->full_tail || c.d.N > 256 || c.d.ntok > 2) return -1;      // beyond what uvc_attention_tok_* takes: all rows, like any other block
   int last = -1;
   for (int l = 0; l < c.d.L; ++l)
     if (c.io->gate_d || !c.io->run_block || c.io->run_block[l] != 0) last = l;
@@ -477,7 +485,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     const void* w1 = mc ? mc->w1 : wmat(c, q[8], c.soff.blk_w[l][2]);
     const void* w2 = mc ? mc->w2 : wmat(c, q[10], c.soff.blk_w[l][3]);
     const float* b1 = mc ? mc->b1 : P + q[9];
-    const bool mlp_one_kernel = uvc_mlp_fused_supported(d.D, Fe, d.dtype) && (io->training ? io->fused_train_mlp != 0 : !io->gate_d);
+    const bool mlp_one_kernel = io->force_generic != 1 && uvc_mlp_fused_supported(d.D, Fe, d.dtype) && (io->training ? io->fused_train_mlp != 0 : !io->gate_d);
     // norm2 as a second output of attn.proj + residual (the MLP kernel, where it runs, normalises its rows itself)
     // (not on the compact token rows of a `tail` block: B * ntok may be below the kernel's 16 rows, and whether a norm is fused must
     // not depend on the batch -- the two forms round differently in the last bit)

@@ -54,7 +54,7 @@ class uvc_vit_io(C.Structure):
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
                 ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
                 ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("fused_train_mlp", C.c_int32), ("patches_in", C.c_void_p),
-                ("fuse_next_ln", C.c_int32), ("reserved0", C.c_int32)]
+                ("fuse_next_ln", C.c_int32), ("force_generic", C.c_int32)]
 
 
 class uvc_mlp_compact(C.Structure):
@@ -75,17 +75,22 @@ _FUSED_TRAIN_MLP_DEFAULT = os.environ.get("UVC_FUSED_TRAIN_MLP", "0") not in (""
 # uvc_vit_io.patches_in (ordered by an event when they run on different streams).  An entry is consumed once, so a loop that feeds
 # the same tensor again (bench.py) still rearranges it once per step.  UVC_SHARE_PATCHES=0 turns the sharing off.
 _SHARE_PATCHES = os.environ.get("UVC_SHARE_PATCHES", "1") not in ("", "0")
-_PATCH_SHARE = dict(key=None, buf=None, ev=None, owner=None)
+_PATCH_SHARE = dict(x=None, key=None, buf=None, ev=None, owner=None)
 
 
-def _shared_patches(model, x):
+def _shared_patches(model, x, x_key=None):
+    """Patch rows of the batch `x` (uvc_patchify), shared between the two models that see the same batch.  A batch is identified by
+    the caller's tensor OBJECT (`x_key`: the tensor as the caller passed it, before any dtype / layout conversion) and its version
+    counter; the entry keeps a strong reference to it, so its storage cannot be handed to another batch while the entry lives -- a
+    (data_ptr, version, shape) key alone matched whatever later batch the caching allocator placed on the freed address."""
     cfg = model._cfg
-    key = (x.data_ptr(), x._version, tuple(x.shape), cfg.patch_size, model.precision)
+    x_key = x if x_key is None else x_key
+    key = (x_key._version, tuple(x.shape), cfg.patch_size, model.precision)
     c = _PATCH_SHARE
     cur = torch.cuda.current_stream()
-    if _SHARE_PATCHES and c["key"] == key and c["owner"] != id(model):
+    if _SHARE_PATCHES and c["x"] is x_key and c["key"] == key and c["owner"] != id(model):
         buf, ev = c["buf"], c["ev"]
-        c.update(key=None, buf=None, ev=None, owner=None)
+        c.update(x=None, key=None, buf=None, ev=None, owner=None)
         cur.wait_event(ev)
         buf.record_stream(cur)
         return buf
@@ -97,8 +102,14 @@ def _shared_patches(model, x):
     if _SHARE_PATCHES:
         ev = torch.cuda.Event()
         ev.record(cur)
-        c.update(key=key, buf=buf, ev=ev, owner=id(model))
+        c.update(x=x_key, key=key, buf=buf, ev=ev, owner=id(model))
     return buf
+
+
+def drop_shared_patches():
+    """Forget a pending entry (a pass by one model alone -- validation, a teacher-only forward -- leaves one behind; it holds the
+    batch and its patch rows alive until the next forward replaces it)."""
+    _PATCH_SHARE.update(x=None, key=None, buf=None, ev=None, owner=None)
 
 
 def _bind():
@@ -521,6 +532,7 @@ class DistilledVisionTransformer(nn.Module):
         io.full_tail = int(getattr(self, "full_tail", _FULL_TAIL_DEFAULT))
         io.fused_train_mlp = int(getattr(self, "fused_train_mlp", _FUSED_TRAIN_MLP_DEFAULT))
         io.fuse_next_ln = int(getattr(self, "fuse_next_ln", _FUSE_NEXT_LN_DEFAULT))
+        io.force_generic = int(getattr(self, "force_generic", 0))      # tests / A-B runs (uvc_vit_io.force_generic)
         return io
 
     def _ws_view(self, B, training, which):
@@ -543,6 +555,7 @@ class DistilledVisionTransformer(nn.Module):
 
     def _run_forward(self, x, tau, ratio, training):
         L.require_cuda(x)
+        x_key = x                               # the caller's tensor: identifies the batch for the patch-row sharing
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.contiguous().float()
         B = x.shape[0]
@@ -588,7 +601,7 @@ class DistilledVisionTransformer(nn.Module):
         if front:
             io.stage_begin, io.stage_end = 1, 2
         else:
-            patches = _shared_patches(self, x)          # the batch's patch rows, rearranged once for student and teacher
+            patches = _shared_patches(self, x, x_key)   # the batch's patch rows, rearranged once for student and teacher
             io.patches_in = L.ptr(patches)
         if mode1 or mode2:
             if not front:

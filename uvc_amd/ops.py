@@ -175,14 +175,15 @@ def gemm_lnbwd_supported(M, D, K, dtype) -> bool:
     return bool(L.lib().uvc_gemm_lnbwd_supported(M, D, K, dtype))
 
 
-def gemm_nt_lnbwd(A, Wt, x, mean, rstd, gamma, dx, partial, dgamma, dbeta, *, add1=None, a1=None, add2=None, a2=None, dots=None, beta_acc=0.0):
+def gemm_nt_lnbwd(A, Wt, x, mean, rstd, gamma, dx, partial, dgamma, dbeta, *, add1=None, a1=None, add2=None, a2=None, dots=None, beta_acc=0.0,
+                  variant=0):
     """dx = LN'(A . Wt^T; x, mean, rstd, gamma) + a1*add1 + a2*add2 in one kernel (include/uvc_kernels.h: uvc_gemm_nt_lnbwd), then the
     batched finish of dgamma / dbeta / dots."""
     _chk(A, Wt, x, mean, rstd, gamma, dx, partial, dgamma, dbeta, add1, a1, add2, a2, dots)
     a = L.uvc_gemm_lnbwd_args()
     a.A, a.W, a.x, a.mean, a.rstd, a.gamma = (L.ptr(t) for t in (A, Wt, x, mean, rstd, gamma))
     a.add1, a.a1, a.add2, a.a2, a.dx, a.partial = (L.ptr(t) for t in (add1, a1, add2, a2, dx, partial))
-    a.M, a.D, a.K, a.dtype = A.shape[0], x.shape[1], A.shape[1], UVC_BF16
+    a.M, a.D, a.K, a.dtype, a.variant = A.shape[0], x.shape[1], A.shape[1], UVC_BF16, int(variant)
     L.check(L.lib().uvc_gemm_nt_lnbwd(C.byref(a), L.cur_stream()), "uvc_gemm_nt_lnbwd")
     item = (L.uvc_ln_reduce_item * 1)()
     item[0].partial, item[0].dgamma, item[0].dbeta, item[0].dots = L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dots)

@@ -230,6 +230,8 @@ def main(argv=None):
             logits, _ = model(x)
             hit += int((logits.argmax(dim=1) == t).sum())
             n += len(t)
+        from .model_distilled import drop_shared_patches
+        drop_shared_patches()
         return 100.0 * (hit + 1e-3) / max(n, 1)          # + epsilon: the first epoch always beats best_acc = 0 and saves (:393-397)
 
     best = post_training(tr, batches, epochs=args.epochs, valid_fn=valid_fn if args.eval_steps > 0 else None,

@@ -48,6 +48,18 @@ def default_args(**over) -> Namespace:
     return Namespace(**a)
 
 
+def _bits_fingerprint(t, chunk=1 << 22):
+    """64-bit hash of a float32 tensor's bit pattern: sum_i (i mod 65521 + 1) * bits_i in wrapping int64 arithmetic, chunked so that
+    the temporaries stay at 2 x chunk x 8 bytes whatever the model size."""
+    v = t.detach().reshape(-1).view(torch.int32)
+    acc = torch.zeros((), dtype=torch.int64, device=v.device)
+    for o in range(0, v.numel(), chunk):
+        c = v[o:o + chunk].to(torch.int64)
+        w = (torch.arange(o, o + c.numel(), device=v.device, dtype=torch.int64) % 65521) + 1
+        acc += (c * w).sum()
+    return acc
+
+
 class Stage1Trainer:
     def __init__(self, args: Namespace, device="cuda", student_state=None, teacher_state=None, distributed=False):
         if not args.enable_pruning:
@@ -141,6 +153,9 @@ class Stage1Trainer:
         a, mm = self.args, self.minimax
         self.epoch = epoch
         self.gating_grad_list = []
+        # the reference counts accumulation windows with the loader index of the epoch, `(step + 1) % k` (:423): a window never straddles
+        # an epoch boundary; gradients of an unfinished window stay in .grad (zero_grad sits inside the `if`) and join the next one
+        self._micro = 0
         # The reference keys the warm-up phase on the epoch alone (:343): --enable_warmup never reaches the model
         # (`enable_warmpup` typo in build_minimax_model's kwargs), so `--enable_warmup 0 --warmup_epochs 5` still warms up.
         if epoch <= a.warmup_epochs:
@@ -199,14 +214,15 @@ class Stage1Trainer:
 
     def check_replicas(self):
         """Data-parallel invariant: every rank holds bit-identical parameters and primal / dual state (the reference assumes it and
-        cannot tell when it breaks).  One all-gather of a 3-number fingerprint; raises on the first divergence.  No-op on one rank."""
+        cannot tell when it breaks).  One all-gather of two 64-bit hashes of the raw float32 BIT PATTERNS (position-weighted integer sums in
+        chunks: no float64 copies of the parameters, and a test of bit identity rather than of sums); raises on the first divergence.
+        No-op on one rank."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return True
         mm = self.minimax
-        state = torch.cat([mm.s.data.flatten(), mm.r.data.flatten(), mm.y.data.flatten(), mm.p.data.flatten(), mm.z.data.flatten()]).double()
-        w = self.model._flat.double()
-        fp = torch.stack([w.sum(), (w * w).sum(), (state * torch.arange(1, state.numel() + 1, device=state.device)).sum()])
+        state = torch.cat([mm.s.data.flatten(), mm.r.data.flatten(), mm.y.data.flatten(), mm.p.data.flatten(), mm.z.data.flatten()]).contiguous()
+        fp = torch.stack([_bits_fingerprint(self.model._flat), _bits_fingerprint(state)])
         allfp = [torch.empty_like(fp) for _ in range(dist.get_world_size())]
         dist.all_gather(allfp, fp)
         if not all(torch.equal(allfp[0], t) for t in allfp):
@@ -233,6 +249,8 @@ class Stage1Trainer:
             nb += 1
             n += x.shape[0]
         model.train()
+        from .model_distilled import drop_shared_patches
+        drop_shared_patches()                 # a pass by one model alone leaves a pending patch-row entry behind
         return dict(loss=float(loss_sum) / max(nb, 1), top1=100.0 * float(hit) / max(n, 1), images=n)
 
     # -- resumable training state.  The reference's checkpoint is the bare model state_dict and it cannot

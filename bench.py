@@ -137,6 +137,20 @@ def pmc_traffic(key):
     return best
 
 
+def pmc_mfma():
+    """Matrix-pipe utilisation per kernel key from the newest rocprofv3 SQ pass committed under profiles/ (tools/pmc_mfma.py:
+    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)); {} when no pass is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma.json")))
+    if not files:
+        return {}, None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return {}, None
+    return d.get("kernels", {}), f"{os.path.basename(files[-1])} @ {d.get('commit')}"
+
+
 def in_step_top():
     """Row 1 of the newest committed in-step rocprofv3 table (profiles/*_kernel_stats_uvc_train_steps_only.csv): the kernel with the
     largest summed duration INSIDE the step.  Reported next to `roofline` because the two rankings differ by construction: the step
@@ -185,7 +199,14 @@ def kernel_table(args):
         r["frac_of_mix_ceiling"] = round(r["gbs"] / r["hbm_mix_ceiling_gbs"], 4) if r.get("hbm_mix_ceiling_gbs") and r["bound"] == "hbm" else None
     roof["hbm_mix_ceiling"] = top.get("hbm_mix_ceiling_gbs")
     roof["frac_of_mix_ceiling"] = top.get("frac_of_mix_ceiling")
-    keep = ("key", "calls", "us", "us_per_step", "bytes", "gbs", "tflops", "bound", "frac", "write_share", "hbm_mix_ceiling_gbs", "frac_of_mix_ceiling")
+    mf, mf_src = pmc_mfma()
+    for r in rows:
+        e = mf.get(r["key"])
+        r["mfma_busy_frac"] = e.get("mfma_busy_frac") if e else None
+    roof["mfma_busy_frac"] = top.get("mfma_busy_frac")
+    roof["mfma_busy_source"] = mf_src
+    keep = ("key", "calls", "us", "us_per_step", "bytes", "gbs", "tflops", "bound", "frac", "write_share", "hbm_mix_ceiling_gbs", "frac_of_mix_ceiling",
+            "mfma_busy_frac")
     return roof, [{k: r[k] for k in keep} for r in rows[:10]], round(sum(r["us_per_step"] for r in rows) / 1e3, 2)
 
 

@@ -28,6 +28,11 @@ from stage1_driver import Stage1Run
 pytestmark = pytest.mark.gpu
 
 BATCH = 32
+# Per-tensor relative L2 error of a bf16-mode gradient against the oracle's float32 autograd.  Measured on the round-2 kernels (float32
+# residual stream): max 1.34 % (blocks.1.norm1.weight), median 0.82 %; streaming against generic kernels: max 1.1 % (patch_embed.proj.weight,
+# the deepest gradient) -- that is the rounding noise of bf16 operands.  The bound is ~2x the measured maximum, so that a change of format
+#  or a wrong kernel cannot hide inside it; a 2 % scaling of one GEMM's output fails it (profiles/r3_perturbation_demo.txt).
+TOL_GRAD_BF16 = 2.5e-2
 
 
 def _recipe():
@@ -95,7 +100,7 @@ def _check_against_oracle(run, out, grads, S, o, tol_grad, tol_out, tol_state, w
     mm = run.minimax
     for k, ref in (("s", S.st.s), ("r", S.st.r), ("y", S.st.y), ("p", S.st.p)):
         np.testing.assert_allclose(getattr(mm, k).data.cpu().numpy(), ref.numpy(), rtol=tol_state, atol=1e-6, err_msg=f"{what} {k}")
-    assert abs(float(mm.z) - float(S.st.z)) <= 1e-4 * abs(float(S.st.z)), (what, "z")
+    assert abs(float(mm.z.detach()) - float(S.st.z)) <= 1e-4 * abs(float(S.st.z)), (what, "z")
     assert abs(float(out["cur"]) - float(o["cur_resource"])) <= 1e-4, (what, "cur_resource")
     np.testing.assert_allclose(out["g"].numpy(), S.params["block_skip_gating"].numpy(), rtol=tol_state, atol=1e-6, err_msg=f"{what} gate logits")
     return worst
@@ -117,7 +122,7 @@ def test_tiny_step_matches_oracle_at_streaming_batch(oracle):
     """bf16 throughput mode, kernels picked by shape (M = 6304: every streaming / LDS-DMA kernel of the bench step runs)."""
     S, o = oracle
     run, out, grads = _hip_step("bf16")
-    worst = _check_against_oracle(run, out, grads, S, o, tol_grad=6e-2, tol_out=2e-2, tol_state=2e-2, what="bf16 streaming")
+    worst = _check_against_oracle(run, out, grads, S, o, tol_grad=TOL_GRAD_BF16, tol_out=2e-2, tol_state=2e-2, what="bf16 streaming")
     for l, ((k1, k3), (r1, r3)) in enumerate(zip(_masks(run), _oracle_keep(S))):
         assert torch.equal(k1.bool(), r1.bool()) and torch.equal(k3.bool(), r3.bool()), f"mask index set of layer {l} differs from the oracle"
     print("per-tensor gradient error vs oracle, bf16 streaming kernels: max %.4f (%s), median %.4f" %
@@ -131,7 +136,7 @@ def test_tiny_step_streaming_and_generic_kernels_agree_per_tensor(oracle):
     S, o = oracle
     run_s, out_s, g_s = _hip_step("bf16")
     run_g, out_g, g_g = _hip_step("bf16", force_generic=1, fuse_next_ln=False)
-    _check_against_oracle(run_g, out_g, g_g, S, o, tol_grad=6e-2, tol_out=2e-2, tol_state=2e-2, what="bf16 generic")
+    _check_against_oracle(run_g, out_g, g_g, S, o, tol_grad=TOL_GRAD_BF16, tol_out=2e-2, tol_state=2e-2, what="bf16 generic")
     diff = {n: _rel(g_s[n], g_g[n]) for n in g_s if g_s[n] is not None}
     bad = {k: round(v, 5) for k, v in diff.items() if v > (2e-2 if k != "block_skip_gating" else 8e-2)}
     assert not bad, ("streaming vs generic kernels", bad)
@@ -143,11 +148,13 @@ def test_tiny_step_streaming_and_generic_kernels_agree_per_tensor(oracle):
 
 def test_tiny_step_register_staged_streaming_kernels_match_the_rings(oracle):
     """force_generic = 2: the streaming kernels in their register-staged forms (k_gemm_wsn16, k_gemm_wsn_lnbwd) instead of the LDS-DMA
-    rings.  Same accumulation order and epilogue arithmetic: the gradients agree to float32 summation order."""
+    rings.  Same accumulation order and epilogue arithmetic; the forward is bit-identical, the gradients agree to the rounding of the bf16
+    gradient stream."""
     run_s, out_s, g_s = _hip_step("bf16")
     run_r, out_r, g_r = _hip_step("bf16", force_generic=2)
     diff = {n: _rel(g_s[n], g_r[n]) for n in g_s if g_s[n] is not None}
-    assert max(diff.values()) <= 2e-3, {k: v for k, v in diff.items() if v > 2e-3}
+    # (bf16 gradient streams: a last-bit float32 difference moves a bf16 rounding by 2^-8 of that element; measured max 0.38 %)
+    assert max(diff.values()) <= 8e-3, {k: v for k, v in diff.items() if v > 8e-3}
     assert float(out_s["loss"]) == float(out_r["loss"])
 
 

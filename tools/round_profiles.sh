@@ -23,6 +23,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/rp_$C && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/rp_$C -o p -- python "$R/tools/kernel_table.py" > /dev/null 2> "$OUT/pmc_$C.err"
 done
 python "$R/tools/pmc_traffic.py" /tmp/rp_FETCH_SIZE /tmp/rp_WRITE_SIZE "$OUT/pmc_traffic.json" "$COMMIT"
+# 4. one SQ pass (matrix-pipe utilisation per kernel; kernel trace only)         -> pmc_mfma.json
+rm -rf /tmp/rp_MFMA && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d /tmp/rp_MFMA -o p -- python "$R/tools/kernel_table.py" > /dev/null 2> "$OUT/pmc_MFMA.err"
+python "$R/tools/pmc_mfma.py" /tmp/rp_MFMA "$OUT/pmc_mfma.json" "$COMMIT" > "$OUT/pmc_mfma.txt" 2>&1; cat "$OUT/pmc_mfma.txt"
 for C in FETCH_SIZE WRITE_SIZE; do
   f=$(find /tmp/rp_$C -name "*counter_collection.csv" | head -1)
   python - "$f" "$OUT/pmc_${C}_kernel_table.csv" $C <<'EOF'

@@ -54,7 +54,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE config 2)")
     p.add_argument("--model_type", default="deit_tiny_patch16_224")
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "bf16_f32resid", "fp32"],
+                   help="bf16 = the throughput mode (bf16 operands AND bf16 residual-stream rows); bf16_f32resid = rounds 1-2's float32 residual rows (A/B)")
     p.add_argument("--stage", type=int, default=1, choices=[1, 2],
                    help="1 = the headline Stage-1 UVC-train step; 2 = the Stage-2 masked fine-tune step (SURVEY §8 f-1)")
     p.add_argument("--no_cpu_baseline", action="store_true")
@@ -180,7 +181,7 @@ def kernel_table(args):
     # are in the rocprofv3 tables under profiles/
     D, H, L, F = {"deit_tiny_patch16_224": (192, 3, 12, 768), "deit_small_patch16_224": (384, 6, 12, 1536), "deit_base_patch16_224": (768, 12, 12, 3072),
                   "t2t_vit_14": (384, 6, 14, 1152)}[args.model_type]
-    rows = KT.measure(KT.build(args.batch, D=D, H=H, L=L, F=F, tail=not args.full_tail), iters=20)
+    rows = KT.measure(KT.build(args.batch, D=D, H=H, L=L, F=F, tail=not args.full_tail, resid_f32=(args.precision == "bf16_f32resid") or None), iters=20)
     rows.sort(key=lambda r: -r["us_per_step"])
     top = rows[0]
     ridge = PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS          # flop per byte where the two roofs meet (312)
@@ -345,7 +346,7 @@ def main():
                 "ms_per_step_device": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3)},
                 "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+                "dtype": "bf16" if args.precision.startswith("bf16") else "f32", "data": "synthetic",
                 "config": {"workload": (f"{args.model_type} Stage-1 UVC-train step, budget 0.5, per-GPU batch {args.batch}, "
                                         f"224x224x3 synthetic, soft distillation alpha 0.1, block gating on") if args.stage == 1 else
                                        (f"{args.model_type} Stage-2 masked fine-tune step, per-GPU batch {args.batch}, masks at the "
@@ -353,6 +354,7 @@ def main():
                            "global_batch": world * args.batch, "parallelism": f"dp{world}"},
                 "step_tflops_per_gpu": round(imgs / world * gf / 1e3, 2) if gf else None,
                 "step_frac_of_bf16_mfma_peak": round(imgs / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,
+                "residual_stream": "float32" if (args.precision != "bf16" or os.environ.get("UVC_RESID_F32", "0") not in ("", "0")) else "bf16",
                 "final_loss": round(loss, 4)}
         if args.stage == 1:
             line["cur_resource"] = round(float(out["cur"]), 4)
@@ -389,7 +391,7 @@ def main():
                 tr.step(x, y)
             torch.cuda.synchronize()
             line["warmup_phase_images_per_sec"] = round(20 * args.batch / (time.perf_counter() - tw), 1)
-        if args.stage == 1 and args.precision == "bf16" and args.model_type in GFLOP_PER_IMG:
+        if args.stage == 1 and args.precision.startswith("bf16") and args.model_type in GFLOP_PER_IMG:
             del tr, out
             torch.cuda.empty_cache()
             roof, top, total_ms = kernel_table(args)

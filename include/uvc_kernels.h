@@ -40,8 +40,8 @@ typedef struct uvc_gemm_nt_args {
   void* C;             /* [M,N]  T, or float32 when c_is_f32 */
   void* C2;            /* second output of UVC_EPI_BIAS_GELU / _GELU_GRAD, same type/ld as C */
   const float* bias;   /* [N] */
-  const float* R;      /* [M,N] float32 residual */
-  const float* R2;     /* [M,N] float32, gate epilogue */
+  const void* R;       /* [M,N] residual rows, element type of C (float32 stream: c_is_f32; bf16 stream: C, R, R2 all bf16) */
+  const void* R2;      /* [M,N] gate epilogue, same type */
   const void* aux;     /* [M,N] T: pre-activation for UVC_EPI_DGELU, multiplier for UVC_EPI_MUL_AUX */
   const float* gate;   /* device float[2] = (g0, g1) block-gate distribution */
   const float* alpha_ptr; /* optional device scalar multiplied into alpha */
@@ -53,7 +53,8 @@ typedef struct uvc_gemm_nt_args {
                              the same epilogue arithmetic) */
   /* optional second output of the residual epilogues where uvc_gemm_nt_ln_supported(): ln_out[M,N] (T) = LayerNorm(C rows; ln_gamma,
    * ln_beta, ln_eps) -- norm1 of the next block on the rows fc2 + residual (+ gate mix) just produced (model_distilled.py:241-244) --
-   * and its float32 statistics ln_mean / ln_rstd [M] (both or neither).  Needs alpha == 1, contiguous A / R (lda == K, ldr == N). */
+   * and its float32 statistics ln_mean / ln_rstd [M] (both or neither).  Needs alpha == 1, contiguous A / R (lda == K, ldr == N).
+   * With a bf16 C the LayerNorm is taken of the ROUNDED rows (what C holds). */
   float ln_eps;
   const float* ln_gamma; const float* ln_beta; void* ln_out; float* ln_mean; float* ln_rstd;
 } uvc_gemm_nt_args;
@@ -123,7 +124,8 @@ int uvc_copy_row_groups(const void* src, void* dst, int64_t groups, int64_t grou
  * (dense: rows_per_group = 1, group_stride = D; class/dist-token rows only: group_stride = N*D).
  * y is dense [rows, D] of type T (or float32 when y_is_f32); mean/rstd float32 [rows]. */
 typedef struct uvc_ln_args {
-  const float* x; const float* gamma; const float* beta;
+  const void* x;        /* float32, or bf16 with x_lowp (the bf16 residual stream of the throughput mode) */
+  const float* gamma; const float* beta;
   void* y; float* mean; float* rstd;
   /* backward */
   const void* dy;       /* dense [rows, D]; T, or float32 when dy_is_f32 */
@@ -140,6 +142,8 @@ typedef struct uvc_ln_args {
                            all arithmetic and the dots stay float32 */
   int32_t defer_reduce; /* backward: leave the per-block partials of dgamma / dbeta / dots in `partial` (one private region per
                            call) and skip the two small reduction launches; uvc_layernorm_bwd_reduce_batch finishes many calls at once */
+  int32_t x_lowp;       /* x is stored as bf16 (statistics, normalisation and every sum stay float32); D % 64 == 0 only */
+  int32_t reserved;
 } uvc_ln_args;
 /* one deferred uvc_layernorm_bwd call: its partial region and outputs (dots may be NULL) */
 typedef struct uvc_ln_reduce_item { const float* partial; float* dgamma; float* dbeta; float* dots; int32_t nblocks; int32_t reserved; } uvc_ln_reduce_item;
@@ -159,12 +163,12 @@ int uvc_layernorm_bwd_nblocks(int32_t rows);
  * uvc_layernorm_bwd_reduce_batch like a deferred uvc_layernorm_bwd call.  Deterministic (fixed summation orders). */
 typedef struct uvc_gemm_lnbwd_args {
   const void* A; const void* W;                 /* bf16 [M,K], bf16 [D,K] (the W^T shadow of the Linear) */
-  const float* x; const float* mean; const float* rstd; const float* gamma;   /* LayerNorm input [M,D] and saved statistics */
+  const void* x; const float* mean; const float* rstd; const float* gamma;    /* LayerNorm input [M,D] (float32, or bf16 with x_lowp) and saved statistics */
   const void* add1; const float* a1; const void* add2; const float* a2;       /* optional bf16 addends, device scalars (NULL = 1) */
   void* dx; float* partial;
   int32_t M, D, K, dtype;
   int32_t variant;      /* tests/tuning: 0 = LDS-DMA ring where the shape allows, 1 = the register-staged kernel */
-  int32_t reserved;
+  int32_t x_lowp;       /* 1: x is bf16 [M,D] (bf16 residual stream) instead of float32 */
 } uvc_gemm_lnbwd_args;
 int uvc_gemm_lnbwd_supported(int32_t M, int32_t D, int32_t K, int32_t dtype);
 int uvc_gemm_lnbwd_nblocks(int32_t M);
@@ -177,16 +181,18 @@ int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* args, void* stream);
  * Training: all five given -- the same pass stores what the backward reads: h = LayerNorm(x) (bf16 [M, D]), mean / rstd [M],
  * gp = GELU'(a) and u = GELU(a) (bf16 [M, F]); it replaces uvc_layernorm_fwd + two uvc_gemm_nt launches of the step. */
 typedef struct uvc_mlp_args {
-  const float* x; const float* gamma; const float* beta;
+  const void* x; const float* gamma; const float* beta;
   const void* w1; const float* b1; const void* w2; const float* b2;
-  float* out;
+  void* out;
   int32_t M, D, F;
   float eps;
-  const float* x_prev; const float* gate;
+  const void* x_prev; const float* gate;
   void* h; float* mean; float* rstd; void* gp; void* u;
   /* optional: LayerNorm of the OUTPUT rows with the next block's norm1 parameters (model_distilled.py:241 of block l+1),
    * written as compute-dtype rows next_h [M,D] (+ float32 next_mean / next_rstd [M] for a backward) */
   const float* next_gamma; const float* next_beta; void* next_h; float* next_mean; float* next_rstd;
+  int32_t rows_lowp;    /* 1: x, out and x_prev are bf16 rows (bf16 residual stream; out is rounded once, next_h is the LayerNorm of the rounded rows) */
+  int32_t reserved;
 } uvc_mlp_args;
 int uvc_mlp_fused_supported(int32_t D, int32_t F, int32_t dtype);
 int uvc_mlp_fused_fwd(const uvc_mlp_args* args, void* stream);
@@ -231,7 +237,7 @@ int uvc_patchify(const float* x, void* out, int32_t B, int32_t C, int32_t S, int
 /* tokens = cat(cls[, dist], patches * mask) + pos  (model_distilled.py:434-471).
  * pe [B,P,D] float32; row_mask optional [B,P] (patch gating), tok [B,N,D] float32. */
 int uvc_assemble_tokens(const float* pe, const float* cls, const float* dist, const float* pos, const float* row_mask,
-                        float* tok, int32_t B, int32_t P, int32_t D, int32_t ntok, void* stream);
+                        void* tok, int32_t B, int32_t P, int32_t D, int32_t ntok, int32_t tok_lowp /* 1: tok is bf16 */, void* stream);
 /* backward of uvc_assemble_tokens: dpe [B,P,D] (T or f32) = dtok rows * mask; dpos/dcls/ddist = sums over batch
  * (written as beta_acc*old + sum); optional dmask[B,P] = <dtok row, pe row>.  dtok [B,N,D] is float32, or T when
  * dtok_lowp (the bf16 gradient stream of the backward). */

@@ -26,6 +26,11 @@ typedef struct uvc_vit_cfg {
   int32_t dtype;   /* UVC_F32 (exact float32 MFMA) or UVC_BF16 */
   float ln_eps;    /* LayerNorm epsilon; <= 0 selects DeiT's 1e-6 (model_distilled.py:402).  T2T-ViT uses nn.LayerNorm's 1e-5 (t2t_vit.py:111) */
   int32_t no_qkv_bias;  /* 1: attn.qkv has no bias (T2T blocks, transformer_block.py:49); its slot in the flat buffers is never read or written */
+  int32_t resid_f32;    /* UVC_BF16 only.  0 (default): the residual stream -- the rows x_l every block reads and writes (model_distilled.py:240,244,
+                           493) -- is stored as bf16 like every other activation (LayerNorm statistics, the residual additions and the gate mix
+                           are float32 arithmetic on the loaded values; one rounding per stored row): the reference's own half-precision mode keeps
+                           half activations (joint_train.py:283-287).  1: float32 rows as in rounds 1-2 (A/B runs).  UVC_F32 always has float32 rows */
+  int32_t reserved;
 } uvc_vit_cfg;
 
 /* element offsets into the flat parameter / gradient buffers (every tensor 16-byte aligned) */

@@ -118,15 +118,18 @@ def _oracle_keep(S):
     return [(keep1, keep3) for _, _, _, keep1, keep3 in OU.prune_masks(S.st, S.w1(), S.w3())]
 
 
-def test_tiny_step_matches_oracle_at_streaming_batch(oracle):
-    """bf16 throughput mode, kernels picked by shape (M = 6304: every streaming / LDS-DMA kernel of the bench step runs)."""
+@pytest.mark.parametrize("precision", ["bf16", "bf16_f32resid"])
+def test_tiny_step_matches_oracle_at_streaming_batch(oracle, precision):
+    """bf16 throughput mode, kernels picked by shape (M = 6304: every streaming / LDS-DMA kernel of the bench step runs); with the bf16
+    residual stream (the default) and with the float32 residual rows of rounds 1-2, both inside the SAME per-tensor bound."""
     S, o = oracle
-    run, out, grads = _hip_step("bf16")
-    worst = _check_against_oracle(run, out, grads, S, o, tol_grad=TOL_GRAD_BF16, tol_out=2e-2, tol_state=2e-2, what="bf16 streaming")
+    run, out, grads = _hip_step(precision)
+    assert run.model.resid_f32 == (precision == "bf16_f32resid") and run.teacher.resid_f32 == run.model.resid_f32
+    worst = _check_against_oracle(run, out, grads, S, o, tol_grad=TOL_GRAD_BF16, tol_out=2e-2, tol_state=2e-2, what=precision + " streaming")
     for l, ((k1, k3), (r1, r3)) in enumerate(zip(_masks(run), _oracle_keep(S))):
         assert torch.equal(k1.bool(), r1.bool()) and torch.equal(k3.bool(), r3.bool()), f"mask index set of layer {l} differs from the oracle"
-    print("per-tensor gradient error vs oracle, bf16 streaming kernels: max %.4f (%s), median %.4f" %
-          (max(worst.values()), max(worst, key=worst.get), float(np.median(list(worst.values())))))
+    print("per-tensor gradient error vs oracle, %s streaming kernels: max %.4f (%s), median %.4f; loss %.6f vs %.6f" %
+          (precision, max(worst.values()), max(worst, key=worst.get), float(np.median(list(worst.values()))), float(out["loss"]), float(o["loss"])))
 
 
 def test_tiny_step_streaming_and_generic_kernels_agree_per_tensor(oracle):

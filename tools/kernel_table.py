@@ -22,11 +22,13 @@ import torch  # noqa: E402
 from uvc_amd import ops  # noqa: E402
 
 
-def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
+def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resid_f32=None):
     """tail=True (the engine's default, uvc_vit_io.full_tail = 0): the last block runs everything behind its qkv projection on the
     B class-token rows only, so the full-row kernels of that part launch L - 1 times per pass and the token-query attention once;
     the proj / MLP GEMMs on B rows are a few microseconds each and are not listed."""
     F, M = (F or 4 * D), B * N
+    if resid_f32 is None:           # the engine's default (uvc_vit_cfg.resid_f32): bf16 residual-stream rows unless UVC_RESID_F32=1
+        resid_f32 = os.environ.get("UVC_RESID_F32", "0") not in ("", "0")
     Lf = L - 1 if tail else L          # launches per pass of the full-row kernels behind the qkv projection
     dev = "cuda"
     bf = torch.bfloat16
@@ -41,8 +43,8 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
              "dfc2": 4 / 9, "dfc1+ln2_bwd": 1 / 8, "dqkv+ln1_bwd": 1 / 8, "dfc1": 0.2, "dqkv": 0.25, "ln_bwd": 0.2, "dproj": 0.5, "attn_bwd": 0.25,
              "dW": 0.15, "clip+adamw": 0.45}
 
-    def add(key, rocprof, calls, nbytes, flops, fn):
-        wf = next((v for k, v in WFRAC.items() if key.startswith(k)), None)
+    def add(key, rocprof, calls, nbytes, flops, fn, wfrac=None):
+        wf = wfrac if wfrac is not None else next((v for k, v in WFRAC.items() if key.startswith(k)), None)
         rows.append(dict(key=key, rocprof=rocprof, calls=calls, bytes=int(nbytes), flops=float(flops), fn=fn, wfrac=wf))
 
     g = torch.Generator(device=dev).manual_seed(1)
@@ -59,6 +61,9 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
     gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
     mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)
     u = 2 * M * D                     # bytes of one bf16 [M, D] tensor
+    ru = 2 * u if resid_f32 else u    # bytes of one [M, D] tensor of residual-stream rows (x_l, x1: float32 in rounds 1-2, bf16 now)
+    rdt = torch.float32 if resid_f32 else bf
+    xr, gr_ = x32.to(rdt), g32.to(rdt)      # residual-stream operands (R, R2, LayerNorm inputs)
 
     # ---- forward (student; the teacher repeats LayerNorm1, qkv, attention, proj and runs the fused MLP)
     y = torch.empty(M, D, device=dev, dtype=bf)
@@ -68,7 +73,7 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
     # block 0's norm1 is a pass of its own (the final norms and the last block's token-row norm2 run on B rows: not listed)
     fuse_ln = tiny
     n_ln1 = 1 if fuse_ln else L
-    add("ln_fwd", "k_ln_fwd_v", (1 + T) * n_ln1 + (0 if fuse_ln else Lf), 3 * u, 0, lambda: ops.layernorm_fwd(x32, gam, bet, y, m_, r_, M, D, dt))
+    add("ln_fwd", "k_ln_fwd_v", (1 + T) * n_ln1 + (0 if fuse_ln else Lf), ru + u, 0, lambda: ops.layernorm_fwd(xr, gam, bet, y, m_, r_, M, D, dt), wfrac=u / (ru + u))
     qkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
     add("qkv", "k_gemm_ws<unsigned short, unsigned short, 1" if tiny else "k_gemm", (1 + T) * L, 4 * u, 2.0 * M * D * 3 * D,
         lambda: ops.gemm_nt(xb, Wqkv, qkv, dtype=dt, epilogue=ops.EPI_BIAS, bias=b3))
@@ -82,27 +87,28 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
         dq_t = torch.empty(B, N, 3 * D, device=dev, dtype=bf)
         add("attn_tok_fwd (last block)", "k_attn_tok_fwd", 1 + T, 2 * u, 0, lambda: ops.attention_tok_fwd(qkv3, oc, B, N, H, 1, dt))
         add("attn_tok_bwd (last block)", "k_attn_tok_bwd", 1, 5 * u, 0, lambda: ops.attention_tok_bwd(qkv3, oc, doc, dq_t, B, N, H, 1, dt))
-    o32 = torch.empty(M, D, device=dev)
+    o32 = torch.empty(M, D, device=dev, dtype=rdt)      # output rows of the residual stream
     # student at DeiT-Tiny width: norm2 leaves with attn.proj's rows (the teacher's fused MLP normalises its rows itself)
     if fuse_ln:
-        add("proj+resid+norm2", "k_gemm_wsn16_dma<3, 6", Lf, 6 * u, 2.0 * M * D * D,
-            lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=x32, ln_gamma=gam, ln_beta=bet, ln_out=y, ln_mean=m_, ln_rstd=r_))
+        add("proj+resid+norm2", "k_gemm_wsn16_dma<3, 6", Lf, 2 * u + 2 * ru, 2.0 * M * D * D,
+            lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=xr, ln_gamma=gam, ln_beta=bet, ln_out=y, ln_mean=m_, ln_rstd=r_),
+            wfrac=(ru + u) / (2 * u + 2 * ru))
     if not fuse_ln or T:
-        add("proj+resid", "k_gemm_wsn16_dma<3, 6, false" if tiny else "k_gemm", (T if fuse_ln else 1 + T) * Lf, 5 * u, 2.0 * M * D * D,
-            lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=x32))
+        add("proj+resid", "k_gemm_wsn16_dma<3, 6, false" if tiny else "k_gemm", (T if fuse_ln else 1 + T) * Lf, u + 2 * ru, 2.0 * M * D * D,
+            lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=xr), wfrac=ru / (u + 2 * ru))
     aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
     add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
         lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu))
     if fuse_ln:
-        add("fc2+resid+gate+norm1", "k_gemm_wsn16_dma<4", Lf, 11 * u, 2.0 * M * D * F,
-            lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate,
-                                ln_gamma=gam, ln_beta=bet, ln_out=y, ln_mean=m_, ln_rstd=r_))
+        add("fc2+resid+gate+norm1", "k_gemm_wsn16_dma<4", Lf, 5 * u + 3 * ru, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=xr, R2=gr_, gate=gate,
+                                ln_gamma=gam, ln_beta=bet, ln_out=y, ln_mean=m_, ln_rstd=r_), wfrac=(ru + u) / (5 * u + 3 * ru))
     else:
-        add("fc2+resid+gate", "k_gemm", Lf, 10 * u, 2.0 * M * D * F,
-            lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=x32, R2=g32, gate=gate))
+        add("fc2+resid+gate", "k_gemm", Lf, 4 * u + 3 * ru, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=xr, R2=gr_, gate=gate), wfrac=ru / (4 * u + 3 * ru))
     if tiny and with_teacher:
-        add("teacher mlp_fused+norm1", "k_mlp_fused", Lf, 5 * u, 4.0 * M * D * F,
-            lambda: ops.mlp_fused_fwd(x32, gam, bet, W1, bF, W2, bD, o32, next_gamma=gam, next_beta=bet, next_h=y))
+        add("teacher mlp_fused+norm1", "k_mlp_fused", Lf, u + 2 * ru, 4.0 * M * D * F,
+            lambda: ops.mlp_fused_fwd(xr, gam, bet, W1, bF, W2, bD, o32, next_gamma=gam, next_beta=bet, next_h=y), wfrac=(ru + u) / (u + 2 * ru))
     # ---- backward, main stream
     dA = torch.empty(M, F, device=dev, dtype=bf)
     add("dfc2 x gelu'", "k_gemm_ws<unsigned short, unsigned short, 8" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
@@ -113,17 +119,17 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None):
     q3 = rn(M, 3 * D).to(bf)
     if ops.gemm_lnbwd_supported(M, D, F, dt):
         W2t, Wqt = (rn(D, F) * .02).to(bf), (rn(D, 3 * D) * .02).to(bf)
-        add("dfc1+ln2_bwd", "k_gemm_wsn_lnbwd_dma<24", Lf, 8 * u, 2.0 * M * D * F,
-            lambda: ops.gemm_nt_lnbwd(hF, W2t, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, a1=gate[1:]))
-        add("dqkv+ln1_bwd", "k_gemm_wsn_lnbwd_dma<18", L, 8 * u, 2.0 * M * D * 3 * D,
-            lambda: ops.gemm_nt_lnbwd(q3, Wqt, x32, mean, rstd, gam, dx16, part, dg, db, add1=g16, add2=add16, a2=gate[:1], dots=dots))
+        add("dfc1+ln2_bwd", "k_gemm_wsn_lnbwd_dma<24", Lf, 6 * u + ru, 2.0 * M * D * F,
+            lambda: ops.gemm_nt_lnbwd(hF, W2t, xr, mean, rstd, gam, dx16, part, dg, db, add1=g16, a1=gate[1:]), wfrac=u / (6 * u + ru))
+        add("dqkv+ln1_bwd", "k_gemm_wsn_lnbwd_dma<18", L, 6 * u + ru, 2.0 * M * D * 3 * D,
+            lambda: ops.gemm_nt_lnbwd(q3, Wqt, xr, mean, rstd, gam, dx16, part, dg, db, add1=g16, add2=add16, a2=gate[:1], dots=dots), wfrac=u / (6 * u + ru))
     else:
         dH = torch.empty(M, D, device=dev, dtype=bf)
         Wt = (rn(D, 3 * D) * .02).to(bf)
         add("dfc1", "k_gemm", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_nt(hF, W2, dH, dtype=dt, epilogue=ops.EPI_NONE))
         add("dqkv", "k_gemm", L, 4 * u, 2.0 * M * D * 3 * D, lambda: ops.gemm_nt(q3, Wt, dH, dtype=dt, epilogue=ops.EPI_NONE))
-        add("ln_bwd", "k_ln_bwd_v", L + Lf, 5.5 * u, 0,
-            lambda: ops.layernorm_bwd(xb, x32, gam, mean, rstd, dx16, part, dg, db, M, D, dt, add1=g16, a1=gate[1:]))
+        add("ln_bwd", "k_ln_bwd_v", L + Lf, 3.5 * u + ru, 0,
+            lambda: ops.layernorm_bwd(xb, xr, gam, mean, rstd, dx16, part, dg, db, M, D, dt, add1=g16, a1=gate[1:]))
     dH2 = torch.empty(M, D, device=dev, dtype=bf)
     add("dproj", "k_gemm_ws<unsigned short, unsigned short, 0" if tiny else "k_gemm", Lf, 2 * u, 2.0 * M * D * D,
         lambda: ops.gemm_nt(g16, Wp, dH2, dtype=dt, epilogue=ops.EPI_NONE))

@@ -73,19 +73,20 @@ class uvc_ln_args(C.Structure):
                                           "a2", "partial", "dgamma", "dbeta", "dots")] + \
                [("eps", C.c_float), ("beta_acc", C.c_float)] + \
                [(n, C.c_int32) for n in ("rows", "D", "rows_per_group", "dtype", "y_is_f32", "dy_is_f32")] + \
-               [("group_stride", C.c_int64), ("g_lowp", C.c_int32), ("defer_reduce", C.c_int32)]
+               [("group_stride", C.c_int64), ("g_lowp", C.c_int32), ("defer_reduce", C.c_int32), ("x_lowp", C.c_int32), ("reserved", C.c_int32)]
 
 
 class uvc_gemm_lnbwd_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("A", "W", "x", "mean", "rstd", "gamma", "add1", "a1", "add2", "a2", "dx", "partial")] + \
-               [(n, C.c_int32) for n in ("M", "D", "K", "dtype", "variant", "reserved")]
+               [(n, C.c_int32) for n in ("M", "D", "K", "dtype", "variant", "x_lowp")]
 
 
 class uvc_mlp_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "gamma", "beta", "w1", "b1", "w2", "b2", "out")] + \
                [(n, C.c_int32) for n in ("M", "D", "F")] + [("eps", C.c_float)] + \
                [(n, C.c_void_p) for n in ("x_prev", "gate", "h", "mean", "rstd", "gp", "u",
-                                          "next_gamma", "next_beta", "next_h", "next_mean", "next_rstd")]
+                                          "next_gamma", "next_beta", "next_h", "next_mean", "next_rstd")] + \
+               [("rows_lowp", C.c_int32), ("reserved", C.c_int32)]
 
 
 class uvc_loss_args(C.Structure):
@@ -151,7 +152,7 @@ _SIGNATURES = {
     "uvc_adamw_step": [C.POINTER(uvc_adamw_args), VP],
     "uvc_scale_by_clip": [VP, I64, VP, F32, VP],
     "uvc_patchify": [VP, VP, I32, I32, I32, I32, I32, VP],
-    "uvc_assemble_tokens": [VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, VP],
+    "uvc_assemble_tokens": [VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, I32, VP],
     "uvc_assemble_tokens_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, I32, I32, I32, I32, I32, I32, I32, F32, VP],
     "uvc_colsum": [VP, I32, I32, I32, I32, I32, VP, VP, F32, VP, F32, VP, VP],
     "uvc_patch_gate_sigmoid": [VP, VP, I32, I32, I32, VP],

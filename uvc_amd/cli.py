@@ -71,7 +71,8 @@ def build_parser():
     a("--warmup_lr", default=1e-4, type=float); a("--warmup_reset", default=0, type=int)
     a("--gpu_num", type=str, default="0, 1")
     # engine-specific (not in the reference)
-    a("--precision", default="bf16", choices=["bf16", "fp32"], help="bf16 MFMA (throughput) or exact float32 MFMA (parity)")
+    a("--precision", default="bf16", choices=["bf16", "bf16_f32resid", "fp32"],
+      help="bf16 MFMA (throughput; bf16_f32resid keeps float32 residual-stream rows) or exact float32 MFMA (parity)")
     a("--synthetic", type=int, default=1, help="synthetic ImageNet-shaped batches (no torchvision in this image)")
     a("--steps_per_epoch", type=int, default=5005, help="len(train_loader) for synthetic data (ImageNet @256 = 5005)")
     a("--num_classes", type=int, default=1000)

@@ -23,9 +23,11 @@ __global__ __launch_bounds__(256) void k_patchify(const float* __restrict__ x, T
 }
 
 // ---------------------------------------------------------------------------- token assembly
+// TK: element type of the token rows (the residual stream): float32, or bf16 in the throughput mode
+template <typename TK>
 __global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ pe, const float* __restrict__ cls,
                                                   const float* __restrict__ dist, const float* __restrict__ pos,
-                                                  const float* __restrict__ mask, float* __restrict__ tok, int B, int P, int D,
+                                                  const float* __restrict__ mask, TK* __restrict__ tok, int B, int P, int D,
                                                   int ntok) {
   const int N = P + ntok, D4 = D / 4;
   const int64_t total = (int64_t)B * N * D4;
@@ -40,7 +42,9 @@ __global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ pe, 
     }
     const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (size_t)t * D + d4 * 4);
     v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
-    *reinterpret_cast<f32x4*>(tok + ((size_t)b * N + t) * D + d4 * 4) = v;
+    TK* o = tok + ((size_t)b * N + t) * D + d4 * 4;
+    if (sizeof(TK) == 4) *reinterpret_cast<f32x4*>(o) = v;
+    else { u32x2 q; q[0] = pack_bf16x2(v[0], v[1]); q[1] = pack_bf16x2(v[2], v[3]); *reinterpret_cast<u32x2*>(o) = q; }
   }
 }
 
@@ -442,9 +446,11 @@ extern "C" int uvc_patchify(const float* x, void* out, int32_t B, int32_t C, int
 }
 
 extern "C" int uvc_assemble_tokens(const float* pe, const float* cls, const float* dist, const float* pos, const float* row_mask,
-                                   float* tok, int32_t B, int32_t P, int32_t D, int32_t ntok, void* stream) {
+                                   void* tok, int32_t B, int32_t P, int32_t D, int32_t ntok, int32_t tok_lowp, void* stream) {
   if (!pe || !cls || !pos || !tok || (ntok == 2 && !dist) || (ntok != 1 && ntok != 2) || D % 4) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_assemble_tokens: bad argument");
-  k_assemble<<<grid_for((int64_t)B * (P + ntok) * D / 4), 256, 0, (hipStream_t)stream>>>(pe, cls, dist, pos, row_mask, tok, B, P, D, ntok);
+  const int grid = grid_for((int64_t)B * (P + ntok) * D / 4);
+  if (tok_lowp) k_assemble<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(pe, cls, dist, pos, row_mask, (bf16_t*)tok, B, P, D, ntok);
+  else k_assemble<float><<<grid, 256, 0, (hipStream_t)stream>>>(pe, cls, dist, pos, row_mask, (float*)tok, B, P, D, ntok);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -1,4 +1,4 @@
-// Fused MLP half of a DeiT block for gfx950 (embed_dim 192, bf16 MFMA, float32 residual stream):
+// Fused MLP half of a DeiT block for gfx950 (embed_dim 192, bf16 MFMA, float32 or bf16 residual stream):
 //     out = d1 * (x1 + fc2(GELU(fc1(LayerNorm(x1))))) + d0 * x_prev        UVC/models/model_distilled.py:107-124,199-204,241-247,493
 // Two instances of one kernel (k_mlp_fused_v3<TRAIN>):
 //   inference (teacher, utils/losses.py:47-49, and eval): nothing but `out` is written; the [M, 768] hidden activation never
@@ -50,8 +50,12 @@ constexpr int V3_OFF_B1 = 2 * V3_BUF;
 constexpr int V3_N1 = V3_FC * 26 / 64, V3_N2 = D * 6 / 64;    // DMA wave-instructions per chunk: 13 + 18
 static_assert(V3_FC * 26 % 64 == 0 && D * 6 % 64 == 0, "whole DMA instructions");
 constexpr int V3_OFF_DUMMY = V3_OFF_B1 + 4096, V3_OFF_GB = V3_OFF_DUMMY + 1024, V3_LDS = V3_OFF_GB + 3 * D * 4;
-constexpr int V3_XS = 50, V3_NXI = (16 * V3_XS + 63) / 64, V3_XTILE = V3_NXI * 1024;     // a wave's 16-row x tile in LDS: 13 KB
-static_assert(V3_NW * V3_XTILE <= 2 * V3_BUF, "row tiles fit the weight buffers");
+// a wave's 16-row x tile in LDS: rows of 48 + 2 slots (float32 residual stream: 800 B, 13 KB per tile) or 24 + 2 (bf16 stream: 416 B, 7 KB);
+// both strides are 8 / 40 words mod 64: conflict-free ds_read_b128 with row = lane & 15
+template <bool RLOW> struct XT {
+  static constexpr int RSZ = RLOW ? 2 : 4, RSL = D * RSZ / 16, XS = RSL + 2, NXI = (16 * XS + 63) / 64, XTILE = NXI * 1024;
+};
+static_assert(V3_NW * XT<false>::XTILE <= 2 * V3_BUF, "row tiles fit the weight buffers");
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_PTR(char))(char*)p; }
 template <int OFF> __device__ __forceinline__ u32x4 ds_rd(unsigned addr) {
@@ -65,8 +69,11 @@ template <int... Is, class Fn> __device__ __forceinline__ void static_for_impl(s
 }
 template <int N, class Fn> __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-template <bool TRAIN>
+// RLOW: x, out, x_prev are bf16 rows (the bf16 residual stream): out is rounded once, at its store, and next_h is the LayerNorm of the
+// ROUNDED rows -- what every consumer of `out` reads
+template <bool TRAIN, bool RLOW>
 __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
+  constexpr int RSZ = XT<RLOW>::RSZ, RSL = XT<RLOW>::RSL, V3_XS = XT<RLOW>::XS, V3_NXI = XT<RLOW>::NXI, V3_XTILE = XT<RLOW>::XTILE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
         const int s = i * 64 + ln, row = s / V3_XS, pc = s % V3_XS;
         int grow = m0 + r * 16 + (row < 16 ? row : 15);
         grow = grow < a.M ? grow : a.M - 1;                          // rows past M: any valid row (masked below, never stored)
-        const unsigned off = (unsigned)grow * (unsigned)(D * 4) + (unsigned)((pc < 48 ? pc : 0) * 16);
+        const unsigned off = (unsigned)grow * (unsigned)(D * RSZ) + (unsigned)((pc < RSL ? pc : 0) * 16);
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(xb + (unsigned long long)off),
                                          (void __attribute__((address_space(3)))*)(xreg + i * 1024), 16, 0, 0);
       }
@@ -116,8 +123,14 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
       f32x4 xv[2 * KT];
 #pragma unroll
       for (int ks = 0; ks < KT; ++ks) {
-        xv[2 * ks] = *reinterpret_cast<const f32x4*>(xrow + (ks * 4 + g) * 32);
-        xv[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xrow + (ks * 4 + g) * 32 + 16);
+        if constexpr (RLOW) {                      // eight consecutive bf16 columns in 16 bytes
+          const u32x4 q = *reinterpret_cast<const u32x4*>(xrow + (ks * 4 + g) * 16);
+          xv[2 * ks] = f32x4{__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16), __uint_as_float(q[1] & 0xffff0000u)};
+          xv[2 * ks + 1] = f32x4{__uint_as_float(q[2] << 16), __uint_as_float(q[2] & 0xffff0000u), __uint_as_float(q[3] << 16), __uint_as_float(q[3] & 0xffff0000u)};
+        } else {
+          xv[2 * ks] = *reinterpret_cast<const f32x4*>(xrow + (ks * 4 + g) * 32);
+          xv[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xrow + (ks * 4 + g) * 32 + 16);
+        }
       }
       float s = 0.f;
 #pragma unroll
@@ -156,7 +169,11 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
       const unsigned b2a = s0 + (unsigned)(V3_OFF_GB + 2 * D * 4 + g * 16);
       static_for<D / 16>([&](auto jv) {
         constexpr int j = jv.value;
-        const f32x4 xr = *reinterpret_cast<const f32x4*>(xrow + (j * 4 + g) * 16);
+        f32x4 xr;
+        if constexpr (RLOW) {
+          const u32x2 q = *reinterpret_cast<const u32x2*>(xrow + (j * 4 + g) * 8);
+          xr = f32x4{__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16), __uint_as_float(q[1] & 0xffff0000u)};
+        } else xr = *reinterpret_cast<const f32x4*>(xrow + (j * 4 + g) * 16);
         u32x4 bq = ds_rd<j * 64>(b2a);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq));
         const f32x4 bv = __builtin_bit_cast(f32x4, bq);
@@ -326,18 +343,26 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
   for (int r = 0; r < RW; ++r) {
     const int row = m0 + r * 16 + li;
     if (row < a.M) {
-      float* orow = a.out + (size_t)row * D;
+      char* orow = reinterpret_cast<char*>(a.out) + (size_t)row * D * RSZ;
 #pragma unroll
       for (int j = 0; j < D / 16; ++j) {
         const int col = j * 16 + g * 4;
         f32x4 o = out[r][j];
         if (a.gate) {
-          const f32x4 xp = *reinterpret_cast<const f32x4*>(a.x_prev + (size_t)row * D + col);
+          f32x4 xp;
+          if constexpr (RLOW) {
+            const u32x2 q = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.x_prev) + (size_t)row * D + col);
+            xp = f32x4{__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16), __uint_as_float(q[1] & 0xffff0000u)};
+          } else xp = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.x_prev) + (size_t)row * D + col);
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(d1, o[e], __builtin_fmaf(d0, xp[e], 0.0f));
-          out[r][j] = o;
         }
-        *reinterpret_cast<f32x4*>(orow + col) = o;
+        if constexpr (RLOW) {
+          u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]);
+          *reinterpret_cast<u32x2*>(orow + col * 2) = q;
+          o = f32x4{__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16), __uint_as_float(q[1] & 0xffff0000u)};
+        } else *reinterpret_cast<f32x4*>(orow + col * 4) = o;
+        out[r][j] = o;                                 // (bf16 stream: the rounded row, which next_h below normalises)
       }
     }
   }
@@ -400,8 +425,10 @@ extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_mlp_fused_fwd: next_mean and next_rstd come together, with next_h");
   hipStream_t st = (hipStream_t)stream;
   {
-    if (train) { UVC_MAX_LDS(V3_LDS, k_mlp_fused_v3<true>); k_mlp_fused_v3<true><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p); }
-    else { UVC_MAX_LDS(V3_LDS, k_mlp_fused_v3<false>); k_mlp_fused_v3<false><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p); }
+#define MLP_ONE(TR_, RL_) { UVC_MAX_LDS(V3_LDS, k_mlp_fused_v3<TR_, RL_>); k_mlp_fused_v3<TR_, RL_><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p); }
+    if (p->rows_lowp) { if (train) MLP_ONE(true, true) else MLP_ONE(false, true) }
+    else { if (train) MLP_ONE(true, false) else MLP_ONE(false, false) }
+#undef MLP_ONE
     UVC_CHECK_LAUNCH();
     return UVC_OK;
   }

@@ -83,7 +83,7 @@ template <> struct OutIO<bf16_t> {
 
 struct NtArgs {
   const void* A; const void* B; void* C; void* C2;
-  const float* bias; const float* R; const float* R2; const void* aux; const float* dptr;
+  const float* bias; const void* R; const void* R2; const void* aux; const float* dptr;      // R, R2: the residual rows, element type of C
   int M, N, K, lda, ldb, ldc, ldr, ldaux;
   float alpha;
   const float* alpha_ptr;   // optional device scalar multiplied into alpha
@@ -122,12 +122,124 @@ template <> __device__ __forceinline__ void load_vec<bf16_t, 4>(const bf16_t* p,
   v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
 }
 
+// Residual operands have the element type of C (float32 stream: 4 floats per 16 bytes; bf16 stream: 8 per 16 bytes, 4 per 8 bytes)
+template <typename TC> struct Resid;
+template <> struct Resid<float> {
+  typedef u32x4 Raw4;                            // four consecutive columns
+  static __device__ __forceinline__ Raw4 ld4(const void* base, size_t elem) { return *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(base) + elem); }
+  static __device__ __forceinline__ f32x4 f4(const Raw4& r) { return __builtin_bit_cast(f32x4, r); }
+  // VN = 4 consecutive columns in 16 bytes
+  static __device__ __forceinline__ void get(const u32x4& r, float* v) { const f32x4 f = __builtin_bit_cast(f32x4, r); v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3]; }
+};
+template <> struct Resid<bf16_t> {
+  typedef u32x2 Raw4;
+  static __device__ __forceinline__ Raw4 ld4(const void* base, size_t elem) { return *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(base) + elem); }
+  static __device__ __forceinline__ f32x4 f4(const Raw4& r) {
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+  }
+  // VN = 8 consecutive columns in 16 bytes
+  static __device__ __forceinline__ void get(const u32x4& r, float* v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(r[e] << 16); v[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+  }
+};
+
 // Epilogue arithmetic with the rounding points spelled out (hipcc contracts a*b + c*d differently from kernel to kernel):
 // every NT kernel computes the same bits for the same accumulator, so a row's result does not depend on which kernel the
 // problem size selects (tests/test_fullsize_gpu.py compares a 512-image run with an 8-image run bit for bit).
 __device__ __forceinline__ float epi_scale_bias(float acc, float alpha, float bias) { return __builtin_fmaf(acc, alpha, bias); }
 __device__ __forceinline__ float epi_gate_mix(float v, float r2, float d0, float d1) { return __builtin_fmaf(d1, v, __builtin_fmaf(d0, r2, 0.0f)); }
 constexpr int EP_LD = 68;   // floats per staged accumulator row (64 + 4 pad: conflict-free 16-byte LDS writes)
+
+// Epilogue of 32 staged accumulator rows x 64 columns of one wave (stg: [32][EP_LD] floats, row r = output row mrow0 + r, columns
+// ncol0 .. ncol0 + 63): scale / bias / residual / gate mix / activation, then 16-byte row-contiguous stores.  Shared by the NT
+// kernels that leave through an LDS transpose, so that a row's bits do not depend on the kernel that produced its accumulator.
+template <typename T, typename TC, int EPI>
+__device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, const float* stg, int lane, int mrow0, int ncol0, float alpha, float d0, float d1) {
+  constexpr int VN = OutVec<TC>::VN;
+  constexpr int LPR = 64 / VN;                  // lanes per 64-column row
+  constexpr int RPI = 64 / LPR;                 // rows per wave instruction
+  TC* __restrict__ C = reinterpret_cast<TC*>(g.C);
+  const int cc = (lane % LPR) * VN;
+  const int n = ncol0 + cc;
+  const bool nfull = (n + VN <= g.N) && ((g.ldc % VN) == 0);
+#pragma unroll
+  for (int it = 0; it < 32 / RPI; ++it) {
+    const int r = it * RPI + lane / LPR;
+    const int m = mrow0 + r;
+    float v[VN];
+    load_vec<float, VN>(stg + r * EP_LD + cc, v);
+    if (m < g.M && n < g.N) {
+      const size_t mo = (size_t)m;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const bool has_bias = EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID ||
+                              EPI == UVC_EPI_BIAS_RESID_GATE || EPI == UVC_EPI_BIAS_GELU_GRAD;
+        v[e] = epi_scale_bias(v[e], alpha, (has_bias && n + e < g.N) ? g.bias[n + e] : 0.f);
+      }
+      if (EPI == UVC_EPI_BIAS_GELU_OUT) {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] = Gelu<T>::f(v[e]);
+      }
+      if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
+        const TC* rp = reinterpret_cast<const TC*>(g.R) + mo * g.ldr + n;
+        float rv[VN];
+        if (nfull && (g.ldr % VN) == 0) load_vec<TC, VN>(rp, rv);
+        else {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) rv[e] = (n + e < g.N) ? ElemIO<TC>::load(rp + e) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] += rv[e];
+      }
+      if (EPI == UVC_EPI_BIAS_RESID_GATE) {
+        const TC* rp = reinterpret_cast<const TC*>(g.R2) + mo * g.ldr + n;
+        float rv[VN];
+        if (nfull && (g.ldr % VN) == 0) load_vec<TC, VN>(rp, rv);
+        else {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) rv[e] = (n + e < g.N) ? ElemIO<TC>::load(rp + e) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] = epi_gate_mix(v[e], rv[e], d0, d1);
+      }
+      if (EPI == UVC_EPI_DGELU || EPI == UVC_EPI_MUL_AUX) {
+        const T* ap = reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n;
+        float av[VN];
+        if (nfull && (g.ldaux % VN) == 0) load_vec<T, VN>(ap, av);
+        else {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) av[e] = (n + e < g.N) ? ElemIO<T>::load(ap + e) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] *= (EPI == UVC_EPI_MUL_AUX) ? av[e] : Gelu<T>::g(av[e]);
+      }
+      float u[VN];
+      if (EPI == UVC_EPI_BIAS_GELU_GRAD) {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { float fo, go; Gelu<T>::fg(v[e], fo, go); u[e] = fo; v[e] = go; }
+      }
+      TC* cp = C + mo * g.ldc + n;
+      if (nfull) OutVec<TC>::st(cp, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) if (n + e < g.N) ElemIO<TC>::store(cp + e, v[e]);
+      }
+      if (EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_GRAD) {
+        TC* c2 = reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n;
+        if (EPI == UVC_EPI_BIAS_GELU) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
+        }
+        if (nfull) OutVec<TC>::st(c2, u);
+        else {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) if (n + e < g.N) ElemIO<TC>::store(c2 + e, u[e]);
+        }
+      }
+    }
+  }
+}
 
 template <typename TA, typename T, typename TC, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
@@ -207,18 +319,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
   // ---- epilogue.  The MFMA leaves lane (l) with row m = (l&15), columns (l>>4)*4+{0..3} of each 16x16
   // tile.  Each wave transposes its 64x64 sub-tile through LDS, 32 rows at a time, so that global
   // accesses are whole 128-byte (bf16) / 256-byte (fp32) row segments: 16 bytes per lane.
-  constexpr int VN = OutVec<TC>::VN;
-  constexpr int LPR = 64 / VN;                  // lanes per 64-column row
-  constexpr int RPI = 64 / LPR;                 // rows per wave instruction
-  TC* __restrict__ C = reinterpret_cast<TC*>(g.C);
   float alpha = g.alpha;
   if (g.alpha_ptr) alpha *= *g.alpha_ptr;
   float d0 = 0.f, d1 = 1.f;
   if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
   float* stg = reinterpret_cast<float*>(smem) + w * (32 * EP_LD);
-  const int cc = (lane % LPR) * VN;
-  const int n = n0 + wn * 64 + cc;
-  const bool nfull = (n + VN <= g.N) && ((g.ldc % VN) == 0);
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -228,82 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<f32x4*>(stg + (ii * 16 + (lane & 15)) * EP_LD + j * 16 + (lane >> 4) * 4) = acc[2 * h + ii][j];
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int r = it * RPI + lane / LPR;
-      const int m = m0 + wm * 64 + h * 32 + r;
-      float v[VN];
-      load_vec<float, VN>(stg + r * EP_LD + cc, v);
-      if (m < g.M && n < g.N) {
-        const size_t mo = (size_t)m;
-#pragma unroll
-        for (int e = 0; e < VN; ++e) {
-          const bool has_bias = EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID ||
-                                EPI == UVC_EPI_BIAS_RESID_GATE || EPI == UVC_EPI_BIAS_GELU_GRAD;
-          v[e] = epi_scale_bias(v[e], alpha, (has_bias && n + e < g.N) ? g.bias[n + e] : 0.f);
-        }
-        if (EPI == UVC_EPI_BIAS_GELU_OUT) {
-#pragma unroll
-          for (int e = 0; e < VN; ++e) v[e] = Gelu<T>::f(v[e]);
-        }
-        if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
-          const float* rp = g.R + mo * g.ldr + n;
-          float rv[VN];
-          if (nfull && (g.ldr % VN) == 0) load_vec<float, VN>(rp, rv);
-          else {
-#pragma unroll
-            for (int e = 0; e < VN; ++e) rv[e] = (n + e < g.N) ? rp[e] : 0.f;
-          }
-#pragma unroll
-          for (int e = 0; e < VN; ++e) v[e] += rv[e];
-        }
-        if (EPI == UVC_EPI_BIAS_RESID_GATE) {
-          const float* rp = g.R2 + mo * g.ldr + n;
-          float rv[VN];
-          if (nfull && (g.ldr % VN) == 0) load_vec<float, VN>(rp, rv);
-          else {
-#pragma unroll
-            for (int e = 0; e < VN; ++e) rv[e] = (n + e < g.N) ? rp[e] : 0.f;
-          }
-#pragma unroll
-          for (int e = 0; e < VN; ++e) v[e] = epi_gate_mix(v[e], rv[e], d0, d1);
-        }
-        if (EPI == UVC_EPI_DGELU || EPI == UVC_EPI_MUL_AUX) {
-          const T* ap = reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n;
-          float av[VN];
-          if (nfull && (g.ldaux % VN) == 0) load_vec<T, VN>(ap, av);
-          else {
-#pragma unroll
-            for (int e = 0; e < VN; ++e) av[e] = (n + e < g.N) ? ElemIO<T>::load(ap + e) : 0.f;
-          }
-#pragma unroll
-          for (int e = 0; e < VN; ++e) v[e] *= (EPI == UVC_EPI_MUL_AUX) ? av[e] : Gelu<T>::g(av[e]);
-        }
-        float u[VN];
-        if (EPI == UVC_EPI_BIAS_GELU_GRAD) {
-#pragma unroll
-          for (int e = 0; e < VN; ++e) { float fo, go; Gelu<T>::fg(v[e], fo, go); u[e] = fo; v[e] = go; }
-        }
-        TC* cp = C + mo * g.ldc + n;
-        if (nfull) OutVec<TC>::st(cp, v);
-        else {
-#pragma unroll
-          for (int e = 0; e < VN; ++e) if (n + e < g.N) ElemIO<TC>::store(cp + e, v[e]);
-        }
-        if (EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_GRAD) {
-          TC* c2 = reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n;
-          if (EPI == UVC_EPI_BIAS_GELU) {
-#pragma unroll
-            for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
-          }
-          if (nfull) OutVec<TC>::st(c2, u);
-          else {
-#pragma unroll
-            for (int e = 0; e < VN; ++e) if (n + e < g.N) ElemIO<TC>::store(c2 + e, u[e]);
-          }
-        }
-      }
-    }
+    nt_epilogue_rows<T, TC, EPI>(g, stg, lane, m0 + wm * 64 + h * 32, n0 + wn * 64, alpha, d0, d1);
     __syncthreads();
   }
 }
@@ -398,7 +428,7 @@ __global__ __launch_bounds__(64 * WS_NW, (NJ == 4 || KT > 6) ? 2 : 4) void k_gem
   // of the current one.  The accumulator transpose buffer is private to a wave: DS operations of one wave
   // execute in order, so only a compiler-level wave barrier separates its writes from its reads.
   constexpr int IT = 16 / RPI;
-  struct Epi { f32x4 r[IT]; f32x4 r2[IT]; u32x4 ax[IT]; };
+  struct Epi { u32x4 r[IT]; u32x4 r2[IT]; u32x4 ax[IT]; };      // r, r2: VN residual values of C's element type in 16 bytes
   auto eload = [&](Epi& E, int tile_, int sub_) {
     if (!active) return;
 #pragma unroll
@@ -406,8 +436,8 @@ __global__ __launch_bounds__(64 * WS_NW, (NJ == 4 || KT > 6) ? 2 : 4) void k_gem
       const int m = tile_ * WS_BM + sub_ * 16 + it * RPI + lane / LPR;
       const bool ok = m < g.M && tile_ < ntiles;
       const size_t mo = (size_t)(ok ? m : 0);
-      if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) E.r[it] = *reinterpret_cast<const f32x4*>(g.R + mo * g.ldr + n);
-      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[it] = *reinterpret_cast<const f32x4*>(g.R2 + mo * g.ldr + n);
+      if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) E.r[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const TC*>(g.R) + mo * g.ldr + n);
+      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const TC*>(g.R2) + mo * g.ldr + n);
       if (EPI == UVC_EPI_DGELU || EPI == UVC_EPI_MUL_AUX) E.ax[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n);
     }
   };
@@ -438,12 +468,16 @@ __global__ __launch_bounds__(64 * WS_NW, (NJ == 4 || KT > 6) ? 2 : 4) void k_gem
 #pragma unroll
         for (int e = 0; e < VN; ++e) v[e] = epi_scale_bias(v[e], alpha, bias_v[e]);
         if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
+          float rv[VN];
+          Resid<TC>::get(E.r[it], rv);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += E.r[it][e];
+          for (int e = 0; e < VN; ++e) v[e] += rv[e];
         }
         if (EPI == UVC_EPI_BIAS_RESID_GATE) {
+          float rv[VN];
+          Resid<TC>::get(E.r2[it], rv);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = epi_gate_mix(v[e], E.r2[it][e], d0, d1);
+          for (int e = 0; e < VN; ++e) v[e] = epi_gate_mix(v[e], rv[e], d0, d1);
         }
         if (EPI == UVC_EPI_DGELU) {
 #pragma unroll
@@ -656,8 +690,8 @@ __global__ __launch_bounds__(768) void k_gemm_wsn(NtArgs g) {
     for (int s2 = 0; s2 < 2; ++s2) {
       const int m = tile_ * WN_BM + s2 * 16 + li;
       const size_t off = (m < g.M && tile_ < ntiles) ? (size_t)m * g.ldr + n : 0;
-      E.r[s2] = *reinterpret_cast<const f32x4*>(g.R + off);
-      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[s2] = *reinterpret_cast<const f32x4*>(g.R2 + off);
+      E.r[s2] = Resid<TC>::f4(Resid<TC>::ld4(g.R, off));
+      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[s2] = Resid<TC>::f4(Resid<TC>::ld4(g.R2, off));
     }
   };
 
@@ -756,15 +790,15 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16(NtArgs g) {
       if (row < 16) *reinterpret_cast<u32x4*>(buf + row * ROWB + c * 16) = ra[i];
     }
   };
-  struct Epi { f32x4 r[1]; f32x4 r2[1]; };
+  struct Epi { typename Resid<TC>::Raw4 r[1]; typename Resid<TC>::Raw4 r2[1]; };      // raw: the bf16 stream keeps 2 instead of 4 registers per operand in flight
   auto eload = [&](Epi& E, int tile_) {
     if (!RES) return;
 #pragma unroll
     for (int s2 = 0; s2 < 1; ++s2) {
       const int m = tile_ * 16 + s2 * 16 + li;
       const size_t off = (m < g.M && tile_ < ntiles) ? (size_t)m * g.ldr + n : 0;
-      E.r[s2] = *reinterpret_cast<const f32x4*>(g.R + off);
-      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[s2] = *reinterpret_cast<const f32x4*>(g.R2 + off);
+      E.r[s2] = Resid<TC>::ld4(g.R, off);
+      if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[s2] = Resid<TC>::ld4(g.R2, off);
     }
   };
 
@@ -795,12 +829,14 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16(NtArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = epi_scale_bias(v[e], alpha, bias4[e]);
         if (RES) {
+          const f32x4 rv = Resid<TC>::f4(E.r[s2]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += E.r[s2][e];
+          for (int e = 0; e < 4; ++e) o[e] += rv[e];
         }
         if (EPI == UVC_EPI_BIAS_RESID_GATE) {
+          const f32x4 rv = Resid<TC>::f4(E.r2[s2]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = epi_gate_mix(o[e], E.r2[s2][e], d0, d1);
+          for (int e = 0; e < 4; ++e) o[e] = epi_gate_mix(o[e], rv[e], d0, d1);
         }
         if (sizeof(TC) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
         else { u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]); *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = q; }
@@ -817,14 +853,15 @@ static bool wsn_ok(const NtArgs& a, int epi, bool a_f32) {
   return !a_f32 && a.N == 192 && (a.K == 768 || a.K == 576 || a.K == 512 || a.K == 256) && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % 4 == 0 && a.ldr % 4 == 0 && a.M >= 4096 &&
          (epi == UVC_EPI_NONE || epi == UVC_EPI_BIAS || epi == UVC_EPI_BIAS_RESID || epi == UVC_EPI_BIAS_RESID_GATE);
 }
-template <int EPI, int KT, bool LN, int NST> __global__ void k_gemm_wsn16_dma(NtArgs g);
-template <int EPI, int KT, bool LN, int NST = 3>
+template <int EPI, int KT, bool LN, int NST, bool RLOW> __global__ void k_gemm_wsn16_dma(NtArgs g);
+template <int EPI, int KT, bool LN, int NST, bool RLOW>
 static int launch_wsn16_dma(const NtArgs& a, hipStream_t st) {
-  constexpr int NA_ = (16 * (KT * 4 + 2) + 63) / 64, NI_ = NA_ + 13 + (EPI == UVC_EPI_BIAS_RESID_GATE ? 13 : 0);
+  constexpr int NX_ = RLOW ? 7 : 13;                              // KB of a stage per residual operand (16 rows x (24 | 48) + 2 slots)
+  constexpr int NA_ = (16 * (KT * 4 + 2) + 63) / 64, NI_ = NA_ + NX_ + (EPI == UVC_EPI_BIAS_RESID_GATE ? NX_ : 0);
   const int sh = NST * NI_ * 1024 + (LN ? 2 * 16 * 12 * 8 + 3 * 192 * 4 : 0);
-  UVC_MAX_LDS(sh, k_gemm_wsn16_dma<EPI, KT, LN, NST>);
+  UVC_MAX_LDS(sh, k_gemm_wsn16_dma<EPI, KT, LN, NST, RLOW>);
   const int ntiles = ceil_div(a.M, 16);
-  k_gemm_wsn16_dma<EPI, KT, LN, NST><<<ntiles < 256 ? ntiles : 256, 768, sh, st>>>(a);
+  k_gemm_wsn16_dma<EPI, KT, LN, NST, RLOW><<<ntiles < 256 ? ntiles : 256, 768, sh, st>>>(a);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }
@@ -834,18 +871,19 @@ static bool wsn16_dma_ok(const NtArgs& a) {
 }
 template <typename TC, int KT>
 static int launch_wsn16_kt(const NtArgs& a, int epi, hipStream_t st) {
-  if constexpr (sizeof(TC) == 4 && (KT == 24 || KT == 16 || KT == 8)) {
+  if constexpr (KT == 24 || KT == 16 || KT == 8) {
+    constexpr bool RLOW = sizeof(TC) == 2;
     // fc2 of DeiT-Tiny on the LDS-DMA ring (uvc_gemm_nt_args.force_generic = 2 keeps the register-staged kernel); with ln_out also the compacted Stage-2
     // widths (K = 512 / 256: more stages of the smaller images fit)
     const bool ok = (!a.no_dma || a.ln_out) && wsn16_dma_ok(a) && (a.ln_out || a.M % 16 == 0);
     constexpr int NST_ = KT == 8 ? 4 : 3;
     if (ok && a.ln_out) {
-      if (epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, true, NST_>(a, st);
-      if (epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, true, NST_>(a, st);
+      if (epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, true, NST_, RLOW>(a, st);
+      if (epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, true, NST_, RLOW>(a, st);
     }
     if constexpr (KT == 24) {
-      if (ok && epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, false>(a, st);
-      if (ok && epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, false>(a, st);
+      if (ok && epi == UVC_EPI_BIAS_RESID) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, KT, false, 3, RLOW>(a, st);
+      if (ok && epi == UVC_EPI_BIAS_RESID_GATE) return launch_wsn16_dma<UVC_EPI_BIAS_RESID_GATE, KT, false, 3, RLOW>(a, st);
     }
   }
   if (a.ln_out) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: ln_out is not available for this problem (uvc_gemm_nt_ln_supported)");
@@ -867,7 +905,7 @@ template <typename TC, int KT>
 static int launch_wsn_kt(const NtArgs& a, int epi, hipStream_t st) {
   // float32 outputs (fc2 with its residual / gate operands) run on 16-row tiles: with 32 rows the two sub-tiles' residual
   // prefetch spilled 24-45 VGPRs next to the 96 of W and cost a third of the time (129 -> 88 us); bf16 outputs keep 32 rows
-  if constexpr (sizeof(TC) == 4) {
+  if (sizeof(TC) == 4 || epi == UVC_EPI_BIAS_RESID || epi == UVC_EPI_BIAS_RESID_GATE) {
     return launch_wsn16_kt<TC, KT>(a, epi, st);
   } else {
   const int ntiles = ceil_div(a.M, WN_BM);
@@ -909,6 +947,11 @@ static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
   return UVC_OK;
 }
 
+// the 256 x 256-tile kernel of the wide models (defined behind the LDS-DMA helpers below)
+int launch_nt256_f32(const NtArgs& a, int epi, hipStream_t st);
+int launch_nt256_bf16(const NtArgs& a, int epi, hipStream_t st);
+bool nt256_takes(const NtArgs& a, bool a_f32);
+
 extern "C" int uvc_gemm_nt_ln_supported(int32_t M, int32_t N, int32_t K, int32_t dtype, int32_t epilogue) {
   if (dtype != UVC_BF16 || N != 192 || M < 16) return 0;      // any row count from 16 up: whether norm is fused must not depend on the batch
   return ((K == 768 || K == 512 || K == 256) && (epilogue == UVC_EPI_BIAS_RESID || epilogue == UVC_EPI_BIAS_RESID_GATE)) || (K == 192 && epilogue == UVC_EPI_BIAS_RESID);
@@ -923,8 +966,8 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   if ((e == UVC_EPI_BIAS || e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_GELU_OUT || e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE ||
        e == UVC_EPI_BIAS_GELU_GRAD) && !p->bias)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue needs bias");
-  if ((e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && (!p->R || !p->c_is_f32))
-    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: residual epilogue needs R and a float32 C");
+  if ((e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && !p->R)
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: residual epilogue needs R");
   if (e == UVC_EPI_BIAS_RESID_GATE && (!p->R2 || !p->gate)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: gate epilogue needs R2 and gate");
   if ((e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_GELU_GRAD) && !p->C2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: GELU epilogue needs C2");
   if ((e == UVC_EPI_DGELU || e == UVC_EPI_MUL_AUX) && !p->aux) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dGELU epilogue needs aux");
@@ -939,14 +982,14 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   if (p->ln_out) {
     if (!p->ln_gamma || !p->ln_beta || (p->ln_mean != nullptr) != (p->ln_rstd != nullptr))
       return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: ln_out needs ln_gamma, ln_beta (and ln_mean, ln_rstd together)");
-    if (!uvc_gemm_nt_ln_supported(p->M, p->N, p->K, p->dtype, e) || generic || p->a_is_f32 || !p->c_is_f32 || p->alpha != 1.0f || p->alpha_ptr ||
+    if (!uvc_gemm_nt_ln_supported(p->M, p->N, p->K, p->dtype, e) || generic || p->a_is_f32 || p->alpha != 1.0f || p->alpha_ptr ||
         a.ldb != a.K || !wsn16_dma_ok(a) || ((uintptr_t)p->ln_out & 7) != 0)
       return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: ln_out is not available for this problem (uvc_gemm_nt_ln_supported)");
     if (p->M % 16 != 0 && (p->C == (const void*)p->R || p->C == (const void*)p->R2))
       return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: with ln_out and M % 16 != 0 the last row tile is computed twice: C must not alias R / R2");
     // attn.proj + residual -> norm2 (K = 192): 20-KB stages, seven of them, six in flight
-    if (p->K == 192) return launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, true, 7>(a, st);
-    return launch_wsn<float>(a, e, st);
+    if (p->K == 192) return p->c_is_f32 ? launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, true, 7, false>(a, st) : launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, true, 7, true>(a, st);
+    return p->c_is_f32 ? launch_wsn<float>(a, e, st) : launch_wsn<bf16_t>(a, e, st);
   }
   if (p->dtype == UVC_F32) {
     if (!p->a_is_f32 || !p->c_is_f32) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: float32 mode needs float32 A and C");
@@ -955,15 +998,17 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   if (p->dtype != UVC_BF16) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dtype must be UVC_F32 or UVC_BF16");
   {
     // attn.proj + residual (K = N = 192) without ln_out: the same seven-stage ring (same k-ordered chain and epilogue: same bits)
-    if (!p->force_generic && !p->a_is_f32 && p->c_is_f32 && e == UVC_EPI_BIAS_RESID && p->K == 192 && p->N == 192 && a.ldb == 192 &&
+    if (!p->force_generic && !p->a_is_f32 && e == UVC_EPI_BIAS_RESID && p->K == 192 && p->N == 192 && a.ldb == 192 &&
         p->M >= 4096 && p->M % 16 == 0 && p->alpha == 1.0f && !p->alpha_ptr && wsn16_dma_ok(a))
-      return launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, false, 7>(a, st);
+      return p->c_is_f32 ? launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, false, 7, false>(a, st) : launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, false, 7, true>(a, st);
   }
   const bool ws = !generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
   if (!generic && ws384_ok(a, e, p->c_is_f32 ? 4 : 8, p->a_is_f32 != 0))
     return p->c_is_f32 ? launch_ws384<float>(a, e, st) : launch_ws384<bf16_t>(a, e, st);
   if (!generic && wsn_ok(a, e, p->a_is_f32 != 0))
     return p->c_is_f32 ? launch_wsn<float>(a, e, st) : launch_wsn<bf16_t>(a, e, st);
+  if (!generic && nt256_takes(a, p->a_is_f32 != 0))
+    return p->c_is_f32 ? launch_nt256_f32(a, e, st) : launch_nt256_bf16(a, e, st);
   if (p->a_is_f32) {
     if ((p->lda % 8) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: lda");
     if (ws) return p->c_is_f32 ? launch_ws<float, float>(a, e, st) : launch_ws<float, bf16_t>(a, e, st);
@@ -989,13 +1034,15 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
 // products <dx, x>, <add2, x> ride along as there.  The row's x / add1 / add2 / mean / rstd are requested before the MFMA
 // chain.  dx may alias add2 (the engine's gA is read and rewritten in place: same lane, same addresses).
 struct LnbArgs {
-  const void* A; const void* W; const float* x; const float* mean; const float* rstd; const float* gamma;
+  const void* A; const void* W; const void* x; const float* mean; const float* rstd; const float* gamma;
   const void* add1; const float* a1; const void* add2; const float* a2; void* dx; float* partial;
   int M, K, want_dots;
 };
 
-template <int KT>
+// XLOW: the LayerNorm input x (the residual stream) is stored as bf16
+template <int KT, bool XLOW>
 __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd(LnbArgs g) {
+  typedef Resid<typename std::conditional<XLOW, bf16_t, float>::type> XS_;
   typedef bf16_t T;
   typedef Mma<T> MM;
   constexpr int K = KT * 32, NTH = 768, D = 192, NWV = 12;
@@ -1061,7 +1108,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd(LnbArgs g) {
     const int m = tile * 16 + li;
     const bool ok = m < g.M;
     const unsigned ro = (unsigned)(ok ? m : 0) * (unsigned)D + (unsigned)n;
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(g.x + ro);
+    const f32x4 xv = XS_::f4(XS_::ld4(g.x, ro));
     u32x2 r1 = {0u, 0u}, r2 = {0u, 0u};
     if (add1) r1 = *reinterpret_cast<const u32x2*>(add1 + ro);
     if (add2) r2 = *reinterpret_cast<const u32x2*>(add2 + ro);
@@ -1177,14 +1224,15 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // "these registers are valid from here": ties a spelled-out wait to the values it covers so nothing consuming them moves above it
 #define TIE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 
-template <int KT, bool HAS2>
+template <int KT, bool HAS2, bool XLOW>
 __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   constexpr int K = KT * 32, D = 192, NWV = 12;
   constexpr int ROWB = K * 2 + 32, SA = ROWB / 16;            // A row: K/8 data slots + 2 pad slots
   constexpr int NA = (16 * SA + 63) / 64;                      // DMA wave-instructions of the A image
-  constexpr int XS = 50, XB = XS * 16, NX = (16 * XS + 63) / 64;      // x rows: 48 + 2 slots (800 B)
+  constexpr int XSZ = XLOW ? 2 : 4, XSL = D * XSZ / 16;        // bytes per element of x (bf16 | float32 residual stream); data slots per row
+  constexpr int XS = XSL + 2, XB = XS * 16, NX = (16 * XS + 63) / 64;      // x rows: 48 + 2 slots (800 B) | 24 + 2 (416 B)
   constexpr int PS = 26, PB = PS * 16, NP = (16 * PS + 63) / 64;      // add rows: 24 + 2 slots (416 B)
   constexpr int I_X = NA, I_1 = I_X + NX, I_2 = I_1 + NP, NI = I_2 + NP;
   constexpr int STAGE = NI * 1024;
@@ -1231,8 +1279,8 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
       loff[q] = row < 16 ? (unsigned)(row * K * 2 + (c < K / 8 ? c : 0) * 16) : 0u;
     } else if (I < I_1) {
       const int row = sl / XS, c = sl % XS;
-      rb[q] = reinterpret_cast<const char*>(g.x); rstride[q] = 16u * D * 4u;
-      loff[q] = row < 16 ? (unsigned)(row * D * 4 + (c < 48 ? c : 0) * 16) : 0u;
+      rb[q] = reinterpret_cast<const char*>(g.x); rstride[q] = 16u * D * (unsigned)XSZ;
+      loff[q] = row < 16 ? (unsigned)(row * D * XSZ + (c < XSL ? c : 0) * 16) : 0u;
     } else {
       const int row = sl / PS, c = sl % PS;
       rb[q] = reinterpret_cast<const char*>(I < I_2 ? g.add1 : g.add2); rstride[q] = 16u * D * 2u;
@@ -1260,7 +1308,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
   };
   const unsigned s0 = lds_addr(smem);
   const unsigned fragoff = (unsigned)(li * ROWB + gq * 16);
-  const unsigned xoff = (unsigned)(I_X * 1024 + li * XB + n * 4), poff = (unsigned)(I_1 * 1024 + li * PB + n * 2), moff = (unsigned)(MR_OFF + li * 4);
+  const unsigned xoff = (unsigned)(I_X * 1024 + li * XB + n * XSZ), poff = (unsigned)(I_1 * 1024 + li * PB + n * 2), moff = (unsigned)(MR_OFF + li * 4);
   const unsigned redr = lds_addr(sRed) + (unsigned)(li * NWV * 8);
 
   int tile = blockIdx.x;
@@ -1297,7 +1345,9 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
 #undef GROUP
 #undef RD2
     // ---- this row's LayerNorm operands from the stage (they stay in registers across the barrier)
-    u32x4 xr = ds_read128<0>(sb + xoff);
+    typename Resid<typename std::conditional<XLOW, bf16_t, float>::type>::Raw4 xr;
+    if constexpr (XLOW) asm volatile("ds_read_b64 %0, %1" : "=v"(xr) : "v"(sb + xoff));
+    else xr = ds_read128<0>(sb + xoff);
     u32x2 r1 = {0u, 0u}, r2 = {0u, 0u};
     if (has1) asm volatile("ds_read_b64 %0, %1" : "=v"(r1) : "v"(sb + poff));
     if (has2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r2) : "v"(sb + poff), "n"((I_2 - I_1) * 1024));
@@ -1307,7 +1357,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
     u32x4 gr = ds_read128<0>(gaddr);
     wait_lgkm<0>();
     asm volatile("" : "+v"(xr), "+v"(r1), "+v"(r2), "+v"(mean), "+v"(rstd), "+v"(gr));
-    const f32x4 xv = __builtin_bit_cast(f32x4, xr);
+    const f32x4 xv = Resid<typename std::conditional<XLOW, bf16_t, float>::type>::f4(xr);
     f32x4 gam = __builtin_bit_cast(f32x4, gr);
     {
       float p1 = 0.f, p2 = 0.f;
@@ -1398,14 +1448,17 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
 // (R = x1, R2 = x_l) go HBM -> LDS by global_load_lds_dwordx4 into three stages, two in flight; one barrier per tile; the epilogue
 // runs from registers after it.  The accumulation is the single k-ordered chain and the epilogue the same fmaf sequence as every other
 // NT kernel, so the output bits do not depend on which kernel a problem size selects (tests/test_fullsize_gpu.py).  M % 16 == 0.
-template <int EPI, int KT, bool LN, int NST>
+// RLOW: the residual stream is bf16 -- R, R2 and C are bf16 rows (24 + 2 slots of 16 bytes in a stage instead of 48 + 2; the result is
+// rounded once, at the store, and the LayerNorm that follows is taken of the ROUNDED row: what the consumers of C will read).
+template <int EPI, int KT, bool LN, int NST, bool RLOW>
 __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   constexpr int K = KT * 32, D = 192, NWV = 12;
   constexpr int ROWB = K * 2 + 32, SA = ROWB / 16;
   constexpr int NA = (16 * SA + 63) / 64;
-  constexpr int XS = 50, XB = XS * 16, NX = (16 * XS + 63) / 64;
+  constexpr int RSZ = RLOW ? 2 : 4, RSL = D * RSZ / 16;         // bytes per residual element; data slots per residual row
+  constexpr int XS = RSL + 2, XB = XS * 16, NX = (16 * XS + 63) / 64;
   constexpr bool GATE = EPI == UVC_EPI_BIAS_RESID_GATE;
   constexpr int I_R = NA, I_R2 = I_R + NX, NI = I_R2 + (GATE ? NX : 0);
   constexpr int STAGE = NI * 1024;
@@ -1417,7 +1470,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, gq = lane >> 4, li = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T* __restrict__ W = reinterpret_cast<const T*>(g.B);
-  float* __restrict__ C = reinterpret_cast<float*>(g.C);
+  char* __restrict__ C = reinterpret_cast<char*>(g.C);
   const int ntiles = (g.M + 15) / 16;                         // M >= 16; a ragged last tile is the LAST 16 rows (it overlaps its neighbour:
                                                               // those rows are computed twice from the same operands, same bits, same stores)
   const int n = w * 16 + gq * 4;
@@ -1452,8 +1505,8 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
       loff[q] = row < 16 ? (unsigned)(row * K * 2 + (c < K / 8 ? c : 0) * 16) : 0u;
     } else {
       const int row = sl / XS, c = sl % XS;
-      rb[q] = reinterpret_cast<const char*>(I < I_R2 ? g.R : g.R2); rstride[q] = D * 4u;
-      loff[q] = row < 16 ? (unsigned)(row * D * 4 + (c < 48 ? c : 0) * 16) : 0u;
+      rb[q] = reinterpret_cast<const char*>(I < I_R2 ? g.R : g.R2); rstride[q] = (unsigned)(D * RSZ);
+      loff[q] = row < 16 ? (unsigned)(row * D * RSZ + (c < RSL ? c : 0) * 16) : 0u;
     }
   }
   auto issue = [&](int tile, int st) {
@@ -1467,7 +1520,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
     }
   };
   const unsigned s0 = lds_addr(smem);
-  const unsigned fragoff = (unsigned)(li * ROWB + gq * 16), roff = (unsigned)(I_R * 1024 + li * XB + n * 4);
+  const unsigned fragoff = (unsigned)(li * ROWB + gq * 16), roff = (unsigned)(I_R * 1024 + li * XB + n * RSZ);
 
   // NST stages, NST - 1 in flight: stage t + NST - 1 is requested at the top of iteration t into the image iteration t - 1 read
   int tile = blockIdx.x;
@@ -1556,14 +1609,23 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
     GROUP(6, fa, fb) GROUP(7, fb, fa) GROUP(8, fa, fb) GROUP(9, fb, fa) GROUP(10, fa, fb) GROUP(11, fb, fa)
 #undef GROUP
 #undef RD2
-    u32x4 rr = ds_read128<0>(sb + roff), rr2 = rr;
-    if (GATE) rr2 = ds_read128<NX * 1024>(sb + roff);
+    // the row's residual operands: four consecutive columns = 16 bytes (float32 stream) or 8 bytes (bf16 stream)
+    typename Resid<typename std::conditional<RLOW, bf16_t, float>::type>::Raw4 rr, rr2;
+    if constexpr (RLOW) {
+      asm volatile("ds_read_b64 %0, %1" : "=v"(rr) : "v"(sb + roff));
+      rr2 = rr;
+      if (GATE) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rr2) : "v"(sb + roff), "n"(NX * 1024));
+    } else {
+      rr = ds_read128<0>(sb + roff); rr2 = rr;
+      if (GATE) rr2 = ds_read128<NX * 1024>(sb + roff);
+    }
+    typedef Resid<typename std::conditional<RLOW, bf16_t, float>::type> RS;
     if constexpr (!LN) {
       wait_vm<(NST - 2) * NPW>();                                 // own part of the next stage has landed
       wait_lgkm<0>();
       asm volatile("" : "+v"(rr), "+v"(rr2));
       __builtin_amdgcn_s_barrier();
-      const f32x4 r = __builtin_bit_cast(f32x4, rr), r2 = __builtin_bit_cast(f32x4, rr2);
+      const f32x4 r = RS::f4(rr), r2 = RS::f4(rr2);
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1571,7 +1633,9 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
         o[e] += r[e];
         if (GATE) o[e] = epi_gate_mix(o[e], r2[e], d0, d1);
       }
-      *reinterpret_cast<f32x4*>(C + ((size_t)(min(tile * 16, g.M - 16) + li) * g.ldc + n)) = f32x4{o[0], o[1], o[2], o[3]};
+      char* cp = C + ((size_t)(min(tile * 16, g.M - 16) + li) * g.ldc + n) * RSZ;
+      if constexpr (RLOW) { u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]); *reinterpret_cast<u32x2*>(cp) = q; }
+      else *reinterpret_cast<f32x4*>(cp) = f32x4{o[0], o[1], o[2], o[3]};
     } else {
       // The output row is spread over the 12 waves (16 columns each).  Every wave leaves (mean, centred sum of squares) of its 16
       // columns in the table BEFORE the tile's one barrier and picks up the 12 pairs after it; they combine exactly (Chan et al.):
@@ -1579,13 +1643,20 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
       u32x4 bq = ds_read128<2 * D * 4>(gaddr);
       wait_lgkm<0>();
       asm volatile("" : "+v"(rr), "+v"(rr2), "+v"(bq));
-      const f32x4 r = __builtin_bit_cast(f32x4, rr), r2 = __builtin_bit_cast(f32x4, rr2), bv = __builtin_bit_cast(f32x4, bq);
+      const f32x4 r = RS::f4(rr), r2 = RS::f4(rr2), bv = __builtin_bit_cast(f32x4, bq);
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         o[e] = epi_scale_bias(c0[e], alpha, bv[e]);
         o[e] += r[e];
         if (GATE) o[e] = epi_gate_mix(o[e], r2[e], d0, d1);
+      }
+      u32x2 oq = {0u, 0u};
+      if constexpr (RLOW) {                       // the stored (rounded) row is what the LayerNorm and every later consumer see
+        oq[0] = pack_bf16x2(o[0], o[1]); oq[1] = pack_bf16x2(o[2], o[3]);
+        const f32x4 t = Resid<bf16_t>::f4(oq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = t[e];
       }
       {
         const float sm = sum_rows4((o[0] + o[1]) + (o[2] + o[3]));
@@ -1598,7 +1669,8 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
       }
       // the output rows leave now; their normalisation follows inside the next iteration (or behind the loop)
       prow0 = min(tile * 16, g.M - 16);
-      *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(C + (size_t)prow0 * g.ldc) + (unsigned)((li * g.ldc + n) * 4)) = f32x4{o[0], o[1], o[2], o[3]};
+      if constexpr (RLOW) *reinterpret_cast<u32x2*>(C + (size_t)prow0 * g.ldc * RSZ + (unsigned)((li * g.ldc + n) * RSZ)) = oq;
+      else *reinterpret_cast<f32x4*>(C + (size_t)prow0 * g.ldc * RSZ + (unsigned)((li * g.ldc + n) * RSZ)) = f32x4{o[0], o[1], o[2], o[3]};
 #pragma unroll
       for (int e = 0; e < 4; ++e) po[e] = o[e];
       have_prev = true;
@@ -1639,26 +1711,175 @@ extern "C" int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
 #define LNB_LAUNCH(KT_) { \
     const size_t sh = (size_t)2 * 16 * (KT_ * 64 + 32) + (2 * 16 * 12 * 2 + 192) * sizeof(float); \
-    UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd<KT_>); \
-    k_gemm_wsn_lnbwd<KT_><<<grid, 768, sh, st>>>(a); }
+    if (p->x_lowp) { UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd<KT_, true>); k_gemm_wsn_lnbwd<KT_, true><<<grid, 768, sh, st>>>(a); } \
+    else { UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd<KT_, false>); k_gemm_wsn_lnbwd<KT_, false><<<grid, 768, sh, st>>>(a); } }
   const bool use_dma = p->variant != 1;
   const bool al16 = (((uintptr_t)p->add1 | (uintptr_t)p->add2 | (uintptr_t)p->mean | (uintptr_t)p->rstd) & 15) == 0;
+#define LNB_DMA_ONE(KT_, H2_, XL_) { UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd_dma<KT_, H2_, XL_>); k_gemm_wsn_lnbwd_dma<KT_, H2_, XL_><<<grid, 768, sh, st>>>(a); }
 #define LNB_LAUNCH_DMA(KT_) { \
-    constexpr int NA_ = (16 * (KT_ * 4 + 2) + 63) / 64, NI_ = NA_ + 13 + 7 + 7; \
+    constexpr int NA_ = (16 * (KT_ * 4 + 2) + 63) / 64; \
+    const int NI_ = NA_ + (p->x_lowp ? 7 : 13) + 7 + 7; \
     const size_t sh = (size_t)3 * NI_ * 1024 + (2 * 16 * 12 * 2 + 192) * sizeof(float); \
-    if (p->add2) { \
-      UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd_dma<KT_, true>); \
-      k_gemm_wsn_lnbwd_dma<KT_, true><<<grid, 768, sh, st>>>(a); \
-    } else { \
-      UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd_dma<KT_, false>); \
-      k_gemm_wsn_lnbwd_dma<KT_, false><<<grid, 768, sh, st>>>(a); } }
+    if (p->x_lowp) { if (p->add2) LNB_DMA_ONE(KT_, true, true) else LNB_DMA_ONE(KT_, false, true) } \
+    else { if (p->add2) LNB_DMA_ONE(KT_, true, false) else LNB_DMA_ONE(KT_, false, false) } }
   if (use_dma && al16 && p->M % 16 == 0) { if (p->K == 768) LNB_LAUNCH_DMA(24) else LNB_LAUNCH_DMA(18) }
   else if (p->K == 768) LNB_LAUNCH(24) else LNB_LAUNCH(18)
 #undef LNB_LAUNCH_DMA
+#undef LNB_DMA_ONE
 #undef LNB_LAUNCH
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }
+
+// ================================================================================================
+//            NT, 256 x 256 output tile, LDS-DMA double buffer (bf16; the wide models' GEMMs)
+// ================================================================================================
+// DeiT-Small / Base and T2T-ViT have K = 384 ... 3072 against N = 384 ... 3072: compute-bound on the matrix pipe, not streaming
+// (2 M N K / (2 (M K + N K + M N)) = 300 ... 600 flop / B), and the 128 x 128 kernel above spends its time around its two barriers
+// per 64-deep step (0.5-0.85 PFLOP/s).  Here a workgroup is 8 waves (2 x 4), one per CU by LDS, and owns a 256 x 256 tile: a wave
+// accumulates 128 x 64 (32 MFMA tiles, 128 accumulator registers), so a 16-byte fragment read feeds four (A) or eight (B) MFMAs.
+//   * Operand tiles (256 rows x 64 k = 32 KB each) go HBM / L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers,
+//     rows past M / N read as zeros through the buffer descriptor's bounds check) into TWO 64-KB stages; the DMA writes a wave's 64
+//     lanes as 64 consecutive 16-byte slots, so the image is linear [row][8 chunks] and the bank swizzle sits in the SOURCE address:
+//     slot (row, c) holds k-chunk c ^ (row & 7), which makes the fragment reads (row = lane & 15, chunk = 4 ks + lane / 16) of every
+//     ds_read_b128 lane group hit 16 different 16-byte slots of the 256-byte bank row.
+//   * One barrier per 64-deep step.  Fragments of k-half 1 are requested before the MFMAs of k-half 0 and those of the NEXT stage's
+//     k-half 0 before the MFMAs of k-half 1 (two fragment sets, 96 registers), and the stage after next is requested right behind the
+//     barrier, a whole step before it is needed:   [read F1 | 32 MFMA F0 | wait F1, wait DMA(t+1) | barrier | DMA(t+2) | read F0' | 32 MFMA F1].
+//     All LDS reads of the loop are inline assembly: behind an LDS-DMA hipcc drains vmcnt(0) in front of any LDS read it can see.
+//   * Epilogue through a wave-private LDS transpose, nt_epilogue_rows: the same arithmetic and stores as k_gemm_nt.
+//   * Tiles are numbered XCD-major (block b runs on XCD b % 8): all N tiles of an M tile share an L2.
+constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
+constexpr int G2_OPB = 256 * 128;              // bytes of one operand tile image (256 rows x 128 B)
+constexpr int G2_STAGE = 2 * G2_OPB;           // A image + B image
+constexpr int G2_LDS = 2 * G2_STAGE;           // 128 KB
+
+struct G2Frags { u32x4 a[8]; u32x4 b[4]; };
+
+template <typename TC, int EPI>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt256(NtArgs g, int tiles_n) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int bn = q % tiles_n, bm = (q / tiles_n) * 8 + xcd;
+  const int m0 = bm * G2_BM, n0 = bn * G2_BN;
+  if (m0 >= g.M) return;
+
+  // ---- LDS-DMA: 32 wave-instructions per operand tile (8 rows x 128 B each), wave w issues instructions w, w + 8, w + 16, w + 24
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)(((size_t)(g.M - 1) * g.lda + g.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)(((size_t)(g.N - 1) * g.ldb + g.K) * 2), 0x00020000);
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;         // slot (row, c) <- k-chunk c ^ (row & 7)
+  const unsigned voA = (unsigned)(((m0 + w * 8 + lrow) * g.lda + lchunk * 8) * 2);
+  const unsigned voB = (unsigned)(((n0 + w * 8 + lrow) * g.ldb + lchunk * 8) * 2);
+  const unsigned stepA = (unsigned)(64 * g.lda * 2), stepB = (unsigned)(64 * g.ldb * 2);
+  auto issue = [&](int kt, int st) {
+    char* base = smem + st * G2_STAGE + w * 1024;
+    const unsigned kb = (unsigned)(kt * G2_BK * 2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + t * 8192), 16, voA + kb + t * stepA, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(base + G2_OPB + t * 8192), 16, voB + kb + t * stepB, 0, 0, 0);
+  };
+  // ---- fragment addresses: row = lane & 15 (+ the tile's offset), k-chunk 4 ks + lane / 16, swizzled with row & 7 = lane & 7
+  const unsigned s0 = lds_addr(smem);
+  const unsigned sw0 = (unsigned)((((lane >> 4)) ^ (lane & 7)) * 16);
+  const unsigned fa0 = s0 + (unsigned)((wm * 128 + (lane & 15)) * 128) + sw0;                    // k-half 0; k-half 1 = address ^ 64
+  const unsigned fb0 = s0 + (unsigned)(G2_OPB + (wn * 64 + (lane & 15)) * 128) + sw0;
+  auto rdfrags = [&](G2Frags& F, int st, int ks) {
+    const unsigned a = (fa0 ^ (unsigned)(ks * 64)) + (unsigned)(st * G2_STAGE), b = (fb0 ^ (unsigned)(ks * 64)) + (unsigned)(st * G2_STAGE);
+    F.b[0] = ds_read128<0 * 2048>(b); F.b[1] = ds_read128<1 * 2048>(b); F.b[2] = ds_read128<2 * 2048>(b); F.b[3] = ds_read128<3 * 2048>(b);
+    F.a[0] = ds_read128<0 * 2048>(a); F.a[1] = ds_read128<1 * 2048>(a); F.a[2] = ds_read128<2 * 2048>(a); F.a[3] = ds_read128<3 * 2048>(a);
+    F.a[4] = ds_read128<4 * 2048>(a); F.a[5] = ds_read128<5 * 2048>(a); F.a[6] = ds_read128<6 * 2048>(a); F.a[7] = ds_read128<7 * 2048>(a);
+  };
+  auto tie = [&](G2Frags& F) {
+    asm volatile("" : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.a[2]), "+v"(F.a[3]), "+v"(F.a[4]), "+v"(F.a[5]), "+v"(F.a[6]), "+v"(F.a[7]),
+                      "+v"(F.b[0]), "+v"(F.b[1]), "+v"(F.b[2]), "+v"(F.b[3]));
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfmas = [&](const G2Frags& F) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = MM::mma(__builtin_bit_cast(typename MM::Frag, F.b[j]), __builtin_bit_cast(typename MM::Frag, F.a[i]), acc[i][j]);
+  };
+
+  const int nk = g.K / G2_BK;                     // >= 2 (the dispatch requires K >= 256)
+  G2Frags F0, F1;
+  issue(0, 0);
+  issue(1, 1);
+  wait_vm<8>();                                   // own part of stage 0 has landed (loads retire in order; 8 per stage and wave)
+  __builtin_amdgcn_s_barrier();
+  rdfrags(F0, 0, 0);
+  wait_lgkm<0>();
+  tie(F0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    rdfrags(F1, st, 1);
+    mfmas(F0);
+    wait_lgkm<0>();                               // F1 is in registers: this wave is done with stage st
+    tie(F1);
+    wait_vm<0>();                                 // own part of stage kt + 1 has landed
+    __builtin_amdgcn_s_barrier();                 // everybody's has; nobody reads stage st any more
+    if (kt + 2 < nk) issue(kt + 2, st);
+    if (kt + 1 < nk) rdfrags(F0, st ^ 1, 0);
+    mfmas(F1);
+    wait_lgkm<0>();
+    tie(F0);
+  }
+
+  // ---- epilogue: 32 rows x 64 columns at a time through a wave-private transpose buffer (the stages are free now)
+  float alpha = g.alpha;
+  if (g.alpha_ptr) alpha *= *g.alpha_ptr;
+  float d0 = 0.f, d1 = 1.f;
+  if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
+  __syncthreads();
+  float* stg = reinterpret_cast<float*>(smem) + w * (32 * EP_LD);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(stg + (ii * 16 + (lane & 15)) * EP_LD + j * 16 + (lane >> 4) * 4) = acc[2 * h + ii][j];
+    __builtin_amdgcn_wave_barrier();
+    nt_epilogue_rows<T, TC, EPI>(g, stg, lane, m0 + wm * 128 + h * 32, n0 + wn * 64, alpha, d0, d1);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// the shapes k_gemm_nt256 takes: bf16 operands with 64-deep k tiles and 16-byte aligned rows, enough rows and columns to fill tiles
+static bool nt256_ok(const NtArgs& a, bool a_f32) {
+  return !a_f32 && a.K % 64 == 0 && a.K >= 256 && a.N >= 256 && a.M >= 2048 && a.lda % 8 == 0 && a.ldb % 8 == 0 &&
+         (((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0 && (size_t)a.M * a.lda * 2 < (1ull << 31) && (size_t)a.N * a.ldb * 2 < (1ull << 31);
+}
+template <typename TC>
+static int launch_nt256(const NtArgs& a, int epi, hipStream_t st) {
+  const int tm = ceil_div(a.M, G2_BM), tn = ceil_div(a.N, G2_BN);
+  const int grid = ceil_div(tm, 8) * 8 * tn;
+#define G2_CASE(E) case E: UVC_MAX_LDS(G2_LDS, k_gemm_nt256<TC, E>); k_gemm_nt256<TC, E><<<grid, 512, G2_LDS, st>>>(a, tn); break;
+  switch (epi) {
+    G2_CASE(UVC_EPI_NONE) G2_CASE(UVC_EPI_BIAS) G2_CASE(UVC_EPI_BIAS_GELU) G2_CASE(UVC_EPI_BIAS_RESID)
+    G2_CASE(UVC_EPI_BIAS_RESID_GATE) G2_CASE(UVC_EPI_DGELU) G2_CASE(UVC_EPI_BIAS_GELU_OUT) G2_CASE(UVC_EPI_BIAS_GELU_GRAD) G2_CASE(UVC_EPI_MUL_AUX)
+    default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
+  }
+#undef G2_CASE
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+int launch_nt256_f32(const NtArgs& a, int epi, hipStream_t st) { return launch_nt256<float>(a, epi, st); }
+int launch_nt256_bf16(const NtArgs& a, int epi, hipStream_t st) { return launch_nt256<bf16_t>(a, epi, st); }
+bool nt256_takes(const NtArgs& a, bool a_f32) { return nt256_ok(a, a_f32); }
 
 // ================================================================================================
 //                                            TN (wgrad)

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(uvc_ln_args a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + w;
   if (r >= a.rows) return;
-  const float* x = a.x + row_off(r, a.rows_per_group, a.group_stride, a.D);
+  const float* x = reinterpret_cast<const float*>(a.x) + row_off(r, a.rows_per_group, a.group_stride, a.D);
   float v[NV];
   float s = 0.f;
 #pragma unroll
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(uvc_ln_args a, int rpb) {
   const float invD = 1.0f / (float)a.D;
   for (int r = r0 + w; r < r1; r += 4) {
     const size_t off = row_off(r, a.rows_per_group, a.group_stride, a.D);
-    const float* x = a.x + off;
+    const float* x = reinterpret_cast<const float*>(a.x) + off;
     const TDY* dy = reinterpret_cast<const TDY*>(a.dy) + (size_t)r * a.D;
     const float mean = a.mean[r], rstd = a.rstd[r];
     float xh[NV], gy[NV];
@@ -164,7 +164,8 @@ __device__ __forceinline__ float sum16(float v) {
 }
 
 constexpr int LNV_FWD_ROWS = 64;     // rows per block (16 per wave, 4 at a time)
-template <typename TY, int NV4>
+// TX: element type of x (float32, or bf16 = the bf16 residual stream of the throughput mode; statistics stay float32)
+template <typename TX, typename TY, int NV4>
 __global__ __launch_bounds__(256) void k_ln_fwd_v(uvc_ln_args a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane & 15, rg = lane >> 4;
   f32x4 gam[NV4], bet[NV4];
@@ -176,12 +177,12 @@ __global__ __launch_bounds__(256) void k_ln_fwd_v(uvc_ln_args a) {
   for (int it = 0; it < 4; ++it) {
     const int r = rbase + it * 4 + rg;
     const bool ok = r < a.rows;
-    const float* x = a.x + (ok ? row_off(r, a.rows_per_group, a.group_stride, a.D) : 0);
+    const TX* x = reinterpret_cast<const TX*>(a.x) + (ok ? row_off(r, a.rows_per_group, a.group_stride, a.D) : 0);
     f32x4 v[NV4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
-      v[i] = ok ? Ld4<float>::ld(x + (sub + 16 * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[i] = ok ? Ld4<TX>::ld(x + (sub + 16 * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = sum16(s) * invD;
@@ -213,7 +214,7 @@ template <int LPR> __device__ __forceinline__ float sum_lpr(float v) {
   for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-template <typename TDY, typename TG, int NV4, int LPR>
+template <typename TX, typename TDY, typename TG, int NV4, int LPR>
 __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a, int rpb) {
   constexpr int DD = 4 * LPR * NV4, RPW = 64 / LPR;        // row length; rows a wave handles at a time
   __shared__ float red[4][2 * DD + 2];
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a, int rpb) {
     const int r = rb + rg;
     R.ok = rb < r1 && r < r1;
     R.off = R.ok ? row_off(r, a.rows_per_group, a.group_stride, a.D) : 0;
-    const float* x = a.x + R.off;
+    const TX* x = reinterpret_cast<const TX*>(a.x) + R.off;
     const TDY* dy = reinterpret_cast<const TDY*>(a.dy) + (size_t)(R.ok ? r : 0) * a.D;
     R.mean = R.ok ? a.mean[r] : 0.f; R.rstd = R.ok ? a.rstd[r] : 0.f;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a, int rpb) {
       R.ad1[i] = (R.ok && add1) ? Ld4<TG>::ld(add1 + R.off + (sub + LPR * i) * 4) : z;
       R.ad2[i] = (R.ok && add2) ? Ld4<TG>::ld(add2 + R.off + (sub + LPR * i) * 4) : z;
       R.dv[i] = R.ok ? Ld4<TDY>::ld(dy + (sub + LPR * i) * 4) : z;
-      R.xv[i] = R.ok ? Ld4<float>::ld(x + (sub + LPR * i) * 4) : z;
+      R.xv[i] = R.ok ? Ld4<TX>::ld(x + (sub + LPR * i) * 4) : z;
     }
   };
   auto process = [&](const Row& R) {
@@ -367,18 +368,17 @@ int check(const uvc_ln_args* p) {
 template <typename T> int launch_fwd(const uvc_ln_args& a, hipStream_t st) {
   if (a.D % 64 == 0 && (a.group_stride % 4) == 0) {
     const int grid = ceil_div(a.rows, LNV_FWD_ROWS);
+#define LNF_CASE(NV4) case NV4: if (a.x_lowp) k_ln_fwd_v<bf16_t, T, NV4><<<grid, 256, 0, st>>>(a); else k_ln_fwd_v<float, T, NV4><<<grid, 256, 0, st>>>(a); break;
     switch (a.D / 64) {
-      case 1: k_ln_fwd_v<T, 1><<<grid, 256, 0, st>>>(a); break;
-      case 2: k_ln_fwd_v<T, 2><<<grid, 256, 0, st>>>(a); break;
-      case 3: k_ln_fwd_v<T, 3><<<grid, 256, 0, st>>>(a); break;
-      case 6: k_ln_fwd_v<T, 6><<<grid, 256, 0, st>>>(a); break;
-      case 12: k_ln_fwd_v<T, 12><<<grid, 256, 0, st>>>(a); break;
+      LNF_CASE(1) LNF_CASE(2) LNF_CASE(3) LNF_CASE(6) LNF_CASE(12)
       default: goto generic;
     }
+#undef LNF_CASE
     UVC_CHECK_LAUNCH();
     return UVC_OK;
   }
 generic:
+  if (a.x_lowp) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "layernorm_fwd: a bf16 x needs D in {64, 128, 192, 384, 768} and a group stride that is a multiple of 4");
   const int grid = ceil_div(a.rows, 4);
   const int nv = ceil_div(a.D, 64);
   if (nv <= 2) k_ln_fwd<T, 2><<<grid, 256, 0, st>>>(a);
@@ -395,14 +395,16 @@ template <typename T> int launch_bwd(const uvc_ln_args& a, hipStream_t st) {
   const int nv = ceil_div(a.D, 64);
   bool vec = a.D % 64 == 0 && (a.group_stride % 4) == 0;
   if (vec) {
-#define LNB_CASE(DV, NV4, LPR) case DV: if (a.g_lowp) k_ln_bwd_v<T, bf16_t, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); else k_ln_bwd_v<T, float, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); break;
+#define LNB_CASE(DV, NV4, LPR) case DV: \
+      if (a.x_lowp) { if (a.g_lowp) k_ln_bwd_v<bf16_t, T, bf16_t, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); else k_ln_bwd_v<bf16_t, T, float, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); } \
+      else { if (a.g_lowp) k_ln_bwd_v<float, T, bf16_t, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); else k_ln_bwd_v<float, T, float, NV4, LPR><<<grid, 256, 0, st>>>(a, rpb); } break;
     switch (a.D) {
       LNB_CASE(64, 1, 16) LNB_CASE(128, 2, 16) LNB_CASE(192, 3, 16) LNB_CASE(256, 2, 32) LNB_CASE(384, 3, 32) LNB_CASE(512, 2, 64) LNB_CASE(768, 3, 64)
       default: vec = false;
     }
 #undef LNB_CASE
   }
-  if (!vec && a.g_lowp) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "layernorm_bwd: a bf16 gradient stream needs D % 64 == 0");
+  if (!vec && (a.g_lowp || a.x_lowp)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "layernorm_bwd: a bf16 gradient stream / bf16 x needs D % 64 == 0");
   if (!vec) {
     if (nv <= 2) k_ln_bwd<T, 2><<<grid, 256, 0, st>>>(a, rpb);
     else if (nv <= 3) k_ln_bwd<T, 3><<<grid, 256, 0, st>>>(a, rpb);

@@ -10,8 +10,9 @@ namespace {
 
 struct Dims {
   int B, S, P, C, D, L, H, F, NC, ntok, np, N, M, K0, dtype, qkv_bias;
+  int rlow;              // the residual stream (x_l, x1 of every block, the final rows) is bf16: the throughput mode unless uvc_vit_cfg.resid_f32
   float eps;
-  size_t tsz;
+  size_t tsz, rsz;       // bytes per operand element (T); per residual-stream element
 };
 Dims dims_of(const uvc_vit_cfg& c, int B) {
   Dims d;
@@ -19,6 +20,8 @@ Dims dims_of(const uvc_vit_cfg& c, int B) {
   d.F = c.hidden; d.NC = c.num_classes; d.ntok = c.ntok; d.np = (c.img_size / c.patch_size) * (c.img_size / c.patch_size);
   d.N = d.np + d.ntok; d.M = B * d.N; d.K0 = c.in_chans * c.patch_size * c.patch_size; d.dtype = c.dtype;
   d.tsz = c.dtype == UVC_F32 ? 4 : 2;
+  d.rlow = (c.dtype == UVC_BF16 && !c.resid_f32) ? 1 : 0;
+  d.rsz = d.rlow ? 2 : 4;
   d.eps = c.ln_eps > 0.f ? c.ln_eps : 1e-6f;
   d.qkv_bias = c.no_qkv_bias ? 0 : 1;
   return d;
@@ -46,19 +49,19 @@ struct Carver {
   void* take(int64_t bytes) { void* p = base ? base + off : nullptr; off += (bytes + 255) & ~(int64_t)255; return p; }
 };
 
-struct BlockBufs {
-  float* x; void* h1; void* qkv; void* o; float* lse; float* mean1; float* rstd1;
-  float* x1; void* h2; float* mean2; float* rstd2; void* a; void* u;
+struct BlockBufs {      // x, x1: residual-stream rows (float32, or bf16 when Dims::rlow)
+  void* x; void* h1; void* qkv; void* o; float* lse; float* mean1; float* rstd1;
+  void* x1; void* h2; float* mean2; float* rstd2; void* a; void* u;
 };
 // Compact [B * ntok, .] buffers of the last block's tail (token_tail.hip): only the class / distillation token rows of the last
 // block reach the head, so its attention output, proj, LayerNorm2, MLP and their backward run on those rows alone
 struct TailBufs {
-  float* xc; void* oc; float* x1c; void* h2c; float* mean2c; float* rstd2c; void* ac; void* uc; float* xoutc;
+  void* xc; void* oc; void* x1c; void* h2c; float* mean2c; float* rstd2c; void* ac; void* uc; void* xoutc;      // xc, x1c, xoutc: residual-stream rows
   void* gAc; void* dAc; void* dHc; void* gBc; void* dOc;      // backward
 };
 struct Work {
   TailBufs tail;
-  void* patches; float* pe; BlockBufs blk[UVC_VIT_MAX_DEPTH]; float* xL;
+  void* patches; float* pe; BlockBufs blk[UVC_VIT_MAX_DEPTH]; void* xL;
   void* hc; float* meanf; float* rstdf;
   // backward scratch
   void* gA; void* gB;      // dL/dx streams of the backward: T (bf16 in the throughput mode: every consumer is a bf16 GEMM
@@ -87,16 +90,16 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
   const int nb = training ? d.L : 1;
   for (int l = 0; l < nb; ++l) {
     BlockBufs& b = w.blk[l];
-    b.x = (float*)c.take(MD * 4);
+    b.x = c.take(MD * d.rsz);
     b.h1 = c.take(MD * d.tsz); b.qkv = c.take(3 * MD * d.tsz); b.o = c.take(MD * d.tsz);
     b.lse = (float*)c.take((int64_t)d.B * d.H * d.N * 4);
     b.mean1 = (float*)c.take((int64_t)d.M * 4); b.rstd1 = (float*)c.take((int64_t)d.M * 4);
-    b.x1 = (float*)c.take(MD * 4);
+    b.x1 = c.take(MD * d.rsz);
     b.h2 = c.take(MD * d.tsz);
     b.mean2 = (float*)c.take((int64_t)d.M * 4); b.rstd2 = (float*)c.take((int64_t)d.M * 4);
     b.a = c.take(MF * d.tsz); b.u = c.take(MF * d.tsz);
   }
-  w.xL = (float*)c.take(MD * 4);
+  w.xL = c.take(MD * d.rsz);
   if (!training) {                       // inference: every block reuses block 0's buffers, x ping-pongs with xL
     for (int l = 1; l < d.L; ++l) { w.blk[l] = w.blk[0]; }
   }
@@ -127,9 +130,9 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
   {
     const int64_t Rt = (int64_t)d.B * d.ntok;
     TailBufs& t = w.tail;
-    t.xc = (float*)c.take(Rt * d.D * 4); t.oc = c.take(Rt * d.D * d.tsz); t.x1c = (float*)c.take(Rt * d.D * 4);
+    t.xc = c.take(Rt * d.D * d.rsz); t.oc = c.take(Rt * d.D * d.tsz); t.x1c = c.take(Rt * d.D * d.rsz);
     t.h2c = c.take(Rt * d.D * d.tsz); t.mean2c = (float*)c.take(Rt * 4); t.rstd2c = (float*)c.take(Rt * 4);
-    t.ac = c.take(Rt * d.F * d.tsz); t.uc = c.take(Rt * d.F * d.tsz); t.xoutc = (float*)c.take(Rt * d.D * 4);
+    t.ac = c.take(Rt * d.F * d.tsz); t.uc = c.take(Rt * d.F * d.tsz); t.xoutc = c.take(Rt * d.D * d.rsz);
     if (training) {
       t.gAc = c.take(Rt * d.D * d.tsz); t.dAc = c.take(Rt * d.F * d.tsz); t.dHc = c.take(Rt * d.D * d.tsz);
       t.gBc = c.take(Rt * d.D * d.tsz); t.dOc = c.take(Rt * d.D * d.tsz);
@@ -181,7 +184,7 @@ const void* wmat(const Ctx& c, int64_t poff, int64_t soff) { return c.d.dtype ==
 // norm1 of the next block that runs, written by the kernel that produces its input rows (uvc_vit_io.fuse_next_ln)
 struct NextLn { const float* gamma; const float* beta; void* h; float* mean; float* rstd; };
 int nt(const Ctx& c, const void* A, int a_f32, const void* B, void* C, int c_f32, int M, int N, int K, int epi, const float* bias = nullptr,
-       const float* R = nullptr, const float* R2 = nullptr, const void* aux = nullptr, const float* gate = nullptr, void* C2 = nullptr,
+       const void* R = nullptr, const void* R2 = nullptr, const void* aux = nullptr, const float* gate = nullptr, void* C2 = nullptr,
        const float* alpha_ptr = nullptr, int lda = 0, int ldc = 0, const NextLn* ln = nullptr) {
   uvc_gemm_nt_args a;
   memset(&a, 0, sizeof(a));
@@ -220,10 +223,10 @@ int tn(Ctx& c, const void* A, int a_f32, const void* B, float* C, float* bias_gr
 int csum(const Ctx& c, const void* X, int x_f32, float* out, int M, int N, const float* alpha_ptr = nullptr, int ldx = 0) {
   return uvc_colsum(X, M, N, ldx ? ldx : N, c.d.dtype, x_f32 || c.d.dtype == UVC_F32, c.w.cs_partial, out, 1.0f, alpha_ptr, c.io->accumulate, nullptr, c.st);
 }
-int ln_fwd(const Ctx& c, const float* x, int64_t pw, int64_t pb, void* y, float* mean, float* rstd, int rows, int rpg, int64_t gs) {
+int ln_fwd(const Ctx& c, const void* x, int64_t pw, int64_t pb, void* y, float* mean, float* rstd, int rows, int rpg, int64_t gs) {
   uvc_ln_args a;
   memset(&a, 0, sizeof(a));
-  a.x = x; a.gamma = c.io->params + pw; a.beta = c.io->params + pb; a.y = y; a.mean = mean; a.rstd = rstd; a.eps = c.d.eps;
+  a.x = x; a.x_lowp = c.d.rlow; a.gamma = c.io->params + pw; a.beta = c.io->params + pb; a.y = y; a.mean = mean; a.rstd = rstd; a.eps = c.d.eps;
   a.rows = rows; a.D = c.d.D; a.rows_per_group = rpg; a.group_stride = gs; a.dtype = c.d.dtype;
   return uvc_layernorm_fwd(&a, c.st);
 }
@@ -233,11 +236,11 @@ int flush_ln(Ctx& c) {
   c.n_ln = 0;
   return e;
 }
-int ln_bwd(Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, void* dx,
+int ln_bwd(Ctx& c, const void* dy, const void* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, void* dx,
            const void* add1, const float* a1, const void* add2, const float* a2, float* dots, int rows, int rpg, int64_t gs) {
   uvc_ln_args a;
   memset(&a, 0, sizeof(a));
-  a.x = x; a.gamma = c.io->params + pw; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx; a.add1 = add1; a.a1 = a1;
+  a.x = x; a.x_lowp = c.d.rlow; a.gamma = c.io->params + pw; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx; a.add1 = add1; a.a1 = a1;
   if (c.n_ln >= 2 * c.d.L + 1) { if (int e = flush_ln(c)) return e; }
   a.add2 = add2; a.a2 = a2; a.partial = c.w.ln_partial + c.w.ln_region * c.n_ln; a.dgamma = c.io->grads + pw; a.dbeta = c.io->grads + pb; a.dots = dots;
   a.defer_reduce = 1;
@@ -250,14 +253,14 @@ int ln_bwd(Ctx& c, const void* dy, const float* x, int64_t pw, int64_t pb, const
 // dgrad GEMM + LayerNorm backward in one kernel (uvc_gemm_nt_lnbwd) where the shape allows; registers the call's partial
 // region with the batched finish exactly like ln_bwd
 bool lnb_fused_ok(const Ctx& c, int K) { return c.io->force_generic != 1 && uvc_gemm_lnbwd_supported(c.d.M, c.d.D, K, c.d.dtype) != 0; }
-int dgrad_ln_bwd(Ctx& c, const void* A, const void* Wt, int K, const float* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, void* dx,
+int dgrad_ln_bwd(Ctx& c, const void* A, const void* Wt, int K, const void* x, int64_t pw, int64_t pb, const float* mean, const float* rstd, void* dx,
                  const void* add1, const float* a1, const void* add2, const float* a2, float* dots) {
   if (c.n_ln >= 2 * c.d.L + 1) { if (int e = flush_ln(c)) return e; }
   uvc_gemm_lnbwd_args a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.W = Wt; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = c.io->params + pw; a.add1 = add1; a.a1 = a1; a.add2 = add2; a.a2 = a2;
   a.dx = dx; a.partial = c.w.ln_partial + c.w.ln_region * c.n_ln; a.M = c.d.M; a.D = c.d.D; a.K = K; a.dtype = c.d.dtype;
-  a.variant = c.io->force_generic == 2 ? 1 : 0;
+  a.variant = c.io->force_generic == 2 ? 1 : 0; a.x_lowp = c.d.rlow;
   uvc_ln_reduce_item& it = c.ln_items[c.n_ln++];
   it.partial = a.partial; it.dgamma = c.io->grads + pw; it.dbeta = c.io->grads + pb; it.dots = dots; it.nblocks = uvc_gemm_lnbwd_nblocks(c.d.M); it.reserved = 0;
   return uvc_gemm_nt_lnbwd(&a, c.st);
@@ -442,24 +445,25 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
   // hard block skip (:496-500).  In training the input of a block that runs must sit in its own w.blk[l].x (backward
   // reads it there), so the buffer chain hops over skipped blocks: producer -> x of the next block that runs.
   auto runs = [&](int l) { return io->gate_d || !io->run_block || io->run_block[l] != 0; };
-  auto next_in = [&](int l) -> float* {
+  auto next_in = [&](int l) -> void* {
     for (int j = l; j < d.L; ++j)
       if (runs(j)) return w.blk[j].x;
     return w.xL;
   };
-  float* x0 = io->training ? next_in(0) : w.blk[0].x;
+  void* x0 = io->training ? next_in(0) : w.blk[0].x;
   TRY(uvc_assemble_tokens(w.pe, P + o.cls_token, d.ntok == 2 ? P + o.dist_token : nullptr, P + o.pos_embed, io->patch_mask, x0, d.B, d.np,
-                          d.D, d.ntok, stream));
-  float* xin = x0;
+                          d.D, d.ntok, d.rlow, stream));
+  void* xin = x0;
   const int tl = tail_block(c);
   const TailBufs& t = w.tail;
   const int Rt = d.B * d.ntok;
+  const int rf = d.rlow ? 0 : 1;             // "C is float32" flag of the GEMMs that write residual-stream rows (their R / R2 have C's type)
   bool h1_ready = false;                     // norm1 of the coming block already in its h1 (epilogue of the producer of its input)
   auto next_running = [&](int l) { for (int j = l + 1; j < d.L; ++j) if (runs(j)) return j; return -1; };
   for (int l = 0; l < d.L; ++l) {
     if (!runs(l)) continue;
     const bool tail = l == tl;
-    float* xout = tail ? t.xoutc : io->training ? next_in(l + 1) : (xin == w.blk[0].x ? w.xL : w.blk[0].x);
+    void* xout = tail ? t.xoutc : io->training ? next_in(l + 1) : (xin == w.blk[0].x ? w.xL : w.blk[0].x);
     const BlockBufs& b = w.blk[l];
     const int64_t* q = o.blk[l];
     if (!h1_ready) TRY(ln_fwd(c, xin, q[0], q[1], b.h1, b.mean1, b.rstd1, d.M, 1, d.D));      // else: written by the previous block's MLP kernel
@@ -467,14 +471,14 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, d.qkv_bias ? UVC_EPI_BIAS : UVC_EPI_NONE, d.qkv_bias ? P + q[3] : nullptr));
     // From here on the last block works on its token rows only (rows = B * ntok, compact buffers): nothing else of it reaches the head
     const int rows = tail ? Rt : d.M;
-    const float* xres = xin;                 // the block's input rows: residual of proj, R2 of the gate mix
-    float* x1 = tail ? t.x1c : b.x1;
+    const void* xres = xin;                  // the block's input rows: residual of proj, R2 of the gate mix
+    void* x1 = tail ? t.x1c : b.x1;
     void* h2 = tail ? t.h2c : b.h2;
     float* mean2 = tail ? t.mean2c : b.mean2; float* rstd2 = tail ? t.rstd2c : b.rstd2;
     void* ga = tail ? t.ac : b.a; void* gu = tail ? t.uc : b.u;
     if (tail) {
       TRY(attn_tok(c, b, false, l));
-      TRY(gather_tok(c, xin, t.xc, 4));
+      TRY(gather_tok(c, xin, t.xc, d.rsz));
       xres = t.xc;
     } else {
       TRY(attn(c, b, false, l));
@@ -492,7 +496,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     const bool ln2_in_proj = !tail && !mlp_one_kernel && io->fuse_next_ln != 0 && uvc_gemm_nt_ln_supported(rows, d.D, d.D, d.dtype, UVC_EPI_BIAS_RESID);
     {
       const NextLn n2 = {P + q[6], P + q[7], h2, io->training ? mean2 : nullptr, io->training ? rstd2 : nullptr};
-      TRY(nt(c, tail ? t.oc : b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), x1, 1, rows, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xres, nullptr, nullptr, nullptr, nullptr,
+      TRY(nt(c, tail ? t.oc : b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), x1, rf, rows, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xres, nullptr, nullptr, nullptr, nullptr,
              nullptr, 0, 0, ln2_in_proj ? &n2 : nullptr));
     }
     if (mlp_one_kernel) {
@@ -503,7 +507,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
       uvc_mlp_args m;
       memset(&m, 0, sizeof(m));
       m.x = x1; m.gamma = P + q[6]; m.beta = P + q[7]; m.w1 = w1; m.b1 = b1;
-      m.w2 = w2; m.b2 = P + q[11]; m.out = xout; m.M = rows; m.D = d.D; m.F = Fe; m.eps = d.eps;
+      m.w2 = w2; m.b2 = P + q[11]; m.out = xout; m.M = rows; m.D = d.D; m.F = Fe; m.eps = d.eps; m.rows_lowp = d.rlow;
       if (io->training) {
         m.h = h2; m.mean = mean2; m.rstd = rstd2; m.gp = ga; m.u = gu;
         if (io->gate_d) { m.x_prev = xres; m.gate = io->gate_d + 2 * l; }
@@ -537,9 +541,9 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
       }
     }
     if (io->gate_d)
-      TRY(nt(c, gu, 0, w2, xout, 1, rows, d.D, Fe, UVC_EPI_BIAS_RESID_GATE, P + q[11], x1, xres, nullptr, io->gate_d + 2 * l, nullptr, nullptr, 0, 0, pnl));
+      TRY(nt(c, gu, 0, w2, xout, rf, rows, d.D, Fe, UVC_EPI_BIAS_RESID_GATE, P + q[11], x1, xres, nullptr, io->gate_d + 2 * l, nullptr, nullptr, 0, 0, pnl));
     else
-      TRY(nt(c, gu, 0, w2, xout, 1, rows, d.D, Fe, UVC_EPI_BIAS_RESID, P + q[11], x1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, pnl));
+      TRY(nt(c, gu, 0, w2, xout, rf, rows, d.D, Fe, UVC_EPI_BIAS_RESID, P + q[11], x1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, pnl));
     xin = xout;
   }
   if (io->training && tl < 0 && xin != w.xL) return uvc_set_error_msg(UVC_ERR_LAUNCH, "uvc_vit_forward: internal buffer chain broken");
@@ -608,7 +612,7 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     const int rows = tail ? d.B * d.ntok : d.M;
     void* gA = tail ? t.gAc : w.gA; void* gB = tail ? t.gBc : w.gB; void* dA = tail ? t.dAc : w.dA; void* dH = tail ? t.dHc : w.dH;
     const void* fa = tail ? t.ac : b.a; const void* fu = tail ? t.uc : b.u; const void* fh2 = tail ? t.h2c : b.h2;
-    const float* fx1 = tail ? t.x1c : b.x1; const float* fm2 = tail ? t.mean2c : b.mean2; const float* fr2 = tail ? t.rstd2c : b.rstd2;
+    const void* fx1 = tail ? t.x1c : b.x1; const float* fm2 = tail ? t.mean2c : b.mean2; const float* fr2 = tail ? t.rstd2c : b.rstd2;
     const int bGA = tail ? BUF_OTHER : BUF_GA, bDA = tail ? BUF_OTHER : BUF_DA, bGB = tail ? BUF_OTHER : BUF_GB;
     const uvc_mlp_compact* mc = (io->mlp_compact && io->mlp_compact[l].width > 0 && io->mlp_compact[l].width < d.F) ? &io->mlp_compact[l] : nullptr;
     const bool fuse2 = !mc && !tail && lnb_fused_ok(c, d.F);

@@ -27,7 +27,8 @@ __all__ = ["DistilledVisionTransformer", "PatchEmbed", "Attention", "Mlp", "Bloc
 
 class uvc_vit_cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("img_size", "patch_size", "in_chans", "num_classes", "embed_dim", "depth",
-                                         "num_heads", "hidden", "ntok", "dtype")] + [("ln_eps", C.c_float), ("no_qkv_bias", C.c_int32)]
+                                         "num_heads", "hidden", "ntok", "dtype")] + [("ln_eps", C.c_float), ("no_qkv_bias", C.c_int32),
+                                                                                       ("resid_f32", C.c_int32), ("reserved", C.c_int32)]
 
 
 MAXD = 32
@@ -67,6 +68,9 @@ class uvc_mlp_compact(C.Structure):
 # model.full_tail = True, runs every row as the reference does (A/B measurements, tests).
 _FULL_TAIL_DEFAULT = os.environ.get("UVC_FULL_TAIL", "0") not in ("", "0")
 _FUSE_NEXT_LN_DEFAULT = os.environ.get("UVC_FUSE_NEXT_LN", "1") not in ("", "0")       # norm1 of block l+1 written by the kernel that produces its input rows
+# bf16 mode: the residual stream (the rows every block reads and writes) is bf16 like every other activation; UVC_RESID_F32=1 or
+# DistilledVisionTransformer(..., resid_f32=True) keeps the float32 rows of rounds 1-2 (A/B runs).  uvc_vit_cfg.resid_f32.
+_RESID_F32_DEFAULT = os.environ.get("UVC_RESID_F32", "0") not in ("", "0")
 _FUSED_TRAIN_MLP_DEFAULT = os.environ.get("UVC_FUSED_TRAIN_MLP", "0") not in ("", "0")     # training forward: one MLP kernel instead of three (slower: opt-in)
 
 
@@ -203,15 +207,18 @@ class DistilledVisionTransformer(nn.Module):
                  patch_hard=False, *, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768,
                  depth=12, num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, drop_rate=0.,
                  attn_drop_rate=0., drop_path_rate=0., norm_layer=None, act_layer=None, weight_init='',
-                 precision="bf16", device=None):
+                 precision="bf16", device=None, resid_f32=None):
         super().__init__()
         if drop_rate or attn_drop_rate or drop_path_rate or representation_size:
             raise NotImplementedError("dropout / drop-path / representation layer are 0/None on the UVC path "
                                       "(joint_train.py:137-138) and are not implemented")
         if not qkv_bias:
             raise NotImplementedError("qkv_bias=False (T2T blocks) is not on the DeiT hot path")
+        if precision == "bf16_f32resid":      # the bf16 mode of rounds 1-2: bf16 operands, float32 residual-stream rows (A/B runs)
+            precision, resid_f32 = "bf16", True
         if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' (throughput) or 'fp32' (exact float32 MFMA, parity mode)")
+            raise ValueError("precision must be 'bf16' (throughput), 'bf16_f32resid' (bf16 operands, float32 residual rows) or 'fp32' "
+                             "(exact float32 MFMA, parity mode)")
         dev = torch.device(device if device is not None else "cuda")
         if dev.type != "cuda":
             raise L.UvcHipError("uvc_amd models run on MI355X only (no CPU fallback)")
@@ -253,6 +260,8 @@ class DistilledVisionTransformer(nn.Module):
         # --- engine state
         self._cfg = uvc_vit_cfg(img_size, patch_size, in_chans, num_classes, embed_dim, depth, num_heads,
                                 int(embed_dim * mlp_ratio), self.num_tokens, ops.UVC_F32 if precision == "fp32" else ops.UVC_BF16)
+        self.resid_f32 = bool(_RESID_F32_DEFAULT if resid_f32 is None else resid_f32) or precision == "fp32"
+        self._cfg.resid_f32 = int(self.resid_f32)
         self._off = uvc_vit_offsets()
         self._soff = uvc_vit_shadow_offsets()
         L.check(_bind().uvc_vit_layout(C.byref(self._cfg), C.byref(self._off), C.byref(self._soff)), "uvc_vit_layout")

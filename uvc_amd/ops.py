@@ -53,6 +53,9 @@ def gemm_nt(A, B, C_, *, dtype, epilogue=EPI_NONE, bias=None, R=None, R2=None, a
     a.ldr = ldr if ldr is not None else a.ldc
     a.ldaux = ldaux if ldaux is not None else a.ldc
     a.dtype, a.a_is_f32, a.c_is_f32, a.epilogue = dtype, _is_f32(A), _is_f32(C_), epilogue
+    for t in (R, R2):
+        if t is not None and t.dtype != C_.dtype:
+            raise L.UvcHipError("gemm_nt: the residual operands R / R2 have C's element type")
     a.force_generic = int(force_generic)
     L.check(L.lib().uvc_gemm_nt(C.byref(a), L.cur_stream()), "uvc_gemm_nt")
 
@@ -142,6 +145,7 @@ def _ln_args(x, gamma, beta, rows, D, dtype, rows_per_group=1, group_stride=None
     a.rows, a.D, a.rows_per_group, a.dtype = rows, D, rows_per_group, dtype
     a.group_stride = group_stride if group_stride is not None else D * rows_per_group
     a.eps = eps
+    a.x_lowp = int(not _is_f32(x))                   # bf16 residual stream
     return a
 
 
@@ -183,7 +187,7 @@ def gemm_nt_lnbwd(A, Wt, x, mean, rstd, gamma, dx, partial, dgamma, dbeta, *, ad
     a = L.uvc_gemm_lnbwd_args()
     a.A, a.W, a.x, a.mean, a.rstd, a.gamma = (L.ptr(t) for t in (A, Wt, x, mean, rstd, gamma))
     a.add1, a.a1, a.add2, a.a2, a.dx, a.partial = (L.ptr(t) for t in (add1, a1, add2, a2, dx, partial))
-    a.M, a.D, a.K, a.dtype, a.variant = A.shape[0], x.shape[1], A.shape[1], UVC_BF16, int(variant)
+    a.M, a.D, a.K, a.dtype, a.variant, a.x_lowp = A.shape[0], x.shape[1], A.shape[1], UVC_BF16, int(variant), int(not _is_f32(x))
     L.check(L.lib().uvc_gemm_nt_lnbwd(C.byref(a), L.cur_stream()), "uvc_gemm_nt_lnbwd")
     item = (L.uvc_ln_reduce_item * 1)()
     item[0].partial, item[0].dgamma, item[0].dbeta, item[0].dots = L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dots)
@@ -203,6 +207,10 @@ def mlp_fused_fwd(x, gamma, beta, w1, b1, w2, b2, out, eps=1e-6, *, x_prev=None,
     a.x, a.gamma, a.beta, a.w1, a.b1, a.w2, a.b2, a.out = (L.ptr(t) for t in (x, gamma, beta, w1, b1, w2, b2, out))
     a.x_prev, a.gate, a.h, a.mean, a.rstd, a.gp, a.u = (L.ptr(t) for t in (x_prev, gate, h, mean, rstd, gp, u))
     a.M, a.D, a.F, a.eps = x.shape[0], x.shape[1], w1.shape[0], eps
+    a.rows_lowp = int(not _is_f32(x))                # bf16 residual stream: x, out, x_prev are bf16 rows
+    for t in (out, x_prev):
+        if t is not None and t.dtype != x.dtype:
+            raise L.UvcHipError("mlp_fused_fwd: x, out and x_prev must share one element type")
     L.check(L.lib().uvc_mlp_fused_fwd(C.byref(a), L.cur_stream()), "uvc_mlp_fused_fwd")
 
 
@@ -246,7 +254,7 @@ def patchify(x, out, P, dtype):
 def assemble_tokens(pe, cls, dist, pos, row_mask, tok, B, P, D, ntok):
     _chk(pe, cls, dist, pos, row_mask, tok)
     L.check(L.lib().uvc_assemble_tokens(L.ptr(pe), L.ptr(cls), L.ptr(dist), L.ptr(pos), L.ptr(row_mask), L.ptr(tok), B, P,
-                                        D, ntok, L.cur_stream()), "uvc_assemble_tokens")
+                                        D, ntok, int(not _is_f32(tok)), L.cur_stream()), "uvc_assemble_tokens")
 
 
 def assemble_tokens_bwd(dtok, pe, row_mask, dpe, dpos, dcls, ddist, dmask, B, P, D, ntok, dtype, beta_acc=0.0):

@@ -99,8 +99,11 @@ class T2T_ViT(DistilledVisionTransformer):
             raise NotImplementedError("t2t_vit_14 as built by joint_train.py:145: qkv_bias=False, default qk_scale")
         if token_dim != 64 or in_chans != 3 or img_size % 16:
             raise NotImplementedError("tokens-to-token kernels: token_dim 64, 3 input channels, img_size a multiple of 16")
+        resid_f32 = None
+        if precision == "bf16_f32resid":
+            precision, resid_f32 = "bf16", True
         if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+            raise ValueError("precision must be 'bf16', 'bf16_f32resid' or 'fp32'")
         dev = torch.device(device if device is not None else "cuda")
         if dev.type != "cuda":
             raise L.UvcHipError("uvc_amd models run on MI355X only (no CPU fallback)")
@@ -152,6 +155,9 @@ class T2T_ViT(DistilledVisionTransformer):
         # --- engine state: the DeiT engine with T2T's LayerNorm eps and bias-free qkv; "patch_size" 16 only sizes the sequence
         self._cfg = uvc_vit_cfg(img_size, 16, in_chans, num_classes, embed_dim, depth, num_heads, int(embed_dim * mlp_ratio), 1,
                                 ops.UVC_F32 if precision == "fp32" else ops.UVC_BF16, LN_EPS, 1)
+        from .model_distilled import _RESID_F32_DEFAULT
+        self.resid_f32 = bool(_RESID_F32_DEFAULT if resid_f32 is None else resid_f32) or precision == "fp32"
+        self._cfg.resid_f32 = int(self.resid_f32)
         self._off = uvc_vit_offsets()
         self._soff = uvc_vit_shadow_offsets()
         L.check(_bind().uvc_vit_layout(C.byref(self._cfg), C.byref(self._off), C.byref(self._soff)), "uvc_vit_layout")

@@ -885,3 +885,43 @@ def test_keyed_exp_noise_is_a_pure_function_of_its_key():
         assert abs(float((e > t).double().mean()) - math.exp(-t)) < 2e-3
     # lag-1 correlation of consecutive elements ~ 0
     assert abs(float(((e[1:] - 1) * (e[:-1] - 1)).mean())) < 3e-3
+
+
+# ---- the 256 x 256-tile LDS-DMA NT kernel of the wide models (DeiT-Small / Base, T2T-ViT: K >= 256 against N >= 256)
+@pytest.mark.parametrize("M,N,K", [(25216, 2304, 768), (25216, 3072, 768), (64 * 256 + 37, 2560, 512), (50432, 1000, 256), (40000, 1152, 1152),
+                                   (25216, 768, 3072)])
+def test_gemm_nt256_matches_generic_kernel_and_float64(M, N, K):
+    """uvc_gemm_nt on the shapes k_gemm_nt256 takes (>= 640 tiles of 256 x 256; the last shape stays on the 128 x 128 kernel), every epilogue,
+    bf16 and float32 outputs: bit-identical to the generic 128 x 128 kernel (same k-ordered accumulation chain per element, same epilogue
+    arithmetic: force_generic = 1), ragged M and N included (rows / columns past the edge are read as zeros through the buffer descriptor
+    and never stored), more than one tile per persistent workgroup, and within bf16 tolerance of float64."""
+    from uvc_amd import ops
+    A = (rnd(M, K, seed=301) * 0.5).bfloat16()
+    W = rnd(N, K, seed=302, scale=0.04).bfloat16()
+    bias = rnd(N, seed=303) * 0.1
+    gate = torch.tensor([0.3, 0.7], device=dev())
+    aux = rnd(M, N, seed=304).bfloat16()
+    ref = A.double() @ W.double().t()
+    for cdt in (torch.bfloat16, torch.float32):
+        R, R2 = rnd(M, N, seed=305).to(cdt), rnd(M, N, seed=306).to(cdt)
+        cases = [(ops.EPI_NONE, {}), (ops.EPI_BIAS, dict(bias=bias)), (ops.EPI_BIAS_RESID, dict(bias=bias, R=R)),
+                 (ops.EPI_BIAS_RESID_GATE, dict(bias=bias, R=R, R2=R2, gate=gate)), (ops.EPI_MUL_AUX, dict(aux=aux)),
+                 (ops.EPI_BIAS_GELU_OUT, dict(bias=bias))]
+        if cdt == torch.bfloat16:
+            cases.append((ops.EPI_BIAS_GELU_GRAD, dict(bias=bias, C2=True)))
+        for epi, kw in cases:
+            outs = []
+            for fg in (0, 1):
+                C1 = torch.full((M, N), float("nan"), device=dev(), dtype=cdt)
+                k2 = dict(kw)
+                if k2.get("C2") is True:
+                    k2["C2"] = torch.full((M, N), float("nan"), device=dev(), dtype=cdt)
+                ops.gemm_nt(A, W, C1, dtype=BF16, epilogue=epi, force_generic=fg, **k2)
+                outs.append((C1, k2.get("C2")))
+            assert torch.equal(outs[0][0], outs[1][0]), (epi, cdt)
+            if outs[0][1] is not None:
+                assert torch.equal(outs[0][1], outs[1][1]), (epi, cdt, "C2")
+            if epi == ops.EPI_BIAS:
+                torch.testing.assert_close(outs[0][0].double(), ref + bias.double(), rtol=2e-2, atol=2e-2)
+            if epi == ops.EPI_NONE:
+                torch.testing.assert_close(outs[0][0].double(), ref, rtol=2e-2, atol=2e-2)

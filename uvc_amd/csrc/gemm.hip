@@ -151,11 +151,26 @@ __device__ __forceinline__ float epi_scale_bias(float acc, float alpha, float bi
 __device__ __forceinline__ float epi_gate_mix(float v, float r2, float d0, float d1) { return __builtin_fmaf(d1, v, __builtin_fmaf(d0, r2, 0.0f)); }
 constexpr int EP_LD = 68;   // floats per staged accumulator row (64 + 4 pad: conflict-free 16-byte LDS writes)
 
-// Epilogue of 32 staged accumulator rows x 64 columns of one wave (stg: [32][EP_LD] floats, row r = output row mrow0 + r, columns
-// ncol0 .. ncol0 + 63): scale / bias / residual / gate mix / activation, then 16-byte row-contiguous stores.  Shared by the NT
-// kernels that leave through an LDS transpose, so that a row's bits do not depend on the kernel that produced its accumulator.
-template <typename T, typename TC, int EPI>
-__device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, const float* stg, int lane, int mrow0, int ncol0, float alpha, float d0, float d1) {
+// Epilogue of ROWS staged accumulator rows x 64 columns of one wave (row r = output row mrow0 + r, columns ncol0 .. ncol0 + 63):
+// scale / bias / residual / gate mix / activation, then 16-byte row-contiguous stores.  Shared by the NT kernels that leave through an
+// LDS transpose, so that a row's bits do not depend on the kernel that produced its accumulator.
+// Staging layouts: SWZ = false: [ROWS][EP_LD] floats (padded rows); SWZ = true: [ROWS][64] floats, the 16-byte column group cg of row r
+// at group cg ^ (r & 7) (no padding: 4 KB per 16 rows; conflict-free for the accumulator writes and for these reads).
+// bias_v: the VN bias values of this lane's columns (0 where the epilogue has no bias or the column is past N), loaded once per tile.
+template <bool SWZ> __device__ __forceinline__ float* stg_at(float* stg, int r, int cg) {
+  return SWZ ? stg + r * 64 + ((cg ^ (r & 7)) << 2) : stg + r * EP_LD + (cg << 2);
+}
+template <typename TC, int EPI> __device__ __forceinline__ void nt_load_bias(const NtArgs& g, int lane, int ncol0, float* bias_v) {
+  constexpr int VN = OutVec<TC>::VN, LPR = 64 / VN;
+  constexpr bool has_bias = EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID ||
+                            EPI == UVC_EPI_BIAS_RESID_GATE || EPI == UVC_EPI_BIAS_GELU_GRAD;
+  const int n = ncol0 + (lane % LPR) * VN;
+#pragma unroll
+  for (int e = 0; e < VN; ++e) bias_v[e] = (has_bias && n + e < g.N) ? g.bias[n + e] : 0.f;
+}
+template <typename T, typename TC, int EPI, int ROWS = 32, bool SWZ = false>
+__device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, float* stg, int lane, int mrow0, int ncol0, float alpha, float d0, float d1,
+                                                 const float* bias_v) {
   constexpr int VN = OutVec<TC>::VN;
   constexpr int LPR = 64 / VN;                  // lanes per 64-column row
   constexpr int RPI = 64 / LPR;                 // rows per wave instruction
@@ -164,19 +179,16 @@ __device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, const float* s
   const int n = ncol0 + cc;
   const bool nfull = (n + VN <= g.N) && ((g.ldc % VN) == 0);
 #pragma unroll
-  for (int it = 0; it < 32 / RPI; ++it) {
+  for (int it = 0; it < ROWS / RPI; ++it) {
     const int r = it * RPI + lane / LPR;
     const int m = mrow0 + r;
     float v[VN];
-    load_vec<float, VN>(stg + r * EP_LD + cc, v);
+    load_vec<float, 4>(stg_at<SWZ>(stg, r, cc >> 2), v);
+    if (VN == 8) load_vec<float, 4>(stg_at<SWZ>(stg, r, (cc >> 2) + 1), v + 4);
     if (m < g.M && n < g.N) {
       const size_t mo = (size_t)m;
 #pragma unroll
-      for (int e = 0; e < VN; ++e) {
-        const bool has_bias = EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID ||
-                              EPI == UVC_EPI_BIAS_RESID_GATE || EPI == UVC_EPI_BIAS_GELU_GRAD;
-        v[e] = epi_scale_bias(v[e], alpha, (has_bias && n + e < g.N) ? g.bias[n + e] : 0.f);
-      }
+      for (int e = 0; e < VN; ++e) v[e] = epi_scale_bias(v[e], alpha, bias_v[e]);
       if (EPI == UVC_EPI_BIAS_GELU_OUT) {
 #pragma unroll
         for (int e = 0; e < VN; ++e) v[e] = Gelu<T>::f(v[e]);
@@ -324,6 +336,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
   float d0 = 0.f, d1 = 1.f;
   if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
   float* stg = reinterpret_cast<float*>(smem) + w * (32 * EP_LD);
+  float bias_v[OutVec<TC>::VN];
+  nt_load_bias<TC, EPI>(g, lane, n0 + wn * 64, bias_v);
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtArgs g) {
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<f32x4*>(stg + (ii * 16 + (lane & 15)) * EP_LD + j * 16 + (lane >> 4) * 4) = acc[2 * h + ii][j];
     __syncthreads();
-    nt_epilogue_rows<T, TC, EPI>(g, stg, lane, m0 + wm * 64 + h * 32, n0 + wn * 64, alpha, d0, d1);
+    nt_epilogue_rows<T, TC, EPI>(g, stg, lane, m0 + wm * 64 + h * 32, n0 + wn * 64, alpha, d0, d1, bias_v);
     __syncthreads();
   }
 }
@@ -1747,44 +1761,50 @@ extern "C" int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* p, void* stream) {
 //     k-half 0 before the MFMAs of k-half 1 (two fragment sets, 96 registers), and the stage after next is requested right behind the
 //     barrier, a whole step before it is needed:   [read F1 | 32 MFMA F0 | wait F1, wait DMA(t+1) | barrier | DMA(t+2) | read F0' | 32 MFMA F1].
 //     All LDS reads of the loop are inline assembly: behind an LDS-DMA hipcc drains vmcnt(0) in front of any LDS read it can see.
+//   * The 8 DMA instructions of a stage are issued between the rows of the second MFMA block (one per four MFMAs): issued in a burst
+//     behind the barrier they kept the matrix pipe idle for ~800 cycles per step (every wave of the lock-stepped workgroup at once).
 //   * Epilogue through a wave-private LDS transpose, nt_epilogue_rows: the same arithmetic and stores as k_gemm_nt.
-//   * Tiles are numbered XCD-major (block b runs on XCD b % 8): all N tiles of an M tile share an L2.
+//   * One PERSISTENT workgroup per CU walks its tiles (numbered XCD-major: block b runs on XCD b % 8, so all N tiles of an M tile
+//     share an L2); the first two k-steps of the next tile are requested during the last two steps of the current one, so only the
+//     first tile of a workgroup pays the operand latency and the epilogue is the only gap between tiles.
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_OPB = 256 * 128;              // bytes of one operand tile image (256 rows x 128 B)
 constexpr int G2_STAGE = 2 * G2_OPB;           // A image + B image
-constexpr int G2_LDS = 2 * G2_STAGE;           // 128 KB
+constexpr int G2_EPI = 8 * 16 * 64 * 4;        // epilogue transpose buffers: 8 waves x 16 rows x 64 floats (swizzled, unpadded)
+constexpr int G2_LDS = 2 * G2_STAGE + G2_EPI;  // 160 KB: the whole CU
 
 struct G2Frags { u32x4 a[8]; u32x4 b[4]; };
 
+// tile number (XCD-major order: block b runs on XCD b % 8, so the tiles v, v + 8, ... share an L2) -> tile coordinates
+__device__ __forceinline__ bool g2_tile(int v, int tiles_m, int tiles_n, int& bm, int& bn) {
+  const int xcd = v & 7, q = v >> 3;
+  bn = q % tiles_n; bm = (q / tiles_n) * 8 + xcd;
+  return bm < tiles_m;
+}
+
 template <typename TC, int EPI>
-__global__ __launch_bounds__(512, 2) void k_gemm_nt256(NtArgs g, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void k_gemm_nt256(NtArgs g, int tiles_m, int tiles_n, int nvirt) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3;
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int bn = q % tiles_n, bm = (q / tiles_n) * 8 + xcd;
-  const int m0 = bm * G2_BM, n0 = bn * G2_BN;
-  if (m0 >= g.M) return;
 
   // ---- LDS-DMA: 32 wave-instructions per operand tile (8 rows x 128 B each), wave w issues instructions w, w + 8, w + 16, w + 24
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)(((size_t)(g.M - 1) * g.lda + g.K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)(((size_t)(g.N - 1) * g.ldb + g.K) * 2), 0x00020000);
   const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;         // slot (row, c) <- k-chunk c ^ (row & 7)
-  const unsigned voA = (unsigned)(((m0 + w * 8 + lrow) * g.lda + lchunk * 8) * 2);
-  const unsigned voB = (unsigned)(((n0 + w * 8 + lrow) * g.ldb + lchunk * 8) * 2);
+  const unsigned laneA = (unsigned)(((w * 8 + lrow) * g.lda + lchunk * 8) * 2), laneB = (unsigned)(((w * 8 + lrow) * g.ldb + lchunk * 8) * 2);
   const unsigned stepA = (unsigned)(64 * g.lda * 2), stepB = (unsigned)(64 * g.ldb * 2);
-  auto issue = [&](int kt, int st) {
+  // one of the 8 DMA instructions of a stage (t = 0..3: A rows 64 t .., 4..7: B rows): tile origin (voA, voB), k-step kt, stage st
+  // (voA / voB are wave-uniform byte offsets of the tile's first row: kept in SGPRs and added to the lane's offset per instruction --
+  //  the bounds check of a raw buffer covers the VGPR offset only, so the whole offset goes there)
+  auto issue1 = [&](int t, unsigned voA, unsigned voB, int kt, int st) {
     char* base = smem + st * G2_STAGE + w * 1024;
     const unsigned kb = (unsigned)(kt * G2_BK * 2);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + t * 8192), 16, voA + kb + t * stepA, 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(base + G2_OPB + t * 8192), 16, voB + kb + t * stepB, 0, 0, 0);
+    if (t < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + t * 8192), 16, laneA + (voA + kb + t * stepA), 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(base + G2_OPB + (t - 4) * 8192), 16, laneB + (voB + kb + (t - 4) * stepB), 0, 0, 0);
   };
   // ---- fragment addresses: row = lane & 15 (+ the tile's offset), k-chunk 4 ks + lane / 16, swizzled with row & 7 = lane & 7
   const unsigned s0 = lds_addr(smem);
@@ -1802,72 +1822,122 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt256(NtArgs g, int tiles_n) {
                       "+v"(F.b[0]), "+v"(F.b[1]), "+v"(F.b[2]), "+v"(F.b[3]));
   };
   f32x4 acc[8][4];
+  auto mfma_row = [&](const G2Frags& F, int i) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mfmas = [&](const G2Frags& F) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = MM::mma(__builtin_bit_cast(typename MM::Frag, F.b[j]), __builtin_bit_cast(typename MM::Frag, F.a[i]), acc[i][j]);
+    for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(__builtin_bit_cast(typename MM::Frag, F.b[j]), __builtin_bit_cast(typename MM::Frag, F.a[i]), acc[i][j]);
   };
-
-  const int nk = g.K / G2_BK;                     // >= 2 (the dispatch requires K >= 256)
-  G2Frags F0, F1;
-  issue(0, 0);
-  issue(1, 1);
-  wait_vm<8>();                                   // own part of stage 0 has landed (loads retire in order; 8 per stage and wave)
-  __builtin_amdgcn_s_barrier();
-  rdfrags(F0, 0, 0);
-  wait_lgkm<0>();
-  tie(F0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int st = kt & 1;
-    rdfrags(F1, st, 1);
-    mfmas(F0);
-    wait_lgkm<0>();                               // F1 is in registers: this wave is done with stage st
-    tie(F1);
-    wait_vm<0>();                                 // own part of stage kt + 1 has landed
-    __builtin_amdgcn_s_barrier();                 // everybody's has; nobody reads stage st any more
-    if (kt + 2 < nk) issue(kt + 2, st);
-    if (kt + 1 < nk) rdfrags(F0, st ^ 1, 0);
-    mfmas(F1);
-    wait_lgkm<0>();
-    tie(F0);
-  }
-
-  // ---- epilogue: 32 rows x 64 columns at a time through a wave-private transpose buffer (the stages are free now)
   float alpha = g.alpha;
   if (g.alpha_ptr) alpha *= *g.alpha_ptr;
   float d0 = 0.f, d1 = 1.f;
   if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
-  __syncthreads();
-  float* stg = reinterpret_cast<float*>(smem) + w * (32 * EP_LD);
+  float* const stg = reinterpret_cast<float*>(smem + 2 * G2_STAGE) + w * (16 * 64);
+
+  // ---- persistent walk over this workgroup's tiles: the k-steps of consecutive tiles form ONE stream through the two stages -- the
+  //      first two k-steps of the NEXT tile are requested in the last two iterations of the current one, so a tile's operand latency
+  //      and the previous tile's epilogue overlap
+  const int nk = g.K / G2_BK;                     // >= 4 (the dispatch requires K >= 256)
+  int v = blockIdx.x, bm = 0, bn = 0;
+  while (v < nvirt && !g2_tile(v, tiles_m, tiles_n, bm, bn)) v += gridDim.x;
+  if (v >= nvirt) return;
+  unsigned voA = (unsigned)(bm * G2_BM * g.lda * 2), voB = (unsigned)(bn * G2_BN * g.ldb * 2);
+  int par = 0;                                    // stage of the current tile's k-step 0
 #pragma unroll
-  for (int h = 0; h < 4; ++h) {
+  for (int t = 0; t < 8; ++t) issue1(t, voA, voB, 0, 0);
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+  for (int t = 0; t < 8; ++t) issue1(t, voA, voB, 1, 1);
+  wait_vm<8>();                                   // own part of the first stage has landed (loads retire in order; 8 per stage and wave)
+  __builtin_amdgcn_s_barrier();
+  G2Frags F0, F1;
+  rdfrags(F0, 0, 0);
+  wait_lgkm<0>();
+  tie(F0);
+  for (;;) {
+    // the tile after this one (its first k-steps are requested while this one finishes)
+    int vn = v + gridDim.x, bmn = 0, bnn = 0;
+    while (vn < nvirt && !g2_tile(vn, tiles_m, tiles_n, bmn, bnn)) vn += gridDim.x;
+    const bool more = vn < nvirt;
+    const unsigned voAn = more ? (unsigned)(bmn * G2_BM * g.lda * 2) : voA, voBn = more ? (unsigned)(bnn * G2_BN * g.ldb * 2) : voB;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(stg + (ii * 16 + (lane & 15)) * EP_LD + j * 16 + (lane >> 4) * 4) = acc[2 * h + ii][j];
-    __builtin_amdgcn_wave_barrier();
-    nt_epilogue_rows<T, TC, EPI>(g, stg, lane, m0 + wm * 128 + h * 32, n0 + wn * 64, alpha, d0, d1);
-    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      const int st = (kt & 1) ^ par;
+      // The order of the step is pinned (scheduling fences): left to itself hipcc sinks two thirds of the first MFMA block below the
+      // barrier, which exposes the fragment reads' latency in front of it and leaves the matrix pipe idle around it (s_memtime trace:
+      // 2950 cycles per step for 1024 cycles of MFMA issue per SIMD).  A wave never waits with nothing queued behind it: the reads of a
+      // block are requested a block ahead, the barrier sits between two MFMA blocks, and the first instructions behind it are MFMAs.
+      rdfrags(F1, st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mfma_row(F0, i);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm<0>();                             // F1 is in registers (requested 32 MFMAs ago): this wave is done with stage st
+      tie(F1);
+      wait_vm<0>();                               // own part of the next k-step's stage has landed (requested a step ago)
+      __builtin_amdgcn_s_barrier();               // everybody's has; nobody reads stage st any more
+      __builtin_amdgcn_sched_barrier(0);
+      // the stage freed now receives k-step kt + 2 of this tile, or k-step kt + 2 - nk of the next one (all scalar selects;
+      // behind the workgroup's last tile the same instructions re-load k-steps 0 / 1 of that tile: no branch around a DMA)
+      const bool tail = kt + 2 >= nk;
+      const unsigned sA = tail ? voAn : voA, sB = tail ? voBn : voB;
+      const int kk = tail ? kt + 2 - nk : kt + 2;
+      mfma_row(F1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rdfrags(F0, st ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the 8 DMA instructions of that stage go BETWEEN the MFMA rows: their issue cost (~100 cycles each) hides under the matrix pipe
+#pragma unroll
+      for (int i = 1; i < 8; ++i) {
+        issue1(i - 1, sA, sB, kk, st);
+        if (i == 7) issue1(7, sA, sB, kk, st);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(F1, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wait_lgkm<0>();
+      tie(F0);
+    }
+    // ---- epilogue: 16 rows x 64 columns at a time through this wave's private transpose buffer (behind the stages: the next tile's
+    //      operands keep arriving meanwhile).  Measured against an epilogue straight from the accumulator layout (v_permlane16_swap
+    //      pairs, 16-byte stores in 64-byte row pieces, operands read in 32-byte pieces): equal with no operands, 10-15 % of the GEMM
+    //      slower with a bias / residual / multiplier to read -- whole 128-byte row segments matter more than the LDS round trips
+    {
+      const int m0 = bm * G2_BM, n0 = bn * G2_BN;
+      float bias_v[OutVec<TC>::VN];
+      nt_load_bias<TC, EPI>(g, lane, n0 + wn * 64, bias_v);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(stg_at<true>(stg, lane & 15, j * 4 + (lane >> 4))) = acc[h][j];
+        __builtin_amdgcn_wave_barrier();
+        nt_epilogue_rows<T, TC, EPI, 16, true>(g, stg, lane, m0 + wm * 128 + h * 16, n0 + wn * 64, alpha, d0, d1, bias_v);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (!more) break;
+    v = vn; bm = bmn; bn = bnn; voA = voAn; voB = voBn;
+    par ^= nk & 1;
   }
+  wait_vm<0>();                                   // the two redundant stages behind the last tile
 }
 
 // the shapes k_gemm_nt256 takes: bf16 operands with 64-deep k tiles and 16-byte aligned rows, enough rows and columns to fill tiles
+// ... and enough tiles: one persistent workgroup per CU means ceil(tiles / 256) rounds, and with fewer than ~3 the last, partly
+// filled round costs more than the kernel gains (N = 768 at 25 k rows: 297 tiles = 2 rounds at 58 %; the 128 x 128 kernel with three
+// workgroups per CU is as fast or faster there, measured).  Operand sizes < 2 GB: 32-bit buffer offsets.
 static bool nt256_ok(const NtArgs& a, bool a_f32) {
-  return !a_f32 && a.K % 64 == 0 && a.K >= 256 && a.N >= 256 && a.M >= 2048 && a.lda % 8 == 0 && a.ldb % 8 == 0 &&
+  const int tiles = ceil_div(a.M, G2_BM) * ceil_div(a.N, G2_BN);
+  return !a_f32 && tiles >= 640 && a.K % 64 == 0 && a.K >= 256 && a.N >= 256 && a.M >= 2048 && a.lda % 8 == 0 && a.ldb % 8 == 0 &&
          (((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0 && (size_t)a.M * a.lda * 2 < (1ull << 31) && (size_t)a.N * a.ldb * 2 < (1ull << 31);
 }
 template <typename TC>
 static int launch_nt256(const NtArgs& a, int epi, hipStream_t st) {
   const int tm = ceil_div(a.M, G2_BM), tn = ceil_div(a.N, G2_BN);
-  const int grid = ceil_div(tm, 8) * 8 * tn;
-#define G2_CASE(E) case E: UVC_MAX_LDS(G2_LDS, k_gemm_nt256<TC, E>); k_gemm_nt256<TC, E><<<grid, 512, G2_LDS, st>>>(a, tn); break;
+  const int nvirt = ceil_div(tm, 8) * 8 * tn;               // tile numbers incl. the holes of the XCD-major order (M tiles padded to the 8 XCDs)
+  const int grid = nvirt < 256 ? nvirt : 256;               // one persistent workgroup per CU
+#define G2_CASE(E) case E: UVC_MAX_LDS(G2_LDS, k_gemm_nt256<TC, E>); k_gemm_nt256<TC, E><<<grid, 512, G2_LDS, st>>>(a, tm, tn, nvirt); break;
   switch (epi) {
     G2_CASE(UVC_EPI_NONE) G2_CASE(UVC_EPI_BIAS) G2_CASE(UVC_EPI_BIAS_GELU) G2_CASE(UVC_EPI_BIAS_RESID)
     G2_CASE(UVC_EPI_BIAS_RESID_GATE) G2_CASE(UVC_EPI_DGELU) G2_CASE(UVC_EPI_BIAS_GELU_OUT) G2_CASE(UVC_EPI_BIAS_GELU_GRAD) G2_CASE(UVC_EPI_MUL_AUX)

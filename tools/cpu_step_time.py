@@ -8,11 +8,13 @@ from uvc_amd.stage1 import Stage1Trainer, default_args
 from uvc_amd.optim import clip_grad_norm_
 from uvc_amd.uvc_optimizer import uvc_optimizer
 
-a = default_args(train_batch_size=512)
+MODEL = os.environ.get("STEP_MODEL", "deit_tiny_patch16_224")
+BATCH = int(os.environ.get("STEP_BATCH", 512))
+a = default_args(model_type=MODEL, train_batch_size=BATCH, **({"enable_patch_gating": 2} if "t2t" in MODEL else {}))
 tr = Stage1Trainer(a)
 tr.begin_epoch(a.warmup_epochs + 1)
-x = torch.randn(512, 3, 224, 224, device="cuda")
-y = torch.softmax(torch.randn(512, 1000, device="cuda"), -1)
+x = torch.randn(BATCH, 3, 224, 224, device="cuda")
+y = torch.softmax(torch.randn(BATCH, 1000, device="cuda"), -1)
 for _ in range(5):
     tr.step(x, y)
 torch.cuda.synchronize()
@@ -33,6 +35,6 @@ for _ in range(N):
 host = (time.perf_counter() - t_all) / N
 torch.cuda.synchronize()
 total = (time.perf_counter() - t_all) / N
-print("host enqueue ms/step %.3f   device-inclusive ms/step %.3f" % (host * 1e3, total * 1e3))
+print("%s batch %d: host enqueue ms/step %.3f   device-inclusive ms/step %.3f" % (MODEL, BATCH, host * 1e3, total * 1e3))
 for k, v in ph.items():
     print("  %-12s %.3f ms" % (k, v / N * 1e3))

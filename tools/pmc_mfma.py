@@ -9,8 +9,10 @@ rocprof MFMA utilisation and HBM GB/s").
     python tools/pmc_mfma.py gpurun_out/pmc_m profiles/r3_pmc_mfma.json [commit]
 
 Units (MI355X_MICROARCH.md, per-instruction constants): SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles summed over the chip's 1024 SIMDs,
-GRBM_GUI_ACTIVE the cycles the launch kept the GPU busy, SQ_WAVE_CYCLES quad-cycles summed over waves.  So
-    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024)
+GRBM_GUI_ACTIVE the cycles the launch kept the GPU busy SUMMED OVER THE 8 XCDs (each XCD has its own GRBM: the per-dispatch value is 8 x
+the launch's cycles -- checked against the kernel-trace duration: qkv 806 684 / 8 = 100.8 k cycles for 41.1 us = 2.45 GHz),
+SQ_WAVE_CYCLES quad-cycles summed over waves.  So
+    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)
 is the fraction of matrix-pipe cycles in use over the launch (1.0 = every SIMD's pipe busy every cycle), and
     mfma_flops_frac = SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512 flop / (GRBM_GUI_ACTIVE * 1024 SIMDs * 1024 flop per cycle and SIMD)
 the same from the executed bf16 MFMA operations (one MOP = 512 flop; a SIMD peaks at 1024 bf16 flop per cycle: 2.5 PF / 1024 / 2.4 GHz).
@@ -25,6 +27,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_traffic import NAMES  # noqa: E402
 
 N_SIMD = 1024
+N_XCD = 8
 CLOCK_HZ = 2.4e9
 
 
@@ -66,9 +69,10 @@ def main(d, out, commit=None):
                 ns += sum(dv) / len(dv)
         if not ok or "SQ_VALU_MFMA_BUSY_CYCLES" not in tot:
             continue
-        cycles = tot.get("GRBM_GUI_ACTIVE") or (ns * 1e-9 * CLOCK_HZ if ns else None)
+        cycles = tot["GRBM_GUI_ACTIVE"] / N_XCD if tot.get("GRBM_GUI_ACTIVE") else (ns * 1e-9 * CLOCK_HZ if ns else None)
         ent = dict(launches=n, mfma_busy_cycles=round(tot["SQ_VALU_MFMA_BUSY_CYCLES"]), gpu_cycles=round(cycles) if cycles else None,
-                   cycles_from="GRBM_GUI_ACTIVE" if tot.get("GRBM_GUI_ACTIVE") else "kernel trace duration x 2.4 GHz",
+                   cycles_from="GRBM_GUI_ACTIVE / 8 XCDs" if tot.get("GRBM_GUI_ACTIVE") else "kernel trace duration x 2.4 GHz",
+                   clock_ghz_under_pmc=round(cycles / ns, 3) if (cycles and ns) else None,
                    launch_us_under_pmc=round(ns / 1e3, 1) if ns else None,
                    sq_busy_cycles=round(tot.get("SQ_BUSY_CYCLES", 0)), sq_wave_quad_cycles=round(tot.get("SQ_WAVE_CYCLES", 0)))
         if cycles:
@@ -79,7 +83,7 @@ def main(d, out, commit=None):
         kernels[key] = ent
     json.dump(dict(commit=commit, method="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES "
                                          "SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE over tools/kernel_table.py; mfma_busy_frac = "
-                                         "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)", kernels=kernels), open(out, "w"), indent=1)
+                                         "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)", kernels=kernels), open(out, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:26s} mfma busy {100 * v.get('mfma_busy_frac', 0):5.1f} %   flops {100 * v.get('mfma_flops_frac', 0):5.1f} % of peak   ({v['launches']} launches)")
 

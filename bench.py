@@ -116,7 +116,13 @@ def stage2_checkpoint_state(model, seed=732, skip_blocks=(4, 9)):
 def _git_head():
     try:
         import subprocess
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+        if h:
+            return h
+    except Exception:
+        pass
+    try:        # a snapshot without .git (the GPU box): the commit the snapshot was taken from, if the sender left it behind
+        return open(os.path.join(ROOT, ".commit_for_profiles")).read().strip() or None
     except Exception:
         return None
 

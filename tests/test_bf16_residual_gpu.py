@@ -212,3 +212,38 @@ def test_fused_mlp_on_bf16_rows(M, gated, train):
     diff = (nh.float() - hb.float()).abs()
     assert float(diff.max()) <= 2.0 ** -7 * float(hb.float().abs().max()) + 1e-6
     assert float((diff > 0).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("M,gated", [(100864, False), (100864 + 5, True), (16384, False), (16 * 4133 + 9, True), (197 * 1000, False)])
+def test_persistent_fused_mlp_equals_the_per_workgroup_kernel_on_row_slices(M, gated):
+    """M >= 16384 bf16 rows (inference form) run k_mlp_fused_p: one persistent 8-wave workgroup per CU that walks its 16-row tiles in
+    passes and prefetches the next pass's rows.  Rows are independent, so k_mlp_fused_v3 on slices below the threshold must give the
+    same out / next_h / next_mean / next_rstd BIT FOR BIT (the engine's batch-independence test relies on exactly that)."""
+    from uvc_amd import ops
+    D, F_ = 192, 768
+    x = (rnd(M, D, seed=71) * 1.5 + 0.2).to(bf)
+    xp = rnd(M, D, seed=72).to(bf)
+    gamma, beta = rnd(D, seed=73) * 0.2 + 1.0, rnd(D, seed=74) * 0.1
+    g2, b2n = rnd(D, seed=75) * 0.3 + 1.0, rnd(D, seed=76) * 0.2
+    W1, b1 = rnd(F_, D, seed=77, scale=0.06).to(bf), rnd(F_, seed=78) * 0.1
+    W2, b2 = rnd(D, F_, seed=79, scale=0.04).to(bf), rnd(D, seed=80) * 0.1
+    gate = torch.tensor([0.3, 0.7], device=dev()) if gated else None
+
+    def run(step):
+        out = torch.full((M, D), float("nan"), device=dev(), dtype=bf)
+        nh = torch.full((M, D), float("nan"), device=dev(), dtype=bf)
+        nm, nr = torch.full((M,), float("nan"), device=dev()), torch.full((M,), float("nan"), device=dev())
+        for lo in range(0, M, step):
+            hi = min(M, lo + step)
+            ops.mlp_fused_fwd(x[lo:hi], gamma, beta, W1, b1, W2, b2, out[lo:hi], next_gamma=g2, next_beta=b2n, next_h=nh[lo:hi],
+                              next_mean=nm[lo:hi], next_rstd=nr[lo:hi], x_prev=xp[lo:hi] if gated else None, gate=gate)
+        return out, nh, nm, nr
+
+    whole, sliced = run(M), run(12800)
+    for a, b in zip(whole, sliced):
+        assert bool(torch.isfinite(a.float()).all())
+        assert torch.equal(a, b)
+    # and without the fused next LayerNorm
+    o2 = torch.empty(M, D, device=dev(), dtype=bf)
+    ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, o2, x_prev=xp if gated else None, gate=gate)
+    assert torch.equal(o2, whole[0])

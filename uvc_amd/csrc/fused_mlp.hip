@@ -11,6 +11,7 @@
 #include "common.h"
 #include "../../include/uvc_kernels.h"
 #include <utility>
+#include <algorithm>
 
 namespace {
 
@@ -405,6 +406,356 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_mlp_fused_p: the inference form for the bf16 residual stream as ONE persistent 8-wave workgroup per CU.
+// k_mlp_fused_v3 at batch 512 is two generations of workgroups (788 = 512 + 276), each [rows in: two serial HBM round trips + LayerNorm]
+// [24 chunks][rows out], all workgroups of the chip in the same phase.  Here:
+//   * a workgroup owns a contiguous range of 16-row tiles (24 or 25 at batch 512) and walks it in passes of up to 16 tiles: wave w
+//     takes tiles w and w + 8 of the pass (NT = 2), or one tile (NT = 1: the second pass has 8-9 tiles, half the MFMAs per chunk);
+//   * the weights stream through LDS ONCE per 256 rows (8 waves share a chunk: half the L2 -> LDS bytes and half the DMA instructions
+//     per wave of the 4-wave form); W2's image is unpadded (64-byte rows, 16-byte slots XOR-swizzled in the SOURCE address);
+//   * the rows of the NEXT pass are requested by LDS-DMA into the wave's own row buffer right behind iteration 0's weight request
+//     (vmcnt retires in order: the only wait that covers them is the one at the end of iteration 1) and the stores of a pass drain
+//     under the next pass's chunks; the row image is unpadded 384-byte rows, slots swizzled by (row >> 1) & 7: conflict-free for
+//     the ds_read_b128 / ds_read_b64 lane groups;
+//   * every LDS read is inline assembly (a compiler-visible LDS read behind an LDS-DMA costs s_waitcnt vmcnt(0));
+//   * per row the arithmetic is k_mlp_fused_v3's, operation for operation: outputs are bit-identical (tests/test_kernels_gpu.py).
+constexpr int P_NW = 8, P_NTH = 64 * P_NW, P_MIN_ROWS = 16384;
+constexpr int P_W2B = D * V3_FC * 2;                         // 12288
+constexpr int P_BUF = V3_W1B + P_W2B;                        // 25600
+constexpr int P_N2 = P_W2B / 1024;                           // 12 DMA instructions for W2, 13 for W1
+constexpr int P_XT = 16 * D * 2;                             // 6144: one 16-row tile of bf16 rows
+constexpr int P_OFF_X = 2 * P_BUF;
+constexpr int P_OFF_B1 = P_OFF_X + P_NW * RW * P_XT;
+constexpr int P_OFF_DUMMY = P_OFF_B1 + 4096, P_OFF_GB = P_OFF_DUMMY + 1024, P_LDS = P_OFF_GB + 5 * D * 4;   // gamma, beta, b2, next_gamma, next_beta
+static_assert(P_LDS <= 160 * 1024, "one workgroup per CU");
+static_assert(P_XT % 1024 == 0 && V3_N1 + P_N2 <= 4 * P_NW, "whole DMA instructions, four per wave and chunk");
+
+template <int OFF> __device__ __forceinline__ u32x2 ds_rd64(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ f32x4 bf4(const u32x2& q) {
+  return f32x4{__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16), __uint_as_float(q[1] & 0xffff0000u)};
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nch = a.F / V3_FC;
+  {
+    float* const sB1 = reinterpret_cast<float*>(smem + P_OFF_B1);
+    float* const sG = reinterpret_cast<float*>(smem + P_OFF_GB);
+    for (int i = tid; i < a.F; i += P_NTH) sB1[i] = a.b1[i];
+    if (tid < D) {
+      sG[tid] = a.gamma[tid]; sG[D + tid] = a.beta[tid]; sG[2 * D + tid] = a.b2[tid];
+      if (a.next_h) { sG[3 * D + tid] = a.next_gamma[tid]; sG[4 * D + tid] = a.next_beta[tid]; }
+    }
+  }
+  float d0 = 0.f, d1 = 1.f;
+  if (a.gate) { d0 = a.gate[0]; d1 = a.gate[1]; }
+  const unsigned s0 = lds_addr(smem);
+  const int t0 = (int)((long long)blockIdx.x * ntiles / gridDim.x), t1 = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  // first row of tile k of the pass that starts at tile `base` (a.M: no such tile -- its rows are masked everywhere)
+  auto tile_rows = [&](int base, int k) { return (base + k < t1) ? (base + k) * 16 : a.M; };
+
+  // ---- rows of a pass: HBM -> LDS by DMA, 6 instructions per tile.  LDS slot n = row * 24 + s' of the tile image holds the 16-byte
+  //      piece s = s' ^ ((row >> 1) & 7) of that row
+  char* const xreg = smem + P_OFF_X + w * (RW * P_XT);
+  auto rowdma = [&](int mb0, int mb1) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                                     // lane addresses recomputed per call (6 + 6 VGPRs for the kernel's life otherwise)
+    const char* xb = reinterpret_cast<const char*>(a.x);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int mb = r ? mb1 : mb0;
+#pragma unroll
+      for (int i = 0; i < P_XT / 1024; ++i) {
+        const int n = i * 64 + ln, row = n / 24, sp = n - row * 24;
+        int grow = mb + row;
+        grow = grow < a.M ? grow : a.M - 1;
+        const unsigned off = (unsigned)grow * (unsigned)(D * 2) + (unsigned)((sp ^ ((row >> 1) & 7)) * 16);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(xb + (unsigned long long)off),
+                                         (void __attribute__((address_space(3)))*)(xreg + r * P_XT + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- weights of a chunk: instructions 0..12 = W1 image (k_mlp_fused_v3's: 416-byte rows, hidden units permuted so that a lane of the
+  //      fc1 result holds 8 consecutive k of fc2), 13..24 = W2 image: slot n = row * 4 + s' holds piece s = s' ^ ((4 - (row >> 2)) & 3).
+  //      Wave w issues w, w + 8, w + 16, w + 24 -- four per chunk ALWAYS (past 24: the dummy KB).
+  unsigned doff[4];
+  const char* gsrc[4];
+  unsigned gstep[4], ldst[4], lbuf[4];
+  bool isw1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = w + P_NW * q;
+    if (j < V3_N1) {
+      const int s = j * 64 + lane, lr = s / 26, pc = s % 26;
+      const int h = ((lr >> 2) & 3) * 8 + (lr >> 4) * 4 + (lr & 3);
+      doff[q] = (unsigned)(h * D * 2 + (pc < 24 ? pc : 0) * 16);
+      gsrc[q] = reinterpret_cast<const char*>(a.w1); gstep[q] = (unsigned)(V3_FC * D * 2);
+      ldst[q] = (unsigned)(j * 1024);
+    } else {
+      const int jj = (j < V3_N1 + P_N2 ? j : V3_N1) - V3_N1;
+      const int n = jj * 64 + lane, row = n >> 2, sp = n & 3;
+      doff[q] = (unsigned)(row * a.F * 2 + (sp ^ ((4 - (row >> 2)) & 3)) * 16);
+      gsrc[q] = reinterpret_cast<const char*>(a.w2); gstep[q] = (unsigned)(V3_FC * 2);
+      ldst[q] = (unsigned)(V3_W1B + jj * 1024);
+    }
+    isw1[q] = j < V3_N1;
+    lbuf[q] = (j < V3_N1 + P_N2) ? (unsigned)P_BUF : 0u;
+  }
+  auto dma = [&](int c1, int c2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = isw1[q] ? c1 : c2;
+      const bool ok = cc < nch && lbuf[q] != 0u;
+      const char* src = gsrc[q] + (unsigned long long)((unsigned)(ok ? cc : 0) * gstep[q] + doff[q]);
+      char* dst = smem + (ok ? ldst[q] + (unsigned)(cc & 1) * lbuf[q] : (unsigned)P_OFF_DUMMY);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+  };
+
+  // per-lane LDS addresses
+  const int fx = (li >> 1) & 7;
+  const unsigned xrow = s0 + (unsigned)(P_OFF_X + w * (RW * P_XT) + li * (D * 2));
+  const unsigned xe0 = xrow + (unsigned)((g ^ fx) * 16), xe1 = xrow + (unsigned)(((4 + g) ^ fx) * 16);          // LayerNorm reads: k-steps even / odd
+  unsigned xo[4];                                                                                               // residual reads: 8-byte piece j * 4 + g
+#pragma unroll
+  for (int q = 0; q < 4; ++q) xo[q] = xrow + (unsigned)((((2 * q + (g >> 1)) ^ fx) * 16) + (g & 1) * 8);
+  const unsigned w1lane = s0 + (unsigned)(li * W1S + g * 16);
+  const unsigned w2lane = s0 + (unsigned)(V3_W1B + li * (V3_FC * 2) + ((g ^ ((4 - (li >> 2)) & 3)) * 16));
+  const unsigned b1lane = s0 + (unsigned)(P_OFF_B1 + g * 32);
+  const unsigned ga = s0 + (unsigned)(P_OFF_GB + g * 32), ba = ga + (unsigned)(D * 4);
+  const unsigned b2a = s0 + (unsigned)(P_OFF_GB + 2 * D * 4 + g * 16), nga = b2a + (unsigned)(D * 4), nba = nga + (unsigned)(D * 4);
+
+  int mb0 = tile_rows(t0, w), mb1 = tile_rows(t0, P_NW + w);
+  rowdma(mb0, mb1);
+  dma(0, nch);
+  wait_vm<0>();
+  __syncthreads();                                                  // constants staged, W1 of chunk 0 and this wave's rows landed
+  __builtin_amdgcn_sched_barrier(0);
+
+  bf16x8 hf[RW][KT];
+  f32x4 out[RW][D / 16];
+  bf16x8 uf[RW];
+  f32x4 acc[RW][2];
+
+  auto pass = [&](auto ntv, int nmb0, int nmb1) {
+    constexpr int NT = decltype(ntv)::value;
+    // ---- rows: LayerNorm2 in the MFMA B-operand layout -> hf; x1 + b2 in the accumulator layout -> out (fc2's initial accumulator)
+    static_for<NT>([&](auto rv) {
+      constexpr int r = rv.value;
+      const int mb = r ? mb1 : mb0;
+      u32x4 xq[KT];
+      static_for<KT>([&](auto ksv) { constexpr int ks = ksv.value; xq[ks] = ds_rd<r * P_XT + (ks >> 1) * 128>((ks & 1) ? xe1 : xe0); });
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(xq[4]), "+v"(xq[5]));
+      f32x4 xv[2 * KT];
+#pragma unroll
+      for (int ks = 0; ks < KT; ++ks) {
+        const u32x4 q = xq[ks];
+        xv[2 * ks] = f32x4{__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16), __uint_as_float(q[1] & 0xffff0000u)};
+        xv[2 * ks + 1] = f32x4{__uint_as_float(q[2] << 16), __uint_as_float(q[2] & 0xffff0000u), __uint_as_float(q[3] << 16), __uint_as_float(q[3] & 0xffff0000u)};
+      }
+      const float okf = (mb + li) < a.M ? 1.0f : 0.0f;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2 * KT; ++i) s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+      s = sum_rows4(s);
+      const float mean = s * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2 * KT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; q += d * d; }
+      q = sum_rows4(q);
+      const float rstd = rsqrtf(q * (1.0f / D) + a.eps);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<KT>([&](auto ksv) {
+        constexpr int ks = ksv.value;
+        u32x4 gq0 = ds_rd<ks * 128>(ga), gq1 = ds_rd<ks * 128 + 16>(ga), bq0 = ds_rd<ks * 128>(ba), bq1 = ds_rd<ks * 128 + 16>(ba);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(bq0), "+v"(bq1));
+        const f32x4 g0 = __builtin_bit_cast(f32x4, gq0), g1 = __builtin_bit_cast(f32x4, gq1);
+        const f32x4 b0 = __builtin_bit_cast(f32x4, bq0), b1 = __builtin_bit_cast(f32x4, bq1);
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y0[e] = ((xv[2 * ks][e] - mean) * rstd * g0[e] + b0[e]) * okf;
+          y1[e] = ((xv[2 * ks + 1][e] - mean) * rstd * g1[e] + b1[e]) * okf;
+        }
+        hf[r][ks] = pack8(y0, y1);
+        asm volatile("" : "+v"(hf[r][ks]));
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      static_for<D / 64>([&](auto jqv) {                           // four output tiles at a time: 4 x (8-byte residual piece, 16 bytes of b2)
+        constexpr int j0 = jqv.value * 4;
+        u32x2 xr[4];
+        u32x4 bq[4];
+        static_for<4>([&](auto qv) {
+          constexpr int j = j0 + qv.value;
+          xr[qv.value] = ds_rd64<r * P_XT + (j >> 2) * 128>(xo[j & 3]);
+          bq[qv.value] = ds_rd<j * 64>(b2a);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 x4 = bf4(xr[q4]), bv = __builtin_bit_cast(f32x4, bq[q4]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[r][j0 + q4][e] = x4[e] + bv[e];
+          asm volatile("" : "+v"(out[r][j0 + q4]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- chunk pipeline (k_mlp_fused_v3's): iteration c = fc1 of chunk c, then fc2 of chunk c - 1 with the GELU of chunk c between its MFMAs
+    auto fc1 = [&](int c) {
+      const unsigned w1a = w1lane + (unsigned)((c & 1) * P_BUF);
+      const unsigned bia = b1lane + (unsigned)(c * (V3_FC * 4));
+      u32x4 bi[2], f1[3][2];
+      bi[0] = ds_rd<0>(bia); bi[1] = ds_rd<16>(bia);
+      f1[0][0] = ds_rd<0>(w1a); f1[0][1] = ds_rd<16 * W1S>(w1a);
+      f1[1][0] = ds_rd<64>(w1a); f1[1][1] = ds_rd<16 * W1S + 64>(w1a);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<KT>([&](auto ksv) {
+        constexpr int ks = ksv.value, cur = ks % 3, nxt = (ks + 2) % 3;
+        wait_tie2<(ks + 1 < KT) ? 2 : 0>(f1[cur][0], f1[cur][1]);
+        if constexpr (ks == 0) asm volatile("" : "+v"(bi[0]), "+v"(bi[1]));
+        static_for<2>([&](auto tv) {
+          constexpr int t = tv.value;
+          const bf16x8 af = __builtin_bit_cast(bf16x8, f1[cur][t]);
+#pragma unroll
+          for (int r = 0; r < NT; ++r) acc[r][t] = mma(af, hf[r][ks], ks == 0 ? __builtin_bit_cast(f32x4, bi[t]) : acc[r][t]);
+          if constexpr (ks + 2 < KT) f1[nxt][t] = ds_rd<t * 16 * W1S + (ks + 2 < KT ? ks + 2 : 0) * 64>(w1a);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    };
+    auto fc2_gelu = [&](auto fc2v, auto geluv, int cprev) {
+      constexpr bool FC2 = decltype(fc2v)::value, GELU = decltype(geluv)::value;
+      const unsigned w2a = w2lane + (unsigned)((cprev & 1) * P_BUF);
+      u32x4 f2[6];
+      if constexpr (FC2) {
+        static_for<6>([&](auto jv) { f2[jv.value] = ds_rd<jv.value * 1024>(w2a); });
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      static_for<12>([&](auto jv) {
+        constexpr int j = jv.value, slot = j % 6;
+        if constexpr (FC2) {
+          constexpr int younger = (j < 6) ? 5 : 11 - j;
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f2[slot]) : "n"(younger));
+          const bf16x8 af = __builtin_bit_cast(bf16x8, f2[slot]);
+#pragma unroll
+          for (int r = 0; r < NT; ++r) out[r][j] = mma(af, uf[r], out[r][j]);
+          if constexpr (j + 6 < 12) f2[slot] = ds_rd<(j + 6 < 12 ? j + 6 : 0) * 1024>(w2a);
+        }
+        if constexpr (GELU && j < 8) {
+          if constexpr (NT == 2) {                                   // units 0..7 carry two values each, as in k_mlp_fused_v3
+            constexpr int r = j >> 2, t = (j >> 1) & 1, e0 = (j & 1) * 2;
+            acc[r][t][e0] = Gelu<T>::f(acc[r][t][e0]);
+            acc[r][t][e0 + 1] = Gelu<T>::f(acc[r][t][e0 + 1]);
+          } else {                                                   // one MFMA per unit: one value each
+            constexpr int t = j >> 2, e = j & 3;
+            acc[0][t][e] = Gelu<T>::f(acc[0][t][e]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (GELU) {
+#pragma unroll
+        for (int r = 0; r < NT; ++r) uf[r] = pack8(acc[r][0], acc[r][1]);
+      }
+    };
+    {
+      dma(1, 0);
+      rowdma(nmb0, nmb1);                                            // the next pass's rows (row buffer: read into registers above)
+      __builtin_amdgcn_sched_barrier(0);
+      fc1(0);
+      fc2_gelu(std::false_type{}, std::true_type{}, -1);
+      wait_vm<RW * (P_XT / 1024)>();                                 // W1 of chunk 1 landed; the row requests stay in flight
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int c = 1; c < nch; ++c) {
+      dma(c + 1 < nch ? c + 1 : 0, c);                               // (last iteration: W1 of chunk 0 for the next pass)
+      __builtin_amdgcn_sched_barrier(0);
+      fc1(c);
+      fc2_gelu(std::true_type{}, std::true_type{}, c - 1);
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    fc2_gelu(std::true_type{}, std::false_type{}, nch - 1);
+
+    // ---- out = d1 * ((x1 + b2) + mlp) + d0 * x_prev, rounded once; next_h = LayerNorm of the rounded row
+    static_for<NT>([&](auto rv) {
+      constexpr int r = rv.value;
+      const int row = (r ? mb1 : mb0) + li;
+      const bool ok = row < a.M;
+      char* orow = reinterpret_cast<char*>(a.out) + (size_t)(ok ? row : 0) * (D * 2);
+#pragma unroll
+      for (int j = 0; j < D / 16; ++j) {
+        const int col = j * 16 + g * 4;
+        f32x4 o = out[r][j];
+        if (a.gate) {
+          const f32x4 xp = bf4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.x_prev) + (size_t)(ok ? row : 0) * D + col));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(d1, o[e], __builtin_fmaf(d0, xp[e], 0.0f));
+        }
+        u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]);
+        if (ok) *reinterpret_cast<u32x2*>(orow + col * 2) = q;
+        out[r][j] = bf4(q);
+      }
+      if (a.next_h) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < D / 16; ++j) s += (out[r][j][0] + out[r][j][1]) + (out[r][j][2] + out[r][j][3]);
+        s = sum_rows4(s);
+        const float mean = s * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < D / 16; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float dd = out[r][j][e] - mean; q += dd * dd; }
+        q = sum_rows4(q);
+        const float rstd = rsqrtf(q * (1.0f / D) + a.eps);
+        if (ok && a.next_mean && g == 0) { a.next_mean[row] = mean; a.next_rstd[row] = rstd; }
+        T* hrow = reinterpret_cast<T*>(a.next_h) + (size_t)(ok ? row : 0) * D;
+        static_for<D / 64>([&](auto jqv) {
+          constexpr int j0 = jqv.value * 4;
+          u32x4 gq[4], bq[4];
+          static_for<4>([&](auto qv) { gq[qv.value] = ds_rd<(j0 + qv.value) * 64>(nga); bq[qv.value] = ds_rd<(j0 + qv.value) * 64>(nba); });
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq[0]), "+v"(gq[1]), "+v"(gq[2]), "+v"(gq[3]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 gm = __builtin_bit_cast(f32x4, gq[q4]), bt = __builtin_bit_cast(f32x4, bq[q4]);
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (out[r][j0 + q4][e] - mean) * rstd * gm[e] + bt[e];
+            u32x2 pk; pk[0] = pack_bf16x2(y[0], y[1]); pk[1] = pack_bf16x2(y[2], y[3]);
+            if (ok) *reinterpret_cast<u32x2*>(hrow + (j0 + q4) * 16 + g * 4) = pk;
+          }
+        });
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int base = t0; base < t1; base += 2 * P_NW) {
+    const int nmb0 = tile_rows(base + 2 * P_NW, w), nmb1 = tile_rows(base + 2 * P_NW, P_NW + w);
+    if (mb1 < a.M) pass(std::integral_constant<int, 2>{}, nmb0, nmb1);
+    else pass(std::integral_constant<int, 1>{}, nmb0, nmb1);
+    mb0 = nmb0; mb1 = nmb1;
+  }
+  wait_vm<0>();
+}
+
 }  // namespace
 
 extern "C" int uvc_mlp_fused_supported(int32_t D_, int32_t F, int32_t dtype) { return D_ == D && F > 0 && F % 64 == 0 && F <= 1024 && dtype == UVC_BF16; }
@@ -426,7 +777,11 @@ extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   {
 #define MLP_ONE(TR_, RL_) { UVC_MAX_LDS(V3_LDS, k_mlp_fused_v3<TR_, RL_>); k_mlp_fused_v3<TR_, RL_><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p); }
-    if (p->rows_lowp) { if (train) MLP_ONE(true, true) else MLP_ONE(false, true) }
+    if (p->rows_lowp && !train && p->M >= P_MIN_ROWS) {
+      const int ntiles = ceil_div(p->M, 16);
+      UVC_MAX_LDS(P_LDS, k_mlp_fused_p);
+      k_mlp_fused_p<<<std::min(256, ceil_div(ntiles, 2 * P_NW)), P_NTH, P_LDS, st>>>(*p, ntiles);   // one workgroup per CU
+    } else if (p->rows_lowp) { if (train) MLP_ONE(true, true) else MLP_ONE(false, true) }
     else { if (train) MLP_ONE(true, false) else MLP_ONE(false, false) }
 #undef MLP_ONE
     UVC_CHECK_LAUNCH();

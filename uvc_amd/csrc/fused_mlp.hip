@@ -410,26 +410,30 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
 // k_mlp_fused_p: the inference form for the bf16 residual stream as ONE persistent 8-wave workgroup per CU.
 // k_mlp_fused_v3 at batch 512 is two generations of workgroups (788 = 512 + 276), each [rows in: two serial HBM round trips + LayerNorm]
 // [24 chunks][rows out], all workgroups of the chip in the same phase.  Here:
-//   * a workgroup owns a contiguous range of 16-row tiles (24 or 25 at batch 512) and walks it in passes of up to 16 tiles: wave w
-//     takes tiles w and w + 8 of the pass (NT = 2), or one tile (NT = 1: the second pass has 8-9 tiles, half the MFMAs per chunk);
-//   * the weights stream through LDS ONCE per 256 rows (8 waves share a chunk: half the L2 -> LDS bytes and half the DMA instructions
-//     per wave of the 4-wave form); W2's image is unpadded (64-byte rows, 16-byte slots XOR-swizzled in the SOURCE address);
-//   * the rows of the NEXT pass are requested by LDS-DMA into the wave's own row buffer right behind iteration 0's weight request
-//     (vmcnt retires in order: the only wait that covers them is the one at the end of iteration 1) and the stores of a pass drain
-//     under the next pass's chunks; the row image is unpadded 384-byte rows, slots swizzled by (row >> 1) & 7: conflict-free for
-//     the ds_read_b128 / ds_read_b64 lane groups;
+//   * a workgroup owns a contiguous range of 16-row tiles (24 or 25 at batch 512) and walks it in passes of up to 13 tiles: tile k of a
+//     pass belongs to wave k & 7 (k >= 8: that wave's second tile), i.e. waves 0..3 run two tiles (NT = 2), waves 4..7 one (NT = 1; wave 4
+//     two in a 13-tile pass): every SIMD carries three tiles per pass, the passes of a 24-tile range are equal;
+//   * the weights stream through LDS ONCE per ~200 rows (half the L2 -> LDS bytes of the 4-wave form, three DMA instructions per wave and
+//     chunk, none of them a dummy) through THREE chunk buffers: a chunk is requested two iterations before its use -- with one request
+//     per iteration in flight the L2 -> LDS round trip (1-1.5 us) was the iteration time;
+//   * W1, W2 and the row tiles are unpadded images whose 16-byte slots are XOR-swizzled in the SOURCE address of the DMA (384-byte rows:
+//     slot ^ ((row >> 1) & 7); W2's 64-byte rows: slot ^ ((4 - (row >> 2)) & 3)): conflict-free for the ds_read_b128 / b64 lane groups;
+//   * the rows of the NEXT pass are requested by LDS-DMA into the wave's own row slots right behind iteration 0's weight request (vmcnt
+//     retires in order: the first wait that covers them is the one at the end of iteration 2) and the stores of a pass drain under the
+//     next pass's chunks;
 //   * every LDS read is inline assembly (a compiler-visible LDS read behind an LDS-DMA costs s_waitcnt vmcnt(0));
-//   * per row the arithmetic is k_mlp_fused_v3's, operation for operation: outputs are bit-identical (tests/test_kernels_gpu.py).
-constexpr int P_NW = 8, P_NTH = 64 * P_NW, P_MIN_ROWS = 16384;
-constexpr int P_W2B = D * V3_FC * 2;                         // 12288
-constexpr int P_BUF = V3_W1B + P_W2B;                        // 25600
-constexpr int P_N2 = P_W2B / 1024;                           // 12 DMA instructions for W2, 13 for W1
-constexpr int P_XT = 16 * D * 2;                             // 6144: one 16-row tile of bf16 rows
-constexpr int P_OFF_X = 2 * P_BUF;
-constexpr int P_OFF_B1 = P_OFF_X + P_NW * RW * P_XT;
-constexpr int P_OFF_DUMMY = P_OFF_B1 + 4096, P_OFF_GB = P_OFF_DUMMY + 1024, P_LDS = P_OFF_GB + 5 * D * 4;   // gamma, beta, b2, next_gamma, next_beta
+//   * per row the arithmetic is k_mlp_fused_v3's, operation for operation: outputs are bit-identical (tests/test_bf16_residual_gpu.py).
+constexpr int P_NW = 8, P_NTH = 64 * P_NW, P_MIN_ROWS = 16384, P_PASS = 13;
+constexpr int P_W1B = V3_FC * D * 2, P_W2B = D * V3_FC * 2;   // 12288 + 12288
+constexpr int P_BUF = P_W1B + P_W2B, P_NBUF = 3;
+constexpr int P_XT = 16 * D * 2;                             // 6144: one 16-row tile of bf16 rows; slot k of the pass at P_OFF_X + k * P_XT
+constexpr int P_OFF_X = P_NBUF * P_BUF;
+constexpr int P_OFF_B1 = P_OFF_X + P_PASS * P_XT;
+constexpr int P_OFF_GB = P_OFF_B1 + 4096, P_LDS = P_OFF_GB + 5 * D * 4;   // gamma, beta, b2, next_gamma, next_beta
+constexpr int P_NR = RW * (P_XT / 1024);                     // row DMA instructions per wave and pass
 static_assert(P_LDS <= 160 * 1024, "one workgroup per CU");
-static_assert(P_XT % 1024 == 0 && V3_N1 + P_N2 <= 4 * P_NW, "whole DMA instructions, four per wave and chunk");
+static_assert(P_XT % 1024 == 0 && P_BUF == 3 * P_NW * 1024, "whole DMA instructions, three per wave and chunk");
+static_assert(P_NW * P_XT + 256 < 65536, "second-tile offsets are ds_read immediates");
 
 template <int OFF> __device__ __forceinline__ u32x2 ds_rd64(unsigned addr) {
   u32x2 v;
@@ -459,19 +463,23 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
   if (a.gate) { d0 = a.gate[0]; d1 = a.gate[1]; }
   const unsigned s0 = lds_addr(smem);
   const int t0 = (int)((long long)blockIdx.x * ntiles / gridDim.x), t1 = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
-  // first row of tile k of the pass that starts at tile `base` (a.M: no such tile -- its rows are masked everywhere)
-  auto tile_rows = [&](int base, int k) { return (base + k < t1) ? (base + k) * 16 : a.M; };
+  // the passes of this range: equal shares of at most P_PASS tiles
+  int npass = (t1 - t0 + P_PASS - 1) / P_PASS;
+  // first row of tile k of a pass [pb, pb + cnt) (a.M: no such tile -- its rows are masked everywhere)
+  auto tile_rows = [&](int pb, int cnt, int k) { return (k < cnt) ? (pb + k) * 16 : a.M; };
 
-  // ---- rows of a pass: HBM -> LDS by DMA, 6 instructions per tile.  LDS slot n = row * 24 + s' of the tile image holds the 16-byte
-  //      piece s = s' ^ ((row >> 1) & 7) of that row
-  char* const xreg = smem + P_OFF_X + w * (RW * P_XT);
+  // ---- rows of a pass: HBM -> LDS by DMA, 6 instructions per tile into slot w (+ 8 for the second tile; waves 5..7 have no second
+  //      slot and fetch their first tile twice).  LDS slot n = row * 24 + s' of the tile image holds the 16-byte piece
+  //      s = s' ^ ((row >> 1) & 7) of that row
+  char* const xreg = smem + P_OFF_X + w * P_XT;
+  const int slot1 = (w + P_NW < P_PASS) ? P_NW * P_XT : 0;
   auto rowdma = [&](int mb0, int mb1) {
     int ln = lane;
-    asm volatile("" : "+v"(ln));                                     // lane addresses recomputed per call (6 + 6 VGPRs for the kernel's life otherwise)
+    asm volatile("" : "+v"(ln));                                     // lane addresses recomputed per call (12 VGPRs for the kernel's life otherwise)
     const char* xb = reinterpret_cast<const char*>(a.x);
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      const int mb = r ? mb1 : mb0;
+      const int mb = (r && slot1) ? mb1 : mb0;
 #pragma unroll
       for (int i = 0; i < P_XT / 1024; ++i) {
         const int n = i * 64 + ln, row = n / 24, sp = n - row * 24;
@@ -479,66 +487,71 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
         grow = grow < a.M ? grow : a.M - 1;
         const unsigned off = (unsigned)grow * (unsigned)(D * 2) + (unsigned)((sp ^ ((row >> 1) & 7)) * 16);
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(xb + (unsigned long long)off),
-                                         (void __attribute__((address_space(3)))*)(xreg + r * P_XT + i * 1024), 16, 0, 0);
+                                         (void __attribute__((address_space(3)))*)(xreg + (r ? slot1 : 0) + i * 1024), 16, 0, 0);
       }
     }
   };
 
-  // ---- weights of a chunk: instructions 0..12 = W1 image (k_mlp_fused_v3's: 416-byte rows, hidden units permuted so that a lane of the
-  //      fc1 result holds 8 consecutive k of fc2), 13..24 = W2 image: slot n = row * 4 + s' holds piece s = s' ^ ((4 - (row >> 2)) & 3).
-  //      Wave w issues w, w + 8, w + 16, w + 24 -- four per chunk ALWAYS (past 24: the dummy KB).
-  unsigned doff[4];
-  const char* gsrc[4];
-  unsigned gstep[4], ldst[4], lbuf[4];
-  bool isw1[4];
+  // ---- weights of a chunk: instructions 0..11 = W1 image (row lr = hidden unit (lr >> 2 & 3) * 8 + (lr >> 4) * 4 + (lr & 3) of the chunk, so
+  //      that a lane of the fc1 result holds 8 consecutive k of fc2; slots swizzled like the row tiles'), 12..23 = W2 image (slot
+  //      n = row * 4 + s' holds piece s = s' ^ ((4 - (row >> 2)) & 3)).  Wave w issues w, w + 8, w + 16.
+  unsigned doff[3];
+  const char* gsrc[3];
+  unsigned gstep[3], ldst[3];
+  bool isw1[3];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < 3; ++q) {
     const int j = w + P_NW * q;
-    if (j < V3_N1) {
-      const int s = j * 64 + lane, lr = s / 26, pc = s % 26;
+    if (j < P_W1B / 1024) {
+      const int n = j * 64 + lane, lr = n / 24, sp = n - lr * 24;
       const int h = ((lr >> 2) & 3) * 8 + (lr >> 4) * 4 + (lr & 3);
-      doff[q] = (unsigned)(h * D * 2 + (pc < 24 ? pc : 0) * 16);
+      doff[q] = (unsigned)(h * D * 2 + (sp ^ ((lr >> 1) & 7)) * 16);
       gsrc[q] = reinterpret_cast<const char*>(a.w1); gstep[q] = (unsigned)(V3_FC * D * 2);
       ldst[q] = (unsigned)(j * 1024);
     } else {
-      const int jj = (j < V3_N1 + P_N2 ? j : V3_N1) - V3_N1;
+      const int jj = j - P_W1B / 1024;
       const int n = jj * 64 + lane, row = n >> 2, sp = n & 3;
       doff[q] = (unsigned)(row * a.F * 2 + (sp ^ ((4 - (row >> 2)) & 3)) * 16);
       gsrc[q] = reinterpret_cast<const char*>(a.w2); gstep[q] = (unsigned)(V3_FC * 2);
-      ldst[q] = (unsigned)(V3_W1B + jj * 1024);
+      ldst[q] = (unsigned)(P_W1B + jj * 1024);
     }
-    isw1[q] = j < V3_N1;
-    lbuf[q] = (j < V3_N1 + P_N2) ? (unsigned)P_BUF : 0u;
+    isw1[q] = j < P_W1B / 1024;
   }
-  auto dma = [&](int c1, int c2) {
+  // W1 of chunk c1 -> buffer at byte offset o1, W2 of chunk c2 -> buffer at o2
+  auto dma = [&](int c1, unsigned o1, int c2, unsigned o2) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 3; ++q) {
       const int cc = isw1[q] ? c1 : c2;
-      const bool ok = cc < nch && lbuf[q] != 0u;
-      const char* src = gsrc[q] + (unsigned long long)((unsigned)(ok ? cc : 0) * gstep[q] + doff[q]);
-      char* dst = smem + (ok ? ldst[q] + (unsigned)(cc & 1) * lbuf[q] : (unsigned)P_OFF_DUMMY);
+      const char* src = gsrc[q] + (unsigned long long)((unsigned)cc * gstep[q] + doff[q]);
+      char* dst = smem + ldst[q] + (isw1[q] ? o1 : o2);
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
     }
   };
 
   // per-lane LDS addresses
   const int fx = (li >> 1) & 7;
-  const unsigned xrow = s0 + (unsigned)(P_OFF_X + w * (RW * P_XT) + li * (D * 2));
-  const unsigned xe0 = xrow + (unsigned)((g ^ fx) * 16), xe1 = xrow + (unsigned)(((4 + g) ^ fx) * 16);          // LayerNorm reads: k-steps even / odd
+  const unsigned sw0 = (unsigned)(li * (D * 2) + (g ^ fx) * 16), sw1 = (unsigned)(li * (D * 2) + ((4 + g) ^ fx) * 16);   // 384-byte rows: k-steps even / odd
+  const unsigned xe0 = s0 + (unsigned)(P_OFF_X + w * P_XT) + sw0, xe1 = s0 + (unsigned)(P_OFF_X + w * P_XT) + sw1;
   unsigned xo[4];                                                                                               // residual reads: 8-byte piece j * 4 + g
 #pragma unroll
-  for (int q = 0; q < 4; ++q) xo[q] = xrow + (unsigned)((((2 * q + (g >> 1)) ^ fx) * 16) + (g & 1) * 8);
-  const unsigned w1lane = s0 + (unsigned)(li * W1S + g * 16);
-  const unsigned w2lane = s0 + (unsigned)(V3_W1B + li * (V3_FC * 2) + ((g ^ ((4 - (li >> 2)) & 3)) * 16));
+  for (int q = 0; q < 4; ++q) xo[q] = s0 + (unsigned)(P_OFF_X + w * P_XT + li * (D * 2) + (((2 * q + (g >> 1)) ^ fx) * 16) + (g & 1) * 8);
+  const unsigned w1e0 = s0 + sw0, w1e1 = s0 + sw1;
+  const unsigned w2lane = s0 + (unsigned)(P_W1B + li * (V3_FC * 2) + ((g ^ ((4 - (li >> 2)) & 3)) * 16));
   const unsigned b1lane = s0 + (unsigned)(P_OFF_B1 + g * 32);
   const unsigned ga = s0 + (unsigned)(P_OFF_GB + g * 32), ba = ga + (unsigned)(D * 4);
   const unsigned b2a = s0 + (unsigned)(P_OFF_GB + 2 * D * 4 + g * 16), nga = b2a + (unsigned)(D * 4), nba = nga + (unsigned)(D * 4);
 
-  int mb0 = tile_rows(t0, w), mb1 = tile_rows(t0, P_NW + w);
+  // chunk buffers: iteration G (counted over all passes) computes fc1 from o_cur, fc2 (of the chunk before) from o_nn, and requests
+  // W1 of chunk G + 2 into o_nn and W2 of chunk G + 1 into o_nxt; then (o_cur, o_nxt, o_nn) <- (o_nxt, o_nn, o_cur)
+  unsigned o_cur = 0, o_nxt = P_BUF, o_nn = 2 * P_BUF;
+  int pb = t0, cnt = (t1 - t0 + npass - 1) / (npass > 0 ? npass : 1);
+  if (w >= P_NW / 2) __builtin_amdgcn_s_setprio(1);                 // the second-dispatched half loses every arbitration otherwise (its one-tile waves arrive last at the barrier)
+  int mb0 = tile_rows(pb, cnt, w), mb1 = tile_rows(pb, cnt, P_NW + w);
   rowdma(mb0, mb1);
-  dma(0, nch);
+  dma(0, o_cur, 0, o_cur);
+  dma(1, o_nxt, 0, o_cur);                                          // (W2 of chunk 0 a second time: three instructions per wave, always)
   wait_vm<0>();
-  __syncthreads();                                                  // constants staged, W1 of chunk 0 and this wave's rows landed
+  __syncthreads();                                                  // constants staged, chunks 0 / 1 and this wave's rows landed
   __builtin_amdgcn_sched_barrier(0);
 
   bf16x8 hf[RW][KT];
@@ -550,10 +563,10 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
     constexpr int NT = decltype(ntv)::value;
     // ---- rows: LayerNorm2 in the MFMA B-operand layout -> hf; x1 + b2 in the accumulator layout -> out (fc2's initial accumulator)
     static_for<NT>([&](auto rv) {
-      constexpr int r = rv.value;
+      constexpr int r = rv.value, XR = r * P_NW * P_XT;
       const int mb = r ? mb1 : mb0;
       u32x4 xq[KT];
-      static_for<KT>([&](auto ksv) { constexpr int ks = ksv.value; xq[ks] = ds_rd<r * P_XT + (ks >> 1) * 128>((ks & 1) ? xe1 : xe0); });
+      static_for<KT>([&](auto ksv) { constexpr int ks = ksv.value; xq[ks] = ds_rd<XR + (ks >> 1) * 128>((ks & 1) ? xe1 : xe0); });
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(xq[4]), "+v"(xq[5]));
       f32x4 xv[2 * KT];
 #pragma unroll
@@ -598,7 +611,7 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
         u32x4 bq[4];
         static_for<4>([&](auto qv) {
           constexpr int j = j0 + qv.value;
-          xr[qv.value] = ds_rd64<r * P_XT + (j >> 2) * 128>(xo[j & 3]);
+          xr[qv.value] = ds_rd64<XR + (j >> 2) * 128>(xo[j & 3]);
           bq[qv.value] = ds_rd<j * 64>(b2a);
         });
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
@@ -616,12 +629,12 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
 
     // ---- chunk pipeline (k_mlp_fused_v3's): iteration c = fc1 of chunk c, then fc2 of chunk c - 1 with the GELU of chunk c between its MFMAs
     auto fc1 = [&](int c) {
-      const unsigned w1a = w1lane + (unsigned)((c & 1) * P_BUF);
+      const unsigned a0 = w1e0 + o_cur, a1 = w1e1 + o_cur;
       const unsigned bia = b1lane + (unsigned)(c * (V3_FC * 4));
       u32x4 bi[2], f1[3][2];
       bi[0] = ds_rd<0>(bia); bi[1] = ds_rd<16>(bia);
-      f1[0][0] = ds_rd<0>(w1a); f1[0][1] = ds_rd<16 * W1S>(w1a);
-      f1[1][0] = ds_rd<64>(w1a); f1[1][1] = ds_rd<16 * W1S + 64>(w1a);
+      f1[0][0] = ds_rd<0>(a0); f1[0][1] = ds_rd<16 * D * 2>(a0);
+      f1[1][0] = ds_rd<0>(a1); f1[1][1] = ds_rd<16 * D * 2>(a1);
       __builtin_amdgcn_sched_barrier(0);
       static_for<KT>([&](auto ksv) {
         constexpr int ks = ksv.value, cur = ks % 3, nxt = (ks + 2) % 3;
@@ -632,14 +645,14 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
           const bf16x8 af = __builtin_bit_cast(bf16x8, f1[cur][t]);
 #pragma unroll
           for (int r = 0; r < NT; ++r) acc[r][t] = mma(af, hf[r][ks], ks == 0 ? __builtin_bit_cast(f32x4, bi[t]) : acc[r][t]);
-          if constexpr (ks + 2 < KT) f1[nxt][t] = ds_rd<t * 16 * W1S + (ks + 2 < KT ? ks + 2 : 0) * 64>(w1a);
+          if constexpr (ks + 2 < KT) f1[nxt][t] = ds_rd<t * 16 * D * 2 + ((ks + 2 < KT ? ks + 2 : 0) >> 1) * 128>((ks & 1) ? a1 : a0);
           __builtin_amdgcn_sched_barrier(0);
         });
       });
     };
-    auto fc2_gelu = [&](auto fc2v, auto geluv, int cprev) {
+    auto fc2_gelu = [&](auto fc2v, auto geluv) {
       constexpr bool FC2 = decltype(fc2v)::value, GELU = decltype(geluv)::value;
-      const unsigned w2a = w2lane + (unsigned)((cprev & 1) * P_BUF);
+      const unsigned w2a = w2lane + o_nn;
       u32x4 f2[6];
       if constexpr (FC2) {
         static_for<6>([&](auto jv) { f2[jv.value] = ds_rd<jv.value * 1024>(w2a); });
@@ -672,45 +685,70 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
         for (int r = 0; r < NT; ++r) uf[r] = pack8(acc[r][0], acc[r][1]);
       }
     };
+    auto rotate = [&]() { const unsigned t = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = t; };
+    // requests of iteration c: W1 of chunk c + 2, W2 of chunk c + 1 (both wrap into the next pass)
+    auto request = [&](int c) {
+      const int c1 = c + 2 < nch ? c + 2 : c + 2 - nch, c2 = c + 1 < nch ? c + 1 : 0;
+      dma(c1, o_nn, c2, o_nxt);
+    };
     {
-      dma(1, 0);
-      rowdma(nmb0, nmb1);                                            // the next pass's rows (row buffer: read into registers above)
+      request(0);
+      rowdma(nmb0, nmb1);                                            // the next pass's rows (row slots: read into registers above)
       __builtin_amdgcn_sched_barrier(0);
       fc1(0);
-      fc2_gelu(std::false_type{}, std::true_type{}, -1);
-      wait_vm<RW * (P_XT / 1024)>();                                 // W1 of chunk 1 landed; the row requests stay in flight
+      fc2_gelu(std::false_type{}, std::true_type{});
+      wait_vm<3 + P_NR>();                                           // everything older than this iteration's requests
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      rotate();
     }
-    for (int c = 1; c < nch; ++c) {
-      dma(c + 1 < nch ? c + 1 : 0, c);                               // (last iteration: W1 of chunk 0 for the next pass)
+    {
+      request(1);
+      __builtin_amdgcn_sched_barrier(0);
+      fc1(1);
+      fc2_gelu(std::true_type{}, std::true_type{});
+      wait_vm<3 + P_NR>();                                           // iteration 0's weights; the row requests behind them stay in flight
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      rotate();
+    }
+    for (int c = 2; c < nch; ++c) {
+      request(c);
       __builtin_amdgcn_sched_barrier(0);
       fc1(c);
-      fc2_gelu(std::true_type{}, std::true_type{}, c - 1);
-      wait_vm<0>();
+      fc2_gelu(std::true_type{}, std::true_type{});
+      wait_vm<3>();
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      rotate();
     }
-    fc2_gelu(std::true_type{}, std::false_type{}, nch - 1);
+    fc2_gelu(std::true_type{}, std::false_type{});
 
     // ---- out = d1 * ((x1 + b2) + mlp) + d0 * x_prev, rounded once; next_h = LayerNorm of the rounded row
     static_for<NT>([&](auto rv) {
       constexpr int r = rv.value;
       const int row = (r ? mb1 : mb0) + li;
       const bool ok = row < a.M;
-      char* orow = reinterpret_cast<char*>(a.out) + (size_t)(ok ? row : 0) * (D * 2);
+      // stores: lanes g, g ^ 1 exchange halves (v_permlane16_swap) so that a lane holds 8 consecutive columns -- of tile j (g even) or
+      // tile j + 1 (g odd): 16 bytes per lane, 64-byte row pieces, half the store instructions of the accumulator layout
+      char* orow = reinterpret_cast<char*>(a.out) + (size_t)(ok ? row : 0) * (D * 2) + ((g & 1) * 16 + (g >> 1) * 8) * 2;
 #pragma unroll
-      for (int j = 0; j < D / 16; ++j) {
-        const int col = j * 16 + g * 4;
-        f32x4 o = out[r][j];
-        if (a.gate) {
-          const f32x4 xp = bf4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.x_prev) + (size_t)(ok ? row : 0) * D + col));
+      for (int j = 0; j < D / 16; j += 2) {
+        u32x2 q[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(d1, o[e], __builtin_fmaf(d0, xp[e], 0.0f));
+        for (int t = 0; t < 2; ++t) {
+          f32x4 o = out[r][j + t];
+          if (a.gate) {
+            const f32x4 xp = bf4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.x_prev) + (size_t)(ok ? row : 0) * D + (j + t) * 16 + g * 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(d1, o[e], __builtin_fmaf(d0, xp[e], 0.0f));
+          }
+          q[t][0] = pack_bf16x2(o[0], o[1]); q[t][1] = pack_bf16x2(o[2], o[3]);
+          out[r][j + t] = bf4(q[t]);
         }
-        u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]);
-        if (ok) *reinterpret_cast<u32x2*>(orow + col * 2) = q;
-        out[r][j] = bf4(q);
+        const auto s0_ = __builtin_amdgcn_permlane16_swap(q[0][0], q[1][0], false, false);
+        const auto s1_ = __builtin_amdgcn_permlane16_swap(q[0][1], q[1][1], false, false);
+        if (ok) *reinterpret_cast<u32x4*>(orow + j * 32) = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};
       }
       if (a.next_h) {
         float s = 0.f;
@@ -726,20 +764,26 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
         q = sum_rows4(q);
         const float rstd = rsqrtf(q * (1.0f / D) + a.eps);
         if (ok && a.next_mean && g == 0) { a.next_mean[row] = mean; a.next_rstd[row] = rstd; }
-        T* hrow = reinterpret_cast<T*>(a.next_h) + (size_t)(ok ? row : 0) * D;
+        char* hrow = reinterpret_cast<char*>(a.next_h) + (size_t)(ok ? row : 0) * (D * 2) + ((g & 1) * 16 + (g >> 1) * 8) * 2;
         static_for<D / 64>([&](auto jqv) {
           constexpr int j0 = jqv.value * 4;
           u32x4 gq[4], bq[4];
           static_for<4>([&](auto qv) { gq[qv.value] = ds_rd<(j0 + qv.value) * 64>(nga); bq[qv.value] = ds_rd<(j0 + qv.value) * 64>(nba); });
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq[0]), "+v"(gq[1]), "+v"(gq[2]), "+v"(gq[3]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+          u32x2 pk[4];
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
             const f32x4 gm = __builtin_bit_cast(f32x4, gq[q4]), bt = __builtin_bit_cast(f32x4, bq[q4]);
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (out[r][j0 + q4][e] - mean) * rstd * gm[e] + bt[e];
-            u32x2 pk; pk[0] = pack_bf16x2(y[0], y[1]); pk[1] = pack_bf16x2(y[2], y[3]);
-            if (ok) *reinterpret_cast<u32x2*>(hrow + (j0 + q4) * 16 + g * 4) = pk;
+            pk[q4][0] = pack_bf16x2(y[0], y[1]); pk[q4][1] = pack_bf16x2(y[2], y[3]);
+          }
+#pragma unroll
+          for (int q4 = 0; q4 < 4; q4 += 2) {
+            const auto s0_ = __builtin_amdgcn_permlane16_swap(pk[q4][0], pk[q4 + 1][0], false, false);
+            const auto s1_ = __builtin_amdgcn_permlane16_swap(pk[q4][1], pk[q4 + 1][1], false, false);
+            if (ok) *reinterpret_cast<u32x4*>(hrow + (j0 + q4) * 32) = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};
           }
         });
       }
@@ -747,11 +791,13 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  for (int base = t0; base < t1; base += 2 * P_NW) {
-    const int nmb0 = tile_rows(base + 2 * P_NW, w), nmb1 = tile_rows(base + 2 * P_NW, P_NW + w);
+  for (int p = 0; p < npass; ++p) {
+    const int npb = pb + cnt, left = npass - 1 - p;
+    const int ncnt = left > 0 ? (t1 - npb + left - 1) / left : 0;
+    const int nmb0 = tile_rows(npb, ncnt, w), nmb1 = tile_rows(npb, ncnt, P_NW + w);
     if (mb1 < a.M) pass(std::integral_constant<int, 2>{}, nmb0, nmb1);
     else pass(std::integral_constant<int, 1>{}, nmb0, nmb1);
-    mb0 = nmb0; mb1 = nmb1;
+    mb0 = nmb0; mb1 = nmb1; pb = npb; cnt = ncnt;
   }
   wait_vm<0>();
 }
@@ -780,7 +826,7 @@ extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
     if (p->rows_lowp && !train && p->M >= P_MIN_ROWS) {
       const int ntiles = ceil_div(p->M, 16);
       UVC_MAX_LDS(P_LDS, k_mlp_fused_p);
-      k_mlp_fused_p<<<std::min(256, ceil_div(ntiles, 2 * P_NW)), P_NTH, P_LDS, st>>>(*p, ntiles);   // one workgroup per CU
+      k_mlp_fused_p<<<std::min(256, ceil_div(ntiles, P_PASS)), P_NTH, P_LDS, st>>>(*p, ntiles);   // one workgroup per CU
     } else if (p->rows_lowp) { if (train) MLP_ONE(true, true) else MLP_ONE(false, true) }
     else { if (train) MLP_ONE(true, false) else MLP_ONE(false, false) }
 #undef MLP_ONE

@@ -32,9 +32,9 @@ def build():
     body = once(body, "      rotate();\n    }\n    for (int c = 2;", "      rotate();\n      ST(2 + pidx * 30 + 2);\n    }\n    for (int c = 2;")
     body = once(body, "      rotate();\n    }\n    fc2_gelu(std::true_type{}, std::false_type{});\n", "      rotate();\n      ST(2 + pidx * 30 + 1 + c);\n    }\n    fc2_gelu(std::true_type{}, std::false_type{});\n    ST(2 + pidx * 30 + 25);\n")
     # inside iteration 10 of every pass (the last pass's values stay): after the requests, after fc1, after fc2 + GELU, after the vmcnt wait
-    body = once(body, "      request(c);\n      __builtin_amdgcn_sched_barrier(0);\n      fc1(c);\n      fc2_gelu(std::true_type{}, std::true_type{});\n      wait_vm<3>();\n",
-                "      if (c == 10) ST(59);\n      request(c);\n      __builtin_amdgcn_sched_barrier(0);\n      if (c == 10) ST(60);\n      fc1(c);\n      if (c == 10) ST(61);\n"
-                "      fc2_gelu(std::true_type{}, std::true_type{});\n      if (c == 10) ST(62);\n      wait_vm<3>();\n      if (c == 10) ST(63);\n")
+    body = once(body, "      if constexpr (LD) request(c);\n      __builtin_amdgcn_sched_barrier(0);\n      fc1(c);\n      fc2_gelu(std::true_type{}, std::true_type{});\n      if constexpr (LD) wait_vm<P_ND>();\n",
+                "      if (c == 10) ST(59);\n      if constexpr (LD) request(c);\n      __builtin_amdgcn_sched_barrier(0);\n      if (c == 10) ST(60);\n      fc1(c);\n      if (c == 10) ST(61);\n"
+                "      fc2_gelu(std::true_type{}, std::true_type{});\n      if (c == 10) ST(62);\n      if constexpr (LD) wait_vm<P_ND>();\n      if (c == 10) ST(63);\n")
     body = once(body, "    __builtin_amdgcn_sched_barrier(0);\n  };\n\n  for (int p = 0; p < npass; ++p) {", "    __builtin_amdgcn_sched_barrier(0);\n    ST(2 + pidx * 30 + 26);\n    ++pidx;\n  };\n\n  for (int p = 0; p < npass; ++p) {")
     os.makedirs("/tmp/mlpprobe", exist_ok=True)
     open("/tmp/mlpprobe/fused_mlp.hip", "w").write(head + body)

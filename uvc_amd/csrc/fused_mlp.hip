@@ -430,9 +430,10 @@ constexpr int P_XT = 16 * D * 2;                             // 6144: one 16-row
 constexpr int P_OFF_X = P_NBUF * P_BUF;
 constexpr int P_OFF_B1 = P_OFF_X + P_PASS * P_XT;
 constexpr int P_OFF_GB = P_OFF_B1 + 4096, P_LDS = P_OFF_GB + 5 * D * 4;   // gamma, beta, b2, next_gamma, next_beta
-constexpr int P_NR = RW * (P_XT / 1024);                     // row DMA instructions per wave and pass
+constexpr int P_ND = (P_BUF / 1024 - P_NW / 2) / (P_NW / 2);  // weight DMA instructions per loader wave and chunk (5; the other four waves: 1)
+constexpr int P_NR = P_XT / 1024;                            // row DMA instructions per loader wave and iteration 0..3 (one slot)
 static_assert(P_LDS <= 160 * 1024, "one workgroup per CU");
-static_assert(P_XT % 1024 == 0 && P_BUF == 3 * P_NW * 1024, "whole DMA instructions, three per wave and chunk");
+static_assert(P_XT % 1024 == 0 && P_BUF == (P_ND + 1) * (P_NW / 2) * 1024 && P_PASS <= 13, "whole DMA instructions; four loader waves, four slots each");
 static_assert(P_NW * P_XT + 256 < 65536, "second-tile offsets are ds_read immediates");
 
 template <int OFF> __device__ __forceinline__ u32x2 ds_rd64(unsigned addr) {
@@ -468,40 +469,38 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
   // first row of tile k of a pass [pb, pb + cnt) (a.M: no such tile -- its rows are masked everywhere)
   auto tile_rows = [&](int pb, int cnt, int k) { return (k < cnt) ? (pb + k) * 16 : a.M; };
 
-  // ---- rows of a pass: HBM -> LDS by DMA, 6 instructions per tile into slot w (+ 8 for the second tile; waves 5..7 have no second
-  //      slot and fetch their first tile twice).  LDS slot n = row * 24 + s' of the tile image holds the 16-byte piece
-  //      s = s' ^ ((row >> 1) & 7) of that row
-  char* const xreg = smem + P_OFF_X + w * P_XT;
-  const int slot1 = (w + P_NW < P_PASS) ? P_NW * P_XT : 0;
-  auto rowdma = [&](int mb0, int mb1) {
+  // ---- rows of a pass: HBM -> LDS by DMA, 6 instructions per tile, issued by the LOADER waves 4..7 (their one-tile passes leave them the
+  //      issue slots), one slot per iteration 0..3 of the pass before: wave 4 + i fills slots i, i + 4, i + 8 and 12 (i > 0: slot i + 8 a
+  //      second time -- four slots per wave, always).  LDS slot n = row * 24 + s' of a tile image
+  //      holds the 16-byte piece s = s' ^ ((row >> 1) & 7) of that row
+  auto rowdma = [&](int npb, int ncnt, int q) {
     int ln = lane;
-    asm volatile("" : "+v"(ln));                                     // lane addresses recomputed per call (12 VGPRs for the kernel's life otherwise)
+    asm volatile("" : "+v"(ln));                                     // lane addresses recomputed per call (VGPRs for the kernel's life otherwise)
     const char* xb = reinterpret_cast<const char*>(a.x);
+    const int slot = (q < 3 || w == P_NW / 2) ? (w & 3) + 4 * q : (w & 3) + 8;
+    const int mb = tile_rows(npb, ncnt, slot);
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      const int mb = (r && slot1) ? mb1 : mb0;
-#pragma unroll
-      for (int i = 0; i < P_XT / 1024; ++i) {
-        const int n = i * 64 + ln, row = n / 24, sp = n - row * 24;
-        int grow = mb + row;
-        grow = grow < a.M ? grow : a.M - 1;
-        const unsigned off = (unsigned)grow * (unsigned)(D * 2) + (unsigned)((sp ^ ((row >> 1) & 7)) * 16);
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(xb + (unsigned long long)off),
-                                         (void __attribute__((address_space(3)))*)(xreg + (r ? slot1 : 0) + i * 1024), 16, 0, 0);
-      }
+    for (int i = 0; i < P_XT / 1024; ++i) {
+      const int n = i * 64 + ln, row = n / 24, sp = n - row * 24;
+      int grow = mb + row;
+      grow = grow < a.M ? grow : a.M - 1;
+      const unsigned off = (unsigned)grow * (unsigned)(D * 2) + (unsigned)((sp ^ ((row >> 1) & 7)) * 16);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(xb + (unsigned long long)off),
+                                       (void __attribute__((address_space(3)))*)(smem + P_OFF_X + slot * P_XT + i * 1024), 16, 0, 0);
     }
   };
 
   // ---- weights of a chunk: instructions 0..11 = W1 image (row lr = hidden unit (lr >> 2 & 3) * 8 + (lr >> 4) * 4 + (lr & 3) of the chunk, so
   //      that a lane of the fc1 result holds 8 consecutive k of fc2; slots swizzled like the row tiles'), 12..23 = W2 image (slot
-  //      n = row * 4 + s' holds piece s = s' ^ ((4 - (row >> 2)) & 3)).  Wave w issues w, w + 8, w + 16.
-  unsigned doff[3];
-  const char* gsrc[3];
-  unsigned gstep[3], ldst[3];
-  bool isw1[3];
+  //      n = row * 4 + s' holds piece s = s' ^ ((4 - (row >> 2)) & 3)).  An LDS-DMA instruction costs its wave 100-200 cycles of issue: the two-tile
+  //      waves 0..3 (the longer chain of an iteration) issue ONE each (0..3), the loader waves 4 + i five (4 + i, 8 + i, ..., 20 + i).
+  unsigned doff[P_ND];
+  const char* gsrc[P_ND];
+  unsigned gstep[P_ND], ldst[P_ND];
+  bool isw1[P_ND];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int j = w + P_NW * q;
+  for (int q = 0; q < P_ND; ++q) {
+    const int j = (w < P_NW / 2) ? w : w + 4 * q;
     if (j < P_W1B / 1024) {
       const int n = j * 64 + lane, lr = n / 24, sp = n - lr * 24;
       const int h = ((lr >> 2) & 3) * 8 + (lr >> 4) * 4 + (lr & 3);
@@ -518,9 +517,9 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
     isw1[q] = j < P_W1B / 1024;
   }
   // W1 of chunk c1 -> buffer at byte offset o1, W2 of chunk c2 -> buffer at o2
-  auto dma = [&](int c1, unsigned o1, int c2, unsigned o2) {
+  auto dma = [&](auto nv, int c1, unsigned o1, int c2, unsigned o2) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < decltype(nv)::value; ++q) {
       const int cc = isw1[q] ? c1 : c2;
       const char* src = gsrc[q] + (unsigned long long)((unsigned)cc * gstep[q] + doff[q]);
       char* dst = smem + ldst[q] + (isw1[q] ? o1 : o2);
@@ -545,11 +544,17 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
   // W1 of chunk G + 2 into o_nn and W2 of chunk G + 1 into o_nxt; then (o_cur, o_nxt, o_nn) <- (o_nxt, o_nn, o_cur)
   unsigned o_cur = 0, o_nxt = P_BUF, o_nn = 2 * P_BUF;
   int pb = t0, cnt = (t1 - t0 + npass - 1) / (npass > 0 ? npass : 1);
-  if (w >= P_NW / 2) __builtin_amdgcn_s_setprio(1);                 // the second-dispatched half loses every arbitration otherwise (its one-tile waves arrive last at the barrier)
   int mb0 = tile_rows(pb, cnt, w), mb1 = tile_rows(pb, cnt, P_NW + w);
-  rowdma(mb0, mb1);
-  dma(0, o_cur, 0, o_cur);
-  dma(1, o_nxt, 0, o_cur);                                          // (W2 of chunk 0 a second time: three instructions per wave, always)
+  const bool loader = w >= P_NW / 2;
+  if (loader) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rowdma(pb, cnt, q);
+    dma(std::integral_constant<int, P_ND>{}, 0, o_cur, 0, o_cur);
+    dma(std::integral_constant<int, P_ND>{}, 1, o_nxt, 0, o_cur);   // (W2 of chunk 0 a second time: every instruction, always)
+  } else {
+    dma(std::integral_constant<int, 1>{}, 0, o_cur, 0, o_cur);
+    dma(std::integral_constant<int, 1>{}, 1, o_nxt, 0, o_cur);
+  }
   wait_vm<0>();
   __syncthreads();                                                  // constants staged, chunks 0 / 1 and this wave's rows landed
   __builtin_amdgcn_sched_barrier(0);
@@ -559,8 +564,9 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
   bf16x8 uf[RW];
   f32x4 acc[RW][2];
 
-  auto pass = [&](auto ntv, int nmb0, int nmb1) {
+  auto pass = [&](auto ntv, auto ldv, int npb, int ncnt) {
     constexpr int NT = decltype(ntv)::value;
+    constexpr bool LD = decltype(ldv)::value;
     // ---- rows: LayerNorm2 in the MFMA B-operand layout -> hf; x1 + b2 in the accumulator layout -> out (fc2's initial accumulator)
     static_for<NT>([&](auto rv) {
       constexpr int r = rv.value, XR = r * P_NW * P_XT;
@@ -689,35 +695,42 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
     // requests of iteration c: W1 of chunk c + 2, W2 of chunk c + 1 (both wrap into the next pass)
     auto request = [&](int c) {
       const int c1 = c + 2 < nch ? c + 2 : c + 2 - nch, c2 = c + 1 < nch ? c + 1 : 0;
-      dma(c1, o_nn, c2, o_nxt);
+      dma(std::integral_constant<int, LD ? P_ND : 1>{}, c1, o_nn, c2, o_nxt);
     };
+    __builtin_amdgcn_s_barrier();                                    // every wave has its rows in registers: the slots may be refilled
+    __builtin_amdgcn_sched_barrier(0);
+    // vmcnt retires in order.  A loader's queue per iteration c: [W(c): 5][R(c): 6 if c < 4]; the wait at the end of iteration c must
+    // cover W(c - 1) and may leave everything younger in flight.  The other waves: [W(c): 1].
     {
       request(0);
-      rowdma(nmb0, nmb1);                                            // the next pass's rows (row slots: read into registers above)
+      if constexpr (LD) rowdma(npb, ncnt, 0);                        // the next pass's rows, a slot per iteration
       __builtin_amdgcn_sched_barrier(0);
       fc1(0);
       fc2_gelu(std::false_type{}, std::true_type{});
-      wait_vm<3 + P_NR>();                                           // everything older than this iteration's requests
+      wait_vm<LD ? P_ND + P_NR : 1>();
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       rotate();
     }
-    {
-      request(1);
+#pragma nounroll
+    for (int c = 1; c < 4; ++c) {
+      request(c);
+      if constexpr (LD) rowdma(npb, ncnt, c);
       __builtin_amdgcn_sched_barrier(0);
-      fc1(1);
+      fc1(c);
       fc2_gelu(std::true_type{}, std::true_type{});
-      wait_vm<3 + P_NR>();                                           // iteration 0's weights; the row requests behind them stay in flight
+      wait_vm<LD ? P_ND + 2 * P_NR : 1>();
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       rotate();
     }
-    for (int c = 2; c < nch; ++c) {
+#pragma nounroll
+    for (int c = 4; c < nch; ++c) {
       request(c);
       __builtin_amdgcn_sched_barrier(0);
       fc1(c);
       fc2_gelu(std::true_type{}, std::true_type{});
-      wait_vm<3>();
+      if (LD && c == 4) wait_vm<LD ? P_ND + P_NR : 1>(); else wait_vm<LD ? P_ND : 1>();
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       rotate();
@@ -794,10 +807,15 @@ __global__ __launch_bounds__(P_NTH, 1) void k_mlp_fused_p(uvc_mlp_args a, int nt
   for (int p = 0; p < npass; ++p) {
     const int npb = pb + cnt, left = npass - 1 - p;
     const int ncnt = left > 0 ? (t1 - npb + left - 1) / left : 0;
-    const int nmb0 = tile_rows(npb, ncnt, w), nmb1 = tile_rows(npb, ncnt, P_NW + w);
-    if (mb1 < a.M) pass(std::integral_constant<int, 2>{}, nmb0, nmb1);
-    else pass(std::integral_constant<int, 1>{}, nmb0, nmb1);
-    mb0 = nmb0; mb1 = nmb1; pb = npb; cnt = ncnt;
+    if (loader) {
+      if (mb1 < a.M) pass(std::integral_constant<int, 2>{}, std::true_type{}, npb, ncnt);
+      else pass(std::integral_constant<int, 1>{}, std::true_type{}, npb, ncnt);
+    } else {
+      if (mb1 < a.M) pass(std::integral_constant<int, 2>{}, std::false_type{}, npb, ncnt);
+      else pass(std::integral_constant<int, 1>{}, std::false_type{}, npb, ncnt);
+    }
+    pb = npb; cnt = ncnt;
+    mb0 = tile_rows(pb, cnt, w); mb1 = tile_rows(pb, cnt, P_NW + w);
   }
   wait_vm<0>();
 }
@@ -823,7 +841,7 @@ extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   {
 #define MLP_ONE(TR_, RL_) { UVC_MAX_LDS(V3_LDS, k_mlp_fused_v3<TR_, RL_>); k_mlp_fused_v3<TR_, RL_><<<ceil_div(p->M, V3_ROWS), V3_NTH, V3_LDS, st>>>(*p); }
-    if (p->rows_lowp && !train && p->M >= P_MIN_ROWS) {
+    if (p->rows_lowp && !train && p->M >= P_MIN_ROWS && p->F >= 256) {
       const int ntiles = ceil_div(p->M, 16);
       UVC_MAX_LDS(P_LDS, k_mlp_fused_p);
       k_mlp_fused_p<<<std::min(256, ceil_div(ntiles, P_PASS)), P_NTH, P_LDS, st>>>(*p, ntiles);   // one workgroup per CU

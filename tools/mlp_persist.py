@@ -68,6 +68,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pmc":          # a few launches of each kernel for a rocprofv3 --pmc pass
         print(bench(int(sys.argv[2]) if len(sys.argv) > 2 else 100864, iters=5), bench(12800, iters=5))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "time":
+        print("M=100864: %.1f us  M=25216: %.1f us" % (bench(100864), bench(25216)))
+        sys.exit(0)
     good = True
     for M, gt in ((100864, False), (100864 + 5, False), (16384, False), (50432, True), (16 * 4133 + 9, False), (197 * 1000, False)):
         good &= check(M, gt)

@@ -28,13 +28,14 @@ def build():
     body = once(body, "  const int nch = a.F / V3_FC;\n", "  const int nch = a.F / V3_FC;\n  int pidx = 0;\n  ST(0);\n")
     body = once(body, "rows landed\n", "rows landed\n  ST(1);\n")
     body = once(body, "    auto fc1 = [&](int c) {\n      const unsigned a0", "    ST(2 + pidx * 30);\n    auto fc1 = [&](int c) {\n      const unsigned a0")
-    body = once(body, "      rotate();\n    }\n    {\n", "      rotate();\n      ST(2 + pidx * 30 + 1);\n    }\n    {\n")
-    body = once(body, "      rotate();\n    }\n    for (int c = 2;", "      rotate();\n      ST(2 + pidx * 30 + 2);\n    }\n    for (int c = 2;")
+    body = once(body, "      rotate();\n    }\n#pragma nounroll\n    for (int c = 1; c < 4; ++c) {", "      rotate();\n      ST(2 + pidx * 30 + 1);\n    }\n#pragma nounroll\n    for (int c = 1; c < 4; ++c) {")
+    body = once(body, "      rotate();\n    }\n#pragma nounroll\n    for (int c = 4;", "      rotate();\n      ST(2 + pidx * 30 + 1 + c);\n    }\n#pragma nounroll\n    for (int c = 4;")
     body = once(body, "      rotate();\n    }\n    fc2_gelu(std::true_type{}, std::false_type{});\n", "      rotate();\n      ST(2 + pidx * 30 + 1 + c);\n    }\n    fc2_gelu(std::true_type{}, std::false_type{});\n    ST(2 + pidx * 30 + 25);\n")
     # inside iteration 10 of every pass (the last pass's values stay): after the requests, after fc1, after fc2 + GELU, after the vmcnt wait
-    body = once(body, "      if constexpr (LD) request(c);\n      __builtin_amdgcn_sched_barrier(0);\n      fc1(c);\n      fc2_gelu(std::true_type{}, std::true_type{});\n      if constexpr (LD) wait_vm<P_ND>();\n",
-                "      if (c == 10) ST(59);\n      if constexpr (LD) request(c);\n      __builtin_amdgcn_sched_barrier(0);\n      if (c == 10) ST(60);\n      fc1(c);\n      if (c == 10) ST(61);\n"
-                "      fc2_gelu(std::true_type{}, std::true_type{});\n      if (c == 10) ST(62);\n      if constexpr (LD) wait_vm<P_ND>();\n      if (c == 10) ST(63);\n")
+    body = once(body, "      request(c);\n      __builtin_amdgcn_sched_barrier(0);\n      fc1(c);\n      fc2_gelu(std::true_type{}, std::true_type{});\n      if (LD && c == 4)",
+                "      if (c == 10) ST(59);\n      request(c);\n      __builtin_amdgcn_sched_barrier(0);\n      if (c == 10) ST(60);\n      fc1(c);\n      if (c == 10) ST(61);\n"
+                "      fc2_gelu(std::true_type{}, std::true_type{});\n      if (c == 10) ST(62);\n      if (LD && c == 4)")
+    body = once(body, "else wait_vm<LD ? P_ND : 1>();\n", "else wait_vm<LD ? P_ND : 1>();\n      if (c == 10) ST(63);\n")
     body = once(body, "    __builtin_amdgcn_sched_barrier(0);\n  };\n\n  for (int p = 0; p < npass; ++p) {", "    __builtin_amdgcn_sched_barrier(0);\n    ST(2 + pidx * 30 + 26);\n    ++pidx;\n  };\n\n  for (int p = 0; p < npass; ++p) {")
     os.makedirs("/tmp/mlpprobe", exist_ok=True)
     open("/tmp/mlpprobe/fused_mlp.hip", "w").write(head + body)

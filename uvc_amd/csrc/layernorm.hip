@@ -158,6 +158,22 @@ template <> struct Ld4<bf16_t> {
     *reinterpret_cast<u32x2*>(p) = r;
   }
 };
+// four elements as they sit in memory (no conversion): what a row set waiting in flight costs in registers
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+  typedef f32x4 V;
+  static __device__ __forceinline__ V ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ V zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ f32x4 cvt(const V& r) { return r; }
+};
+template <> struct Raw4<bf16_t> {
+  typedef u32x2 V;
+  static __device__ __forceinline__ V ld(const bf16_t* p) { return *reinterpret_cast<const u32x2*>(p); }
+  static __device__ __forceinline__ V zero() { return u32x2{0u, 0u}; }
+  static __device__ __forceinline__ f32x4 cvt(const V& r) {
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+  }
+};
 __device__ __forceinline__ float sum16(float v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
   return v;
@@ -233,21 +249,35 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a, int rpb) {
   const TG* add1 = reinterpret_cast<const TG*>(a.add1);
   const TG* add2 = reinterpret_cast<const TG*>(a.add2);
   struct Row { f32x4 xv[NV4], dv[NV4], ad1[NV4], ad2[NV4]; float mean, rstd; size_t off; bool ok; };
-  auto load_row = [&](Row& R, int rb) {
+  // a row set as loaded (bf16 tensors: 2 registers per 4 elements): THREE of them are in flight per wave, converted when their turn comes
+  struct RawRow {
+    typename Raw4<TX>::V xv[NV4]; typename Raw4<TDY>::V dv[NV4]; typename Raw4<TG>::V ad1[NV4], ad2[NV4];
+    float mean, rstd; size_t off; bool ok;
+  };
+  auto load_raw = [&](RawRow& R, int rb) {
     const int r = rb + rg;
     R.ok = rb < r1 && r < r1;
     R.off = R.ok ? row_off(r, a.rows_per_group, a.group_stride, a.D) : 0;
     const TX* x = reinterpret_cast<const TX*>(a.x) + R.off;
     const TDY* dy = reinterpret_cast<const TDY*>(a.dy) + (size_t)(R.ok ? r : 0) * a.D;
     R.mean = R.ok ? a.mean[r] : 0.f; R.rstd = R.ok ? a.rstd[r] : 0.f;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
-      R.ad1[i] = (R.ok && add1) ? Ld4<TG>::ld(add1 + R.off + (sub + LPR * i) * 4) : z;
-      R.ad2[i] = (R.ok && add2) ? Ld4<TG>::ld(add2 + R.off + (sub + LPR * i) * 4) : z;
-      R.dv[i] = R.ok ? Ld4<TDY>::ld(dy + (sub + LPR * i) * 4) : z;
-      R.xv[i] = R.ok ? Ld4<TX>::ld(x + (sub + LPR * i) * 4) : z;
+      R.ad1[i] = (R.ok && add1) ? Raw4<TG>::ld(add1 + R.off + (sub + LPR * i) * 4) : Raw4<TG>::zero();
+      R.ad2[i] = (R.ok && add2) ? Raw4<TG>::ld(add2 + R.off + (sub + LPR * i) * 4) : Raw4<TG>::zero();
+      R.dv[i] = R.ok ? Raw4<TDY>::ld(dy + (sub + LPR * i) * 4) : Raw4<TDY>::zero();
+      R.xv[i] = R.ok ? Raw4<TX>::ld(x + (sub + LPR * i) * 4) : Raw4<TX>::zero();
     }
+  };
+  auto convert = [&](const RawRow& W) {
+    Row R;
+    R.mean = W.mean; R.rstd = W.rstd; R.off = W.off; R.ok = W.ok;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      R.xv[i] = Raw4<TX>::cvt(W.xv[i]); R.dv[i] = Raw4<TDY>::cvt(W.dv[i]);
+      R.ad1[i] = Raw4<TG>::cvt(W.ad1[i]); R.ad2[i] = Raw4<TG>::cvt(W.ad2[i]);
+    }
+    return R;
   };
   auto process = [&](const Row& R) {
     f32x4 gy[NV4];
@@ -285,14 +315,21 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a, int rpb) {
       }
     }
   };
-  // One row set per wave (~140 VGPRs, three workgroups per CU).  A second set that kept the next rows' loads in flight
-  // during the reductions (205 VGPRs, one workgroup per CU) was 10 % faster alone with both addends, but the kernel runs
-  // next to the weight-gradient stream and could then not share a CU with it: in the step the single set is 3 % faster
-  // end to end (DeiT-Tiny 16.40 -> 15.89 ms) and ~1 % on Small / Base / T2T.
-  Row Ra;
-  for (int rb = r0 + w * RPW; rb < r1; rb += 4 * RPW) {
-    load_row(Ra, rb);
-    process(Ra);
+  // Three row sets per wave in flight, in the registers they were loaded into; the row in turn is converted and processed (same
+  // arithmetic and the same row order per lane as one set at a time: same bits).  Beside the weight-gradient stream this kernel gets
+  // one workgroup per CU instead of three, and with one set per wave its loop was an HBM round trip per 2-4 rows: 133 us in the
+  // DeiT-Small step against 71 alone (round 2's float32 second set cost 205 VGPRs and lost in the step; the raw sets cost 2-4 each
+  // per 4 elements).
+  {
+    constexpr int S = 4 * RPW;
+    RawRow A, B, C;
+    int rb = r0 + w * RPW;
+    load_raw(A, rb); load_raw(B, rb + S); load_raw(C, rb + 2 * S);
+    for (; rb < r1; rb += 3 * S) {
+      process(convert(A)); load_raw(A, rb + 3 * S);
+      process(convert(B)); load_raw(B, rb + 4 * S);
+      process(convert(C)); load_raw(C, rb + 5 * S);
+    }
   }
   // reduce the 4 row groups of the wave, then the 4 waves (fixed order)
 #pragma unroll

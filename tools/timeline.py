@@ -47,6 +47,17 @@ def main():
     for q, lst in byq.items():
         busy = sum(e - s for s, e, _ in lst)
         print(f"queue {q}: {len(lst)} kernels, busy {busy / 1e6:.2f} ms, span {(max(e for _, e, _ in lst) - min(s for s, _, _ in lst)) / 1e6:.2f} ms, first {(lst[0][0] - t0) / 1e6:.2f} ms")
+    # per-queue gaps (time the queue has nothing running inside its span) and the kernels that follow the largest ones
+    for q, lst in byq.items():
+        lst = sorted(lst)
+        gaps_q, end = [], lst[0][0]
+        for s, e, n in lst:
+            if s > end:
+                gaps_q.append((s - end, (end - t0) / 1e6, n[:60]))
+            end = max(end, e)
+        gaps_q.sort(reverse=True)
+        print(f"  queue {q}: {sum(g for g, _, _ in gaps_q) / 1e6:.2f} ms of gaps in {len(gaps_q)} gaps; largest (us @ ms -> next kernel): " +
+              "; ".join("%.0f @ %.2f -> %s" % (g / 1e3, at, n) for g, at, n in gaps_q[:6]))
     # phase markers
     def first(pred):
         for n, s, e, q, st in step:

@@ -214,13 +214,14 @@ def test_fused_mlp_on_bf16_rows(M, gated, train):
     assert float((diff > 0).float().mean()) < 0.02
 
 
-@pytest.mark.parametrize("M,gated", [(100864, False), (100864 + 5, True), (16384, False), (16 * 4133 + 9, True), (197 * 1000, False)])
-def test_persistent_fused_mlp_equals_the_per_workgroup_kernel_on_row_slices(M, gated):
+@pytest.mark.parametrize("M,gated,F_", [(100864, False, 768), (100864 + 5, True, 768), (16384, False, 768), (16 * 4133 + 9, True, 768), (197 * 1000, False, 768),
+                                        (50432, False, 256), (50432 + 3, True, 512), (33000, False, 1024), (20000, False, 192)])
+def test_persistent_fused_mlp_equals_the_per_workgroup_kernel_on_row_slices(M, gated, F_):
     """M >= 16384 bf16 rows (inference form) run k_mlp_fused_p: one persistent 8-wave workgroup per CU that walks its 16-row tiles in
     passes and prefetches the next pass's rows.  Rows are independent, so k_mlp_fused_v3 on slices below the threshold must give the
     same out / next_h / next_mean / next_rstd BIT FOR BIT (the engine's batch-independence test relies on exactly that)."""
     from uvc_amd import ops
-    D, F_ = 192, 768
+    D = 192                                               # F_: hidden widths of compacted MLPs too (192 < 256: stays on k_mlp_fused_v3)
     x = (rnd(M, D, seed=71) * 1.5 + 0.2).to(bf)
     xp = rnd(M, D, seed=72).to(bf)
     gamma, beta = rnd(D, seed=73) * 0.2 + 1.0, rnd(D, seed=74) * 0.1

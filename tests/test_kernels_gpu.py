@@ -925,3 +925,34 @@ def test_gemm_nt256_matches_generic_kernel_and_float64(M, N, K):
                 torch.testing.assert_close(outs[0][0].double(), ref + bias.double(), rtol=2e-2, atol=2e-2)
             if epi == ops.EPI_NONE:
                 torch.testing.assert_close(outs[0][0].double(), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_cast_transpose_multi_all_shadows_in_one_launch(dtype):
+    """uvc_cast_transpose_multi (the per-step refresh of every weight shadow): 64 x 64 tiles with 16-byte loads / 8-byte bf16 stores where
+    the matrix allows it, the scalar path for shapes and offsets that do not (R or C not a multiple of 4, odd offsets), both against torch."""
+    import ctypes as C
+    from uvc_amd import _lib as L, ops
+    shapes = [(576, 192), (192, 192), (768, 192), (192, 768), (1000, 192), (192, 768), (70, 36), (37, 50), (64, 64), (130, 4), (8, 260)]
+    T = ops.tdtype(dtype)
+    n = len(shapes)
+    srcs, ws, wts, off, so = [], [], [], 0, 0
+    for i, (R, Cc) in enumerate(shapes):
+        if i == 7:
+            off += 1                                       # an odd source offset: scalar path
+        srcs.append(off); off += R * Cc
+        ws.append(so if i % 3 != 2 else -1); so += R * Cc
+        wts.append(so if i % 4 != 3 else -1); so += R * Cc
+    params = rnd(off + 3, seed=91)
+    shadow = torch.full((so,), 7.0, device=dev(), dtype=T)
+    arr64 = lambda v: (C.c_int64 * n)(*v)
+    arr32 = lambda v: (C.c_int32 * n)(*v)
+    L.check(L.lib().uvc_cast_transpose_multi(L.ptr(params), L.ptr(shadow), n, arr64(srcs), arr32([s[0] for s in shapes]), arr32([s[1] for s in shapes]),
+                                             arr64(ws), arr64(wts), dtype, L.cur_stream()), "uvc_cast_transpose_multi")
+    torch.cuda.synchronize()
+    for i, (R, Cc) in enumerate(shapes):
+        W = params[srcs[i]:srcs[i] + R * Cc].view(R, Cc)
+        if ws[i] >= 0:
+            assert torch.equal(shadow[ws[i]:ws[i] + R * Cc].view(R, Cc), W.to(T)), ("w", i, R, Cc)
+        if wts[i] >= 0:
+            assert torch.equal(shadow[wts[i]:wts[i] + R * Cc].view(Cc, R), W.t().contiguous().to(T)), ("wt", i, R, Cc)

@@ -189,16 +189,30 @@ __global__ __launch_bounds__(256) void k_ln_fwd_v(uvc_ln_args a) {
   for (int i = 0; i < NV4; ++i) { gam[i] = Ld4<float>::ld(a.gamma + (sub + 16 * i) * 4); bet[i] = Ld4<float>::ld(a.beta + (sub + 16 * i) * 4); }
   const float invD = 1.0f / (float)a.D;
   const int rbase = blockIdx.x * LNV_FWD_ROWS + w * 16;
-#pragma unroll 2
-  for (int it = 0; it < 4; ++it) {
+  // the wave's four row sets (4 rows each) are ALL requested up front, in the registers they are loaded into (bf16 rows: 2 registers per 4
+  // elements), and converted when their turn comes: beside another stream's kernels this kernel gets a fraction of its three workgroups per
+  // CU, and with one or two sets in flight per wave it was an HBM round trip per 4-8 rows (26 us in the DeiT-Small step against 17 alone)
+  constexpr int PF = NV4 >= 12 ? 2 : 4;                    // (D = 768: two sets at a time -- four cost 252 registers)
+  typename Raw4<TX>::V raw[PF][NV4];
+#pragma unroll
+  for (int it0 = 0; it0 < 4; it0 += PF) {
+#pragma unroll
+  for (int it = it0; it < it0 + PF; ++it) {
     const int r = rbase + it * 4 + rg;
     const bool ok = r < a.rows;
     const TX* x = reinterpret_cast<const TX*>(a.x) + (ok ? row_off(r, a.rows_per_group, a.group_stride, a.D) : 0);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) raw[it - it0][i] = ok ? Raw4<TX>::ld(x + (sub + 16 * i) * 4) : Raw4<TX>::zero();
+  }
+#pragma unroll
+  for (int it = it0; it < it0 + PF; ++it) {
+    const int r = rbase + it * 4 + rg;
+    const bool ok = r < a.rows;
     f32x4 v[NV4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
-      v[i] = ok ? Ld4<TX>::ld(x + (sub + 16 * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[i] = Raw4<TX>::cvt(raw[it - it0][i]);
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = sum16(s) * invD;
@@ -219,6 +233,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd_v(uvc_ln_args a) {
       }
       if (sub == 0) { a.mean[r] = mean; a.rstd[r] = rstd; }
     }
+  }
   }
 }
 

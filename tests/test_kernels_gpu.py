@@ -956,3 +956,49 @@ def test_cast_transpose_multi_all_shadows_in_one_launch(dtype):
             assert torch.equal(shadow[ws[i]:ws[i] + R * Cc].view(R, Cc), W.to(T)), ("w", i, R, Cc)
         if wts[i] >= 0:
             assert torch.equal(shadow[wts[i]:wts[i] + R * Cc].view(Cc, R), W.t().contiguous().to(T)), ("wt", i, R, Cc)
+
+
+@pytest.mark.parametrize("K,with_add2,x_bf16", [(1536, False, True), (1152, True, True), (384, True, False), (1152, False, False)])
+@pytest.mark.parametrize("M", [128 * 40 + 53, 128 * 300, 50432])     # ragged last tile; more tiles than workgroups; DeiT-Small at batch 256
+def test_gemm_nt_lnbwd_row_tile_d384_equals_the_unfused_pair(K, with_add2, x_bf16, M):
+    """D = 384 (DeiT-Small, T2T-ViT-14): uvc_gemm_nt_lnbwd runs k_gemm_row384_lnbwd -- k_gemm_nt256's main loop on a 128 x 384 row tile, the
+    tile rounded to bf16 in LDS (what the GEMM of the unfused pair stores) and k_ln_bwd_v's row arithmetic over it.  dx must equal
+    uvc_gemm_nt -> uvc_layernorm_bwd BIT FOR BIT; dgamma / dbeta / dots are other partitions of the same sums; two runs bit-identical;
+    dx in place over add2."""
+    from uvc_amd import ops
+    D = 384
+    A = rnd(M, K, seed=211).to(torch.bfloat16)
+    Wt = rnd(D, K, seed=212, scale=0.04).to(torch.bfloat16)
+    x = rnd(M, D, seed=213) * 1.5 + 0.3
+    if x_bf16:
+        x = x.to(torch.bfloat16)
+    gamma = 1.0 + 0.2 * rnd(D, seed=214)
+    add1 = rnd(M, D, seed=215).to(torch.bfloat16)
+    add2 = rnd(M, D, seed=216).to(torch.bfloat16) if with_add2 else None
+    a1 = torch.tensor([0.7], device=dev())
+    a2 = torch.tensor([0.3], device=dev()) if with_add2 else None
+    mean = x.float().mean(1)
+    rstd = torch.rsqrt(x.float().var(1, unbiased=False) + 1e-6)
+    assert ops.gemm_lnbwd_supported(M, D, K, BF16)
+    nb = max(ops.layernorm_bwd_blocks(M), 256 + 16)
+    outs = []
+    for rep in range(2):
+        dx = add2.clone() if with_add2 else torch.full((M, D), float("nan"), device=dev(), dtype=torch.bfloat16)
+        part = torch.full((nb * (2 * D + 2),), float("nan"), device=dev())
+        dg, db, dots = torch.empty(D, device=dev()), torch.empty(D, device=dev()), torch.zeros(2, device=dev())
+        ops.gemm_nt_lnbwd(A, Wt, x, mean, rstd, gamma, dx, part, dg, db, add1=add1, a1=a1, add2=dx if with_add2 else None, a2=a2, dots=dots)
+        outs.append((dx.clone(), dg.clone(), db.clone(), dots.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "not deterministic"
+    dx, dg, db, dots = outs[0]
+    dyb = torch.empty(M, D, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(A, Wt, dyb, dtype=BF16, epilogue=ops.EPI_NONE)
+    dx2 = torch.empty(M, D, device=dev(), dtype=torch.bfloat16)
+    dg2, db2, dots2 = torch.empty(D, device=dev()), torch.empty(D, device=dev()), torch.zeros(2, device=dev())
+    part = torch.empty(nb * (2 * D + 2), device=dev())
+    ops.layernorm_bwd(dyb, x, gamma, mean, rstd, dx2, part, dg2, db2, M, D, BF16, add1=add1, a1=a1, add2=add2, a2=a2, dots=dots2 if with_add2 else None)
+    assert bool(torch.isfinite(dx.float()).all())
+    assert torch.equal(dx, dx2)
+    torch.testing.assert_close(dg, dg2, rtol=1e-4, atol=1e-2 + 1e-5 * M)
+    torch.testing.assert_close(db, db2, rtol=1e-4, atol=1e-2 + 1e-5 * M)
+    if with_add2:
+        torch.testing.assert_close(dots, dots2, rtol=1e-4, atol=0.5)

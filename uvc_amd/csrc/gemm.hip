@@ -1047,6 +1047,22 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
 // partial table of the stand-alone kernel ([grid][2D+2], finished by uvc_layernorm_bwd_reduce_batch); the two gate dot
 // products <dx, x>, <add2, x> ride along as there.  The row's x / add1 / add2 / mean / rstd are requested before the MFMA
 // chain.  dx may alias add2 (the engine's gA is read and rewritten in place: same lane, same addresses).
+// four elements as they sit in memory (no conversion)
+template <typename T> struct Raw4L;
+template <> struct Raw4L<float> {
+  typedef f32x4 V;
+  static __device__ __forceinline__ V ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ V zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ f32x4 cvt(const V& r) { return r; }
+};
+template <> struct Raw4L<bf16_t> {
+  typedef u32x2 V;
+  static __device__ __forceinline__ V ld(const bf16_t* p) { return *reinterpret_cast<const u32x2*>(p); }
+  static __device__ __forceinline__ V zero() { return u32x2{0u, 0u}; }
+  static __device__ __forceinline__ f32x4 cvt(const V& r) {
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+  }
+};
 struct LnbArgs {
   const void* A; const void* W; const void* x; const float* mean; const float* rstd; const float* gamma;
   const void* add1; const float* a1; const void* add2; const float* a2; void* dx; float* partial;
@@ -1706,15 +1722,19 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
   wait_vm<0>();
 }
 
+int launch_row384_lnbwd(const LnbArgs& a, int x_lowp, hipStream_t st);
 extern "C" int uvc_gemm_lnbwd_supported(int32_t M, int32_t D, int32_t K, int32_t dtype) {
-  return dtype == UVC_BF16 && D == 192 && (K == 768 || K == 576) && M >= 4096;
+  if (dtype != UVC_BF16 || M < 4096) return 0;
+  if (D == 192) return K == 768 || K == 576;
+  return D == 384 && K % 64 == 0 && K >= 128 && (int64_t)M * K < (1ll << 30);      // the row-tile kernel (DeiT-Small, T2T-ViT-14)
 }
 extern "C" int uvc_gemm_lnbwd_nblocks(int32_t M) { const int nt = ceil_div(M, 16); return nt < 256 ? nt : 256; }
 
 extern "C" int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* p, void* stream) {
   if (!p || !p->A || !p->W || !p->x || !p->mean || !p->rstd || !p->gamma || !p->dx || !p->partial)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt_lnbwd: null pointer");
-  if (!uvc_gemm_lnbwd_supported(p->M, p->D, p->K, p->dtype)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt_lnbwd: bf16, D = 192, K in {576, 768}, M >= 4096");
+  if (!uvc_gemm_lnbwd_supported(p->M, p->D, p->K, p->dtype))
+    return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt_lnbwd: bf16, M >= 4096, D = 192 with K in {576, 768} or D = 384 with K % 64 == 0");
   if ((((uintptr_t)p->A | (uintptr_t)p->W | (uintptr_t)p->x | (uintptr_t)p->gamma) & 15) != 0 ||
       (((uintptr_t)p->add1 | (uintptr_t)p->add2 | (uintptr_t)p->dx | (uintptr_t)p->partial) & 7) != 0)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt_lnbwd: misaligned buffer");
@@ -1723,6 +1743,7 @@ extern "C" int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* p, void* stream) {
   a.add2 = p->add2; a.a2 = p->a2; a.dx = p->dx; a.partial = p->partial; a.M = p->M; a.K = p->K; a.want_dots = 1;
   const int grid = uvc_gemm_lnbwd_nblocks(p->M);
   hipStream_t st = (hipStream_t)stream;
+  if (p->D == 384) return launch_row384_lnbwd(a, p->x_lowp, st);
 #define LNB_LAUNCH(KT_) { \
     const size_t sh = (size_t)2 * 16 * (KT_ * 64 + 32) + (2 * 16 * 12 * 2 + 192) * sizeof(float); \
     if (p->x_lowp) { UVC_MAX_LDS(sh, k_gemm_wsn_lnbwd<KT_, true>); k_gemm_wsn_lnbwd<KT_, true><<<grid, 768, sh, st>>>(a); } \
@@ -1921,6 +1942,258 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt256(NtArgs g, int tiles_m, in
     par ^= nk & 1;
   }
   wait_vm<0>();                                   // the two redundant stages behind the last tile
+}
+
+// ================================================================================================
+// D = 384 (DeiT-Small, T2T-ViT-14): the dgrad of fc1 / qkv with the LayerNorm BACKWARD as its epilogue, on a ROW TILE.
+//     dx = LN'(A . W^T; x, mean, rstd, gamma) + a1 * add1 + a2 * add2        (uvc_gemm_nt_lnbwd; model_distilled.py:199-204,218-247)
+// The weights (384 x 1152 / 1536) do not fit the register files the D = 192 kernels keep them in, so this is k_gemm_nt256's main loop
+// on a 128 x 384 tile -- whole rows of dx per workgroup: 8 waves as 2 x 4, a wave accumulates 64 x 96 (4 A- and 6 B-fragments per
+// k-half, 96 accumulator registers), the same two 64-KB stages (16 KB of A, 48 KB of W per k-step: 2 + 6 DMA instructions per wave)
+// and the same pinned step.  Behind the last k-step the tile is rounded to bf16 -- exactly what the unfused pair stores between the
+// GEMM and the LayerNorm pass -- into the (now free) stages as 128 rows of 776 bytes, and the eight waves run k_ln_bwd_v's row
+// arithmetic over it with that kernel's lane mapping (32 lanes x 12 columns, two rows at a time, three row sets of x / add1 / add2 in
+// flight): dx is BIT-IDENTICAL to k_gemm_nt + k_ln_bwd_v (tests/test_kernels_gpu.py); dgamma / dbeta / dots leave as one partial row
+// per workgroup for the batched LayerNorm reduce (256 rows: workgroups without a tile write zeros).
+constexpr int R3_BM = 128, R3_BN = 384, R3_BK = 64;
+constexpr int R3_OPA = R3_BM * 128, R3_OPB = R3_BN * 128;   // operand images of a k-step: 16 KB + 48 KB
+constexpr int R3_STAGE = R3_OPA + R3_OPB;
+constexpr int R3_RS = R3_BN * 2 + 8;                        // row stride of the bf16 result tile: 16 rows = 16 different 8-byte bank slots
+constexpr int R3_LDS = 2 * R3_STAGE + 8 * (2 * R3_BN + 2) * 4;   // stages (the result tile lives in them) + the waves' partial rows
+static_assert(R3_BM * R3_RS <= 2 * R3_STAGE, "the result tile fits the stages");
+
+struct R3Frags { u32x4 a[4]; u32x4 b[6]; };
+
+template <bool XLOW>
+__global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int tiles_m) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  constexpr int D = R3_BN, NV4 = 3, LPR = 32;
+  typedef typename std::conditional<XLOW, bf16_t, float>::type TX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int sub = lane & (LPR - 1), rg = lane / LPR;
+
+  // ---- LDS-DMA of a k-step: 16 wave-instructions of A rows, 48 of W rows (8 rows x 128 B each); wave w issues w, w + 8, ...
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)(((size_t)(g.M - 1) * g.K + g.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.W), 0, (int)((size_t)R3_BN * g.K * 2), 0x00020000);
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;         // slot (row, c) <- k-chunk c ^ (row & 7)
+  const unsigned laneAB = (unsigned)(((w * 8 + lrow) * g.K + lchunk * 8) * 2);
+  const unsigned step64 = (unsigned)(64 * g.K * 2);
+  auto issue1 = [&](int t, unsigned voA, int kt, int st) {
+    char* base = smem + st * R3_STAGE + w * 1024;
+    const unsigned kb = (unsigned)(kt * R3_BK * 2);
+    if (t < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + t * 8192), 16, laneAB + (voA + kb + t * step64), 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(base + R3_OPA + (t - 2) * 8192), 16, laneAB + (kb + (t - 2) * step64), 0, 0, 0);
+  };
+  const unsigned s0 = lds_addr(smem);
+  const unsigned sw0 = (unsigned)((((lane >> 4)) ^ (lane & 7)) * 16);
+  const unsigned fa0 = s0 + (unsigned)((wm * 64 + (lane & 15)) * 128) + sw0;
+  const unsigned fb0 = s0 + (unsigned)(R3_OPA + (wn * 96 + (lane & 15)) * 128) + sw0;
+  auto rdfrags = [&](R3Frags& F, int st, int ks) {
+    const unsigned a = (fa0 ^ (unsigned)(ks * 64)) + (unsigned)(st * R3_STAGE), b = (fb0 ^ (unsigned)(ks * 64)) + (unsigned)(st * R3_STAGE);
+    F.b[0] = ds_read128<0 * 2048>(b); F.b[1] = ds_read128<1 * 2048>(b); F.b[2] = ds_read128<2 * 2048>(b);
+    F.b[3] = ds_read128<3 * 2048>(b); F.b[4] = ds_read128<4 * 2048>(b); F.b[5] = ds_read128<5 * 2048>(b);
+    F.a[0] = ds_read128<0 * 2048>(a); F.a[1] = ds_read128<1 * 2048>(a); F.a[2] = ds_read128<2 * 2048>(a); F.a[3] = ds_read128<3 * 2048>(a);
+  };
+  auto tie = [&](R3Frags& F) {
+    asm volatile("" : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.a[2]), "+v"(F.a[3]),
+                      "+v"(F.b[0]), "+v"(F.b[1]), "+v"(F.b[2]), "+v"(F.b[3]), "+v"(F.b[4]), "+v"(F.b[5]));
+  };
+  f32x4 acc[4][6];
+  auto mfma_row = [&](const R3Frags& F, int i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = MM::mma(__builtin_bit_cast(typename MM::Frag, F.b[j]), __builtin_bit_cast(typename MM::Frag, F.a[i]), acc[i][j]);
+  };
+
+  // ---- LayerNorm backward state of this lane: columns (sub + 32 i) * 4 .. + 3, i = 0..2 (k_ln_bwd_v<.., 3, 32>'s map)
+  f32x4 gam[NV4], dgam[NV4], dbet[NV4];
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    gam[i] = *reinterpret_cast<const f32x4*>(g.gamma + (sub + LPR * i) * 4);
+    dgam[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbet[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float a1 = g.a1 ? *g.a1 : 1.f, a2 = g.a2 ? *g.a2 : 1.f;
+  float dotA = 0.f, dotB = 0.f;
+  const float invD = 1.0f / (float)D;
+  const bf16_t* add1 = reinterpret_cast<const bf16_t*>(g.add1);
+  const bf16_t* add2 = reinterpret_cast<const bf16_t*>(g.add2);
+  struct RawRow { typename Raw4L<TX>::V xv[NV4]; u32x2 ad1[NV4], ad2[NV4]; float mean, rstd; int r; bool ok; };
+
+  const int nk = g.K / R3_BK;
+  for (int bm = blockIdx.x; bm < tiles_m; bm += gridDim.x) {
+    const unsigned voA = (unsigned)(bm * R3_BM * g.K * 2);
+    __syncthreads();                                              // the last tile's row pass is done with the stages
+#pragma unroll
+    for (int t = 0; t < 8; ++t) issue1(t, voA, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) issue1(t, voA, 1, 1);
+    wait_vm<8>();
+    __builtin_amdgcn_s_barrier();
+    R3Frags F0, F1;
+    rdfrags(F0, 0, 0);
+    wait_lgkm<0>();
+    tie(F0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      const int st = kt & 1;
+      rdfrags(F1, st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mfma_row(F0, i);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm<0>();
+      tie(F1);
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // the stage freed now receives k-step kt + 2 (behind the last k-steps: k-steps 0 / 1 of the same tile again -- no branch around a DMA;
+      // they have landed before the result tile is written over them)
+      const int kk = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
+      mfma_row(F1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rdfrags(F0, st ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 1; i < 4; ++i) {
+        issue1(3 * (i - 1), voA, kk, st);
+        issue1(3 * (i - 1) + 1, voA, kk, st);
+        if (i < 3) issue1(3 * (i - 1) + 2, voA, kk, st);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(F1, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wait_lgkm<0>();
+      tie(F0);
+    }
+    wait_vm<0>();
+    __syncthreads();                                              // every wave is done with the stages and nothing is in flight into them
+    // ---- the tile, rounded to bf16 (what k_gemm_nt stores), row-major in LDS: lane (li, gq) of acc[i][j] = row i * 16 + li, columns j * 16 + 4 gq ..
+    {
+      const unsigned base = s0 + (unsigned)((wm * 64 + (lane & 15)) * R3_RS + (wn * 96 + (lane >> 4) * 4) * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          f32x2 q;
+          q[0] = __uint_as_float(pack_bf16x2(acc[i][j][0], acc[i][j][1]));
+          q[1] = __uint_as_float(pack_bf16x2(acc[i][j][2], acc[i][j][3]));
+          ds_write64_a(base + (unsigned)(i * 16 * R3_RS + j * 32), q);
+        }
+    }
+    wait_lgkm<0>();
+    __syncthreads();
+    // ---- row pass: wave w owns rows w * 16 .. + 15 of the tile, two at a time (k_ln_bwd_v's arithmetic on dy = the LDS row)
+    {
+      const int rbase = bm * R3_BM + w * 16;
+      auto load_raw = [&](RawRow& R, int it) {
+        R.r = rbase + it * 2 + rg;
+        R.ok = it < 8 && R.r < g.M;
+        const size_t off = (size_t)(R.ok ? R.r : 0) * D;
+        const TX* x = reinterpret_cast<const TX*>(g.x) + off;
+        R.mean = R.ok ? g.mean[R.r] : 0.f; R.rstd = R.ok ? g.rstd[R.r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+          R.ad1[i] = (R.ok && add1) ? *reinterpret_cast<const u32x2*>(add1 + off + (sub + LPR * i) * 4) : u32x2{0u, 0u};
+          R.ad2[i] = (R.ok && add2) ? *reinterpret_cast<const u32x2*>(add2 + off + (sub + LPR * i) * 4) : u32x2{0u, 0u};
+          R.xv[i] = R.ok ? Raw4L<TX>::ld(x + (sub + LPR * i) * 4) : Raw4L<TX>::zero();
+        }
+      };
+      auto process = [&](const RawRow& R, int it) {
+        f32x4 xv[NV4], dv[NV4], ad1[NV4], ad2[NV4], gy[NV4];
+        u32x2 dq[NV4];
+        const unsigned la = s0 + (unsigned)((w * 16 + it * 2 + rg) * R3_RS + sub * 8);
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) dq[i] = ds_read64_a(la + (unsigned)(i * LPR * 8));
+        wait_lgkm<0>();
+        asm volatile("" : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]));
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+          xv[i] = Raw4L<TX>::cvt(R.xv[i]); dv[i] = Raw4L<bf16_t>::cvt(R.ok ? dq[i] : u32x2{0u, 0u});
+          ad1[i] = Raw4L<bf16_t>::cvt(R.ad1[i]); ad2[i] = Raw4L<bf16_t>::cvt(R.ad2[i]);
+        }
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[i][e] - R.mean) * R.rstd;
+            gy[i][e] = dv[i][e] * gam[i][e];
+            dgam[i][e] += dv[i][e] * xh;
+            dbet[i][e] += dv[i][e];
+            c1 += gy[i][e];
+            c2 += gy[i][e] * xh;
+          }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) c1 += __shfl_xor(c1, o, 64);
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) c2 += __shfl_xor(c2, o, 64);
+        c1 *= invD; c2 *= invD;
+        if (R.ok) {
+          bf16_t* dx = reinterpret_cast<bf16_t*>(g.dx) + (size_t)R.r * D;
+#pragma unroll
+          for (int i = 0; i < NV4; ++i) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = R.rstd * (gy[i][e] - c1 - ((xv[i][e] - R.mean) * R.rstd) * c2);
+            if (add1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] += a1 * ad1[i][e]; }
+            if (add2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { o[e] += a2 * ad2[i][e]; dotB += ad2[i][e] * xv[i][e]; } }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dotA += o[e] * xv[i][e];
+            u32x2 r; r[0] = pack_bf16x2(o[0], o[1]); r[1] = pack_bf16x2(o[2], o[3]);
+            *reinterpret_cast<u32x2*>(dx + (sub + LPR * i) * 4) = r;
+          }
+        }
+      };
+      RawRow Ra, Rb, Rc;
+      load_raw(Ra, 0); load_raw(Rb, 1); load_raw(Rc, 2);
+      for (int it = 0; it < 8; it += 3) {
+        process(Ra, it); load_raw(Ra, it + 3);
+        if (it + 1 < 8) { process(Rb, it + 1); load_raw(Rb, it + 4); }
+        if (it + 2 < 8) { process(Rc, it + 2); load_raw(Rc, it + 5); }
+      }
+    }
+  }
+  // ---- this workgroup's partial row [2 D + 2]: the two row groups of a wave, then the eight waves in a fixed order
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem + 2 * R3_STAGE);
+  constexpr int PW = 2 * D + 2;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gq = dgam[i][e], bq = dbet[i][e];
+      gq += __shfl_xor(gq, 32, 64); bq += __shfl_xor(bq, 32, 64);
+      if (rg == 0) { red[w * PW + (sub + LPR * i) * 4 + e] = gq; red[w * PW + D + (sub + LPR * i) * 4 + e] = bq; }
+    }
+  dotA = wave_sum(dotA); dotB = wave_sum(dotB);
+  if (lane == 0) { red[w * PW + 2 * D] = dotA; red[w * PW + 2 * D + 1] = dotB; }
+  __syncthreads();
+  float* P = g.partial + (size_t)blockIdx.x * PW;
+  for (int c = tid; c < PW; c += 512) {
+    float t = red[c];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += red[q * PW + c];
+    P[c] = t;
+  }
+}
+
+int launch_row384_lnbwd(const LnbArgs& a, int x_lowp, hipStream_t st) {
+  const int tiles_m = ceil_div(a.M, R3_BM);
+  const int grid = uvc_gemm_lnbwd_nblocks(a.M);           // 256 partial rows (M >= 4096): workgroups past the tiles write zeros
+  if (x_lowp) { UVC_MAX_LDS(R3_LDS, k_gemm_row384_lnbwd<true>); k_gemm_row384_lnbwd<true><<<grid, 512, R3_LDS, st>>>(a, tiles_m); }
+  else { UVC_MAX_LDS(R3_LDS, k_gemm_row384_lnbwd<false>); k_gemm_row384_lnbwd<false><<<grid, 512, R3_LDS, st>>>(a, tiles_m); }
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
 }
 
 // the shapes k_gemm_nt256 takes: bf16 operands with 64-deep k tiles and 16-byte aligned rows, enough rows and columns to fill tiles

@@ -2584,15 +2584,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
       goff[q] = (int64_t)row * g.ldb * 2 + (n20 + (c < B2 / 8 ? c : 0) * 8) * 2;
     }
   }
-  auto issue = [&](int t) {                              // full stages only: every row is inside the split
+  auto issue_one = [&](int t, int q) {                   // DMA instruction q of stage t (full stages only: every row is inside the split)
     const int m0 = mbeg + t * TD_BM;
     char* img = smem_td + (t % TD_NST) * IMG;
+    const char* src = (isA[q] ? A : B) + goff[q] + (int64_t)m0 * gstr[q];
+    char* dst = (w + 8 * q < NWI) ? img + (w + 8 * q) * 1024 : dummy;
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+  };
+  auto issue = [&](int t) {
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const char* src = (isA[q] ? A : B) + goff[q] + (int64_t)m0 * gstr[q];
-      char* dst = (w + 8 * q < NWI) ? img + (w + 8 * q) * 1024 : dummy;
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
-    }
+    for (int q = 0; q < PER; ++q) issue_one(t, q);
   };
 
   f32x4 acc[TI][TJ], cs[TI];
@@ -2605,7 +2606,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
   const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   const typename MM::Frag ones = __builtin_bit_cast(typename MM::Frag, ones_u);
 
-  auto compute = [&](const char* sA) {
+  // tn >= 0: the DMA instructions of stage tn go BETWEEN the MFMA rows (their issue cost hides under the matrix pipe; issued as a burst
+  // behind the barrier they cost every wave of the lock-stepped workgroup 100-200 cycles each with nothing else to issue)
+  auto compute = [&](const char* sA, int tn) {
     const char* sB = sA + TD_BM * LD1;
     typename MM::Frag fa[TI], fb[TJ];
 #pragma unroll
@@ -2619,6 +2622,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
 #pragma unroll
       for (int j = 0; j < TJ; ++j) acc[i][j] = MM::mma(fb[j], fa[i], acc[i][j]);
       if (do_cs) cs[i] = MM::mma(ones, fa[i], cs[i]);
+      if (tn >= 0) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if (q * TI / PER == i) issue_one(tn, q);
+      }
     }
   };
   const int rows = mbeg < mend ? mend - mbeg : 0;
@@ -2630,8 +2638,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
     else if (younger == 1) wait_vmcnt<PER>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                            // stage t complete for every wave; image (t-1) % 4 is free again
-    if (t + TD_NST - 1 < nfull) issue(t + TD_NST - 1);
-    compute(smem_td + (t % TD_NST) * IMG);
+    compute(smem_td + (t % TD_NST) * IMG, t + TD_NST - 1 < nfull ? t + TD_NST - 1 : -1);
   }
   if (rows % TD_BM) {                                        // partial last stage of the split: through registers, rows past mend = 0
     __builtin_amdgcn_s_barrier();
@@ -2643,7 +2650,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
       if (w + 8 * q < NWI) *reinterpret_cast<u32x4*>(smem_td + (w + 8 * q) * 1024 + lane * 16) = v;
     }
     __syncthreads();
-    compute(smem_td);
+    compute(smem_td, -1);
   }
   if (do_cs && (lane >> 4) == 0) {
 #pragma unroll

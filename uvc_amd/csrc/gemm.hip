@@ -1320,21 +1320,24 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
   const long long mr_delta = reinterpret_cast<const char*>(g.rstd) - reinterpret_cast<const char*>(g.mean);     // scalar
   const unsigned mr_lo = (unsigned)(lane & 3) * 16u;
   const bool mr_lane = lane >= 32 && lane < 40, mr_r = lane >= 36;
-  auto issue = [&](int tile, int st) {
+  // DMA instruction q of a stage (q = 5: the tile's mean / rstd)
+  auto issue_q = [&](int tile, int st, int q) {
     const int t = tile < ntiles ? tile : ntiles - 1;            // past the end: redundant loads keep the instruction count uniform
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
+    if (q < 5) {
       // (tile * bytes-per-tile + lane offset) is formed per issue and added to the SCALAR region base: written as base + lane offset
       // first, hipcc hoists six loop-invariant 64-bit per-lane pointers (12 VGPRs) and spills W^T fragments to make room
       const char* src = rb[q] + ((unsigned long long)(unsigned)t * (unsigned long long)rstride[q] + (unsigned long long)loff[q]);
       char* dst = smem + st * STAGE + rdst[q];
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
-    }
-    if (mr_lane) {
+    } else if (mr_lane) {
       const char* src = reinterpret_cast<const char*>(g.mean) + ((unsigned long long)(unsigned)t * 64ull + mr_lo) + (mr_r ? mr_delta : 0ll);
       char* dst = smem + st * STAGE + (NA - 1) * 1024;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
     }
+  };
+  auto issue = [&](int tile, int st) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) issue_q(tile, st, q);
   };
   const unsigned s0 = lds_addr(smem);
   const unsigned fragoff = (unsigned)(li * ROWB + gq * 16);
@@ -1348,7 +1351,9 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
   __builtin_amdgcn_s_barrier();
   int st = 0, par = 0;
   for (; tile < ntiles; tile += gridDim.x) {
-    issue(tile + 2 * gridDim.x, st == 0 ? 2 : st - 1);        // stage (it + 2) % 3: nobody reads it since the last barrier
+    // stage (it + 2) % 3 (nobody reads it since the last barrier) is requested BETWEEN the groups of the MFMA chain: issued as a burst in
+    // front of it, the six instructions cost the wave 100-200 cycles each with nothing of its own in the matrix pipe
+    const int nt_ = tile + 2 * (int)gridDim.x, ns_ = st == 0 ? 2 : st - 1;
     const unsigned sb = s0 + (unsigned)(st * STAGE);
     // ---- MFMA chain: fragments in pairs, the next pair requested before the current one is waited for (16 VGPRs of fragments
     //      next to the 96 of W^T; groups of four spilled 16 registers at K = 768 and ran 132 us against 104 register-staged)
@@ -1370,8 +1375,9 @@ __global__ __launch_bounds__(768) void k_gemm_wsn_lnbwd_dma(LnbArgs g) {
              c0 = MM::mma(bf[(gk) * 2 + 3], __builtin_bit_cast(typename MM::Frag, fb[1]), c0); } }
     static_assert(KT % 2 == 0 && KT <= 24, "pairs of k-steps");
     if (DB) { RD2(fa, 0) }
-    GROUP(0, fa, fb) GROUP(1, fb, fa) GROUP(2, fa, fb) GROUP(3, fb, fa) GROUP(4, fa, fb) GROUP(5, fb, fa)
-    GROUP(6, fa, fb) GROUP(7, fb, fa) GROUP(8, fa, fb) GROUP(9, fb, fa) GROUP(10, fa, fb) GROUP(11, fb, fa)
+    GROUP(0, fa, fb) issue_q(nt_, ns_, 0); GROUP(1, fb, fa) GROUP(2, fa, fb) issue_q(nt_, ns_, 1); GROUP(3, fb, fa)
+    GROUP(4, fa, fb) issue_q(nt_, ns_, 2); GROUP(5, fb, fa) GROUP(6, fa, fb) issue_q(nt_, ns_, 3); GROUP(7, fb, fa)
+    GROUP(8, fa, fb) issue_q(nt_, ns_, 4); issue_q(nt_, ns_, 5); GROUP(9, fb, fa) GROUP(10, fa, fb) GROUP(11, fb, fa)
 #undef GROUP
 #undef RD2
     // ---- this row's LayerNorm operands from the stage (they stay in registers across the barrier)

@@ -152,7 +152,8 @@ def test_gemm_nt_ksplit_streaming_kernel_matches_generic(K, M):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("M,N1,N2", [(1576, 576, 192), (403, 192, 768), (3001, 768, 192), (64, 1000, 192), (5000, 128, 128), (40, 8, 16), (4133, 192, 192)])
+@pytest.mark.parametrize("M,N1,N2", [(1576, 576, 192), (403, 192, 768), (3001, 768, 192), (64, 1000, 192), (5000, 128, 128), (40, 8, 16), (4133, 192, 192),
+                                     (2500, 3072, 768), (1210, 768, 3072), (999, 2304, 768)])     # the last three: DeiT-Base (256 x 256 tiles)
 def test_gemm_tn(dtype, M, N1, N2):
     from uvc_amd import ops
     A, B = rnd(M, N1, seed=11), rnd(M, N2, seed=12)

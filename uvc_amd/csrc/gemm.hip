@@ -2546,7 +2546,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
   constexpr int PER = (NWI + 7) / 8;                     // per wave (waves past NWI aim theirs at a dummy KB)
   constexpr int IMG = NWI * 1024;
   constexpr int TI = B1 / W1 / 16, TJ = B2 / W2 / 16;
-  static_assert(W1 * W2 == 8 && PER <= 4, "tile config");
+  static_assert(W1 * W2 == 8 && PER <= 5, "tile config");
   extern __shared__ __attribute__((aligned(16))) char smem_td[];
   char* const dummy = smem_td + TD_NST * IMG;
   const char* __restrict__ A = reinterpret_cast<const char*>(g.A);
@@ -2711,13 +2711,17 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ par
 
 // 0 = generic 128x64 tiles; 1 = 192x256, 2 = 256x192, 3 = 192x192, 4 = 96x192 (bf16 big tiles)
 static int tn_config(int N1, int N2) {
+  // 5 = 256 x 256 (LDS-DMA kernel, bf16 operands): DeiT-Base's shapes.  131 flop per operand byte through LDS against 108 for 192 x 256; the
+  // split-M kernels are bound by the L2 -> LDS rate of their 32-row stages (pipe 31 % busy at 0.75 PFLOP/s).  Wide matrices only: at
+  // DeiT-Tiny / Small widths the 192-wide tiles divide the shapes and leave more splits.
+  if (N1 % 256 == 0 && N2 % 256 == 0 && (N1 / 256) * (N2 / 256) >= 16) return 5;
   if (N1 % 192 == 0 && N2 % 256 == 0) return 1;
   if (N1 % 256 == 0 && N2 % 192 == 0) return 2;
   if (N1 % 192 == 0 && N2 % 192 == 0 && (N1 / 192) * (N2 / 192) >= 2) return 3;   // a single 192x192 tile would need 256 splits
   if (N1 == 192 && N2 == 192) return 4;       // dW_proj of DeiT-Tiny: two 96x192 tiles x 128 splits (the generic kernel ran it at 1.75 TB/s)
   return 0;
 }
-static void tn_tile(int cfg, int& b1, int& b2) { b1 = cfg == 2 ? 256 : cfg == 4 ? 96 : 192; b2 = cfg == 1 ? 256 : 192; }
+static void tn_tile(int cfg, int& b1, int& b2) { b1 = (cfg == 2 || cfg == 5) ? 256 : cfg == 4 ? 96 : 192; b2 = (cfg == 1 || cfg == 5) ? 256 : 192; }
 static int tn_splits(int M, int N1, int N2, int cfg) {
   int tiles, target;
   if (cfg == 0) { tiles = ceil_div(N1, TN_B1) * ceil_div(N2, TN_B2); target = 768; }
@@ -2748,6 +2752,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   if (p->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: workspace too small");
   int cfg = (p->dtype == UVC_BF16 && p->lda % 8 == 0 && p->ldb % 8 == 0) ? tn_config(p->N1, p->N2) : 0;
   if (cfg == 4 && p->a_is_f32) cfg = 0;                      // the 96x192 tile exists as an LDS-DMA (bf16 operands) kernel only
+  if (cfg == 5 && p->a_is_f32) cfg = (p->N1 % 192 == 0 && p->N2 % 256 == 0) ? 1 : (p->N1 % 256 == 0 && p->N2 % 192 == 0) ? 2 : 0;
   splits = tn_splits(p->M, p->N1, p->N2, cfg);
   TnArgs a;
   a.A = p->A; a.B = p->B; a.part = (float*)p->workspace; a.M = p->M; a.N1 = p->N1; a.N2 = p->N2; a.lda = p->lda; a.ldb = p->ldb;
@@ -2783,6 +2788,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
       else if (cfg == 1) TN_DMA_ONE(192, 256, 2, 4)
       else if (cfg == 2) TN_DMA_ONE(256, 192, 4, 2)
       else if (cfg == 4) TN_DMA_ONE(96, 192, 2, 4)
+      else if (cfg == 5) TN_DMA_ONE(256, 256, 2, 4)
       else TN_DMA_ONE(192, 192, 2, 4)
 #undef TN_DMA_ONE
 #undef TN_BIG

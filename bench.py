@@ -416,7 +416,42 @@ def main():
         dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks_if_needed():
+    """`--gpus N` is the number of ranks that RUN (the reference launches one process per GPU: run_uvc_train.sh:1-3).
+    Started under torch.distributed.run (WORLD_SIZE set), WORLD_SIZE must equal --gpus, otherwise the line would carry a wrong
+    n_gpus: exit 2.  Started as plain `python bench.py --gpus N` with N > 1, this process becomes the launcher: it re-executes
+    itself under `torch.distributed.run --nproc-per-node N` on 127.0.0.1 and returns the children's exit code."""
+    args = parse()
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: refusing to print a line with a wrong n_gpus", file=sys.stderr)
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    share = os.environ.get("UVC_BENCH_SHARE_DEVICE", "0") not in ("", "0")
+    if not share and torch.cuda.device_count() < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
+        sys.exit(2)
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 if __name__ == "__main__":
+    launch_ranks_if_needed()
     # stdout carries exactly ONE line, the JSON record: the library's progress prints (FLOP size, eps updates, gating banners)
     # are the reference's own messages and go to stderr here
     import contextlib

@@ -71,3 +71,18 @@ def test_bucketed_allreduce_with_front_end_segment_gloo_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, 14, 4, out, 7777), nprocs=2, join=True)
     assert out[0] and out[1]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """bench.py started under a launcher whose WORLD_SIZE differs from --gpus exits non-zero before touching a device (it would otherwise
+    print a line whose n_gpus is not what the caller asked for); and with no launcher and more ranks asked for than devices visible."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and not r.stdout.strip()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "UVC_BENCH_SHARE_DEVICE")}
+    if torch.cuda.device_count() < 64:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "device(s) visible" in r.stderr and not r.stdout.strip()

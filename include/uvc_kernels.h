@@ -49,8 +49,13 @@ typedef struct uvc_gemm_nt_args {
   int32_t M, N, K, lda, ldb, ldc, ldr, ldaux;
   int32_t dtype, a_is_f32, c_is_f32, epilogue;
   int32_t force_generic;  /* tests/tuning: 0 = pick the kernel by shape; 1 = the generic LDS-tiled kernel; 2 = the streaming kernels in their
-                             register-staged forms (no LDS-DMA ring).  Every choice computes the same bits (one k-ordered accumulation chain,
-                             the same epilogue arithmetic) */
+                             register-staged forms (no LDS-DMA ring; the 256 x 256-tile kernel IS an LDS-DMA kernel and is skipped too);
+                             3 = the wide-tile kernels (256 x 256) wherever the shape admits them, whatever the row / tile count -- what
+                             the production batch of DeiT-Small / Base selects, at a size the host oracle finishes in seconds.  Every
+                             choice computes the same bits (one k-ordered accumulation chain, the same epilogue arithmetic) */
+  int32_t r_is_f32;       /* element type of R / R2, stated by the caller and checked: they have C's type (c_is_f32, or float32 mode), so
+                             this must equal it whenever R is given.  Rounds 1-2 took float32 R beside a bf16 C; a caller still built to
+                             that contract gets UVC_ERR_ARG instead of its rows read as bf16 */
   /* optional second output of the residual epilogues where uvc_gemm_nt_ln_supported(): ln_out[M,N] (T) = LayerNorm(C rows; ln_gamma,
    * ln_beta, ln_eps) -- norm1 of the next block on the rows fc2 + residual (+ gate mix) just produced (model_distilled.py:241-244) --
    * and its float32 statistics ln_mean / ln_rstd [M] (both or neither).  Needs alpha == 1, contiguous A / R (lda == K, ldr == N).

@@ -43,7 +43,7 @@ class uvc_gemm_nt_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("A", "B", "C", "C2", "bias", "R", "R2", "aux", "gate", "alpha_ptr")] + \
                [("alpha", C.c_float)] + \
                [(n, C.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldr", "ldaux", "dtype", "a_is_f32",
-                                         "c_is_f32", "epilogue", "force_generic")] + \
+                                         "c_is_f32", "epilogue", "force_generic", "r_is_f32")] + \
                [("ln_eps", C.c_float)] + [(n, C.c_void_p) for n in ("ln_gamma", "ln_beta", "ln_out", "ln_mean", "ln_rstd")]
 
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define UVC_OK 0
 #define UVC_ERR_ARG 1
@@ -20,19 +21,21 @@ int uvc_set_error_msg(int code, const char* msg);
 // hipFuncAttributeMaxDynamicSharedMemorySize applies per DEVICE: a kernel that needs more than 64 KB of dynamic LDS must get the
 // attribute on every device the process launches it on.  One bit per device ordinal and call site; usage (inside a function that
 // returns an int status):  UVC_MAX_LDS(bytes, kernel<template, arguments>);
-static inline hipError_t uvc_max_lds_once(uint64_t& mask, const void* func, int bytes) {
+// (at most 64 devices per process: ordinals beyond that set the attribute on every launch; the mask is atomic, so two host threads
+//  launching the same kernel at once at worst both set the attribute)
+static inline hipError_t uvc_max_lds_once(std::atomic<uint64_t>& mask, const void* func, int bytes) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  const uint64_t bit = 1ull << (dev & 63);
-  if (mask & bit) return hipSuccess;
+  const uint64_t bit = dev < 64 ? 1ull << dev : 0;
+  if (mask.load(std::memory_order_relaxed) & bit) return hipSuccess;
   e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e == hipSuccess) mask |= bit;
+  if (e == hipSuccess) mask.fetch_or(bit, std::memory_order_relaxed);
   return e;
 }
 #define UVC_MAX_LDS(bytes, ...)                                                              \
   do {                                                                                       \
-    static uint64_t lds_mask__ = 0;                                                          \
+    static std::atomic<uint64_t> lds_mask__{0};                                              \
     const hipError_t lds_e__ = uvc_max_lds_once(lds_mask__, (const void*)(__VA_ARGS__), (int)(bytes)); \
     if (lds_e__ != hipSuccess) return uvc_set_error(lds_e__, __FILE__, __LINE__);            \
   } while (0)

@@ -964,7 +964,7 @@ static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
 // the 256 x 256-tile kernel of the wide models (defined behind the LDS-DMA helpers below)
 int launch_nt256_f32(const NtArgs& a, int epi, hipStream_t st);
 int launch_nt256_bf16(const NtArgs& a, int epi, hipStream_t st);
-bool nt256_takes(const NtArgs& a, bool a_f32);
+bool nt256_takes(const NtArgs& a, bool a_f32, bool any_size);
 
 extern "C" int uvc_gemm_nt_ln_supported(int32_t M, int32_t N, int32_t K, int32_t dtype, int32_t epilogue) {
   if (dtype != UVC_BF16 || N != 192 || M < 16) return 0;      // any row count from 16 up: whether norm is fused must not depend on the batch
@@ -982,6 +982,8 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue needs bias");
   if ((e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && !p->R)
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: residual epilogue needs R");
+  if ((e == UVC_EPI_BIAS_RESID || e == UVC_EPI_BIAS_RESID_GATE) && (p->r_is_f32 != 0) != (p->c_is_f32 != 0 || p->dtype == UVC_F32))
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: R / R2 have C's element type (r_is_f32 must equal c_is_f32)");
   if (e == UVC_EPI_BIAS_RESID_GATE && (!p->R2 || !p->gate)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: gate epilogue needs R2 and gate");
   if ((e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_GELU_GRAD) && !p->C2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: GELU epilogue needs C2");
   if ((e == UVC_EPI_DGELU || e == UVC_EPI_MUL_AUX) && !p->aux) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dGELU epilogue needs aux");
@@ -1021,7 +1023,8 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
     return p->c_is_f32 ? launch_ws384<float>(a, e, st) : launch_ws384<bf16_t>(a, e, st);
   if (!generic && wsn_ok(a, e, p->a_is_f32 != 0))
     return p->c_is_f32 ? launch_wsn<float>(a, e, st) : launch_wsn<bf16_t>(a, e, st);
-  if (!generic && nt256_takes(a, p->a_is_f32 != 0))
+  // (force_generic == 2 asks for kernels WITHOUT an LDS-DMA ring: the 256 x 256 kernel is one; == 3 takes it at any size)
+  if (!generic && !a.no_dma && nt256_takes(a, p->a_is_f32 != 0, p->force_generic == 3))
     return p->c_is_f32 ? launch_nt256_f32(a, e, st) : launch_nt256_bf16(a, e, st);
   if (p->a_is_f32) {
     if ((p->lda % 8) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: lda");
@@ -2206,9 +2209,9 @@ int launch_row384_lnbwd(const LnbArgs& a, int x_lowp, hipStream_t st) {
 // ... and enough tiles: one persistent workgroup per CU means ceil(tiles / 256) rounds, and with fewer than ~3 the last, partly
 // filled round costs more than the kernel gains (N = 768 at 25 k rows: 297 tiles = 2 rounds at 58 %; the 128 x 128 kernel with three
 // workgroups per CU is as fast or faster there, measured).  Operand sizes < 2 GB: 32-bit buffer offsets.
-static bool nt256_ok(const NtArgs& a, bool a_f32) {
+static bool nt256_ok(const NtArgs& a, bool a_f32, bool any_size) {
   const int tiles = ceil_div(a.M, G2_BM) * ceil_div(a.N, G2_BN);
-  return !a_f32 && tiles >= 640 && a.K % 64 == 0 && a.K >= 256 && a.N >= 256 && a.M >= 2048 && a.lda % 8 == 0 && a.ldb % 8 == 0 &&
+  return !a_f32 && (any_size || (tiles >= 640 && a.M >= 2048)) && a.K % 64 == 0 && a.K >= 256 && a.N >= 256 && a.lda % 8 == 0 && a.ldb % 8 == 0 &&
          (((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0 && (size_t)a.M * a.lda * 2 < (1ull << 31) && (size_t)a.N * a.ldb * 2 < (1ull << 31);
 }
 template <typename TC>
@@ -2228,7 +2231,7 @@ static int launch_nt256(const NtArgs& a, int epi, hipStream_t st) {
 }
 int launch_nt256_f32(const NtArgs& a, int epi, hipStream_t st) { return launch_nt256<float>(a, epi, st); }
 int launch_nt256_bf16(const NtArgs& a, int epi, hipStream_t st) { return launch_nt256<bf16_t>(a, epi, st); }
-bool nt256_takes(const NtArgs& a, bool a_f32) { return nt256_ok(a, a_f32); }
+bool nt256_takes(const NtArgs& a, bool a_f32, bool any_size) { return nt256_ok(a, a_f32, any_size); }
 
 // ================================================================================================
 //                                            TN (wgrad)

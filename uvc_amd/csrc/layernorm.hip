@@ -20,18 +20,18 @@ __device__ __forceinline__ size_t row_off(int r, int rpg, int64_t gs, int D) {
   return (size_t)(r / rpg) * gs + (size_t)(r % rpg) * D;
 }
 
-template <typename TY, int NV>
+template <typename TX, typename TY, int NV>
 __global__ __launch_bounds__(256) void k_ln_fwd(uvc_ln_args a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + w;
   if (r >= a.rows) return;
-  const float* x = reinterpret_cast<const float*>(a.x) + row_off(r, a.rows_per_group, a.group_stride, a.D);
+  const TX* x = reinterpret_cast<const TX*>(a.x) + row_off(r, a.rows_per_group, a.group_stride, a.D);
   float v[NV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
-    v[i] = c < a.D ? x[c] : 0.f;
+    v[i] = c < a.D ? ElemIO<TX>::load(x + c) : 0.f;
     s += v[i];
   }
   const float mean = wave_sum(s) / (float)a.D;
@@ -422,7 +422,7 @@ template <typename T> int launch_fwd(const uvc_ln_args& a, hipStream_t st) {
     const int grid = ceil_div(a.rows, LNV_FWD_ROWS);
 #define LNF_CASE(NV4) case NV4: if (a.x_lowp) k_ln_fwd_v<bf16_t, T, NV4><<<grid, 256, 0, st>>>(a); else k_ln_fwd_v<float, T, NV4><<<grid, 256, 0, st>>>(a); break;
     switch (a.D / 64) {
-      LNF_CASE(1) LNF_CASE(2) LNF_CASE(3) LNF_CASE(6) LNF_CASE(12)
+      LNF_CASE(1) LNF_CASE(2) LNF_CASE(3) LNF_CASE(4) LNF_CASE(6) LNF_CASE(8) LNF_CASE(12)
       default: goto generic;
     }
 #undef LNF_CASE
@@ -430,14 +430,17 @@ template <typename T> int launch_fwd(const uvc_ln_args& a, hipStream_t st) {
     return UVC_OK;
   }
 generic:
-  if (a.x_lowp) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "layernorm_fwd: a bf16 x needs D in {64, 128, 192, 384, 768} and a group stride that is a multiple of 4");
+  // any other width (and ragged group strides): one wave per row, scalar accesses; x may be the bf16 residual stream here too
+  // (the engine's bf16 mode defaults to bf16 rows for every embed_dim % 64 == 0 it accepts)
   const int grid = ceil_div(a.rows, 4);
   const int nv = ceil_div(a.D, 64);
-  if (nv <= 2) k_ln_fwd<T, 2><<<grid, 256, 0, st>>>(a);
-  else if (nv <= 3) k_ln_fwd<T, 3><<<grid, 256, 0, st>>>(a);
-  else if (nv <= 6) k_ln_fwd<T, 6><<<grid, 256, 0, st>>>(a);
-  else if (nv <= 12) k_ln_fwd<T, 12><<<grid, 256, 0, st>>>(a);
-  else k_ln_fwd<T, 16><<<grid, 256, 0, st>>>(a);
+#define LNG(NV) do { if (a.x_lowp) k_ln_fwd<bf16_t, T, NV><<<grid, 256, 0, st>>>(a); else k_ln_fwd<float, T, NV><<<grid, 256, 0, st>>>(a); } while (0)
+  if (nv <= 2) LNG(2);
+  else if (nv <= 3) LNG(3);
+  else if (nv <= 6) LNG(6);
+  else if (nv <= 12) LNG(12);
+  else LNG(16);
+#undef LNG
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -192,6 +192,7 @@ int nt(const Ctx& c, const void* A, int a_f32, const void* B, void* C, int c_f32
   a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.R = R; a.R2 = R2; a.aux = aux; a.gate = gate; a.alpha_ptr = alpha_ptr;
   a.alpha = 1.0f; a.M = M; a.N = N; a.K = K; a.lda = lda ? lda : K; a.ldb = K; a.ldc = ldc ? ldc : N; a.ldr = a.ldc; a.ldaux = a.ldc;
   a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32; a.c_is_f32 = c_f32 || c.d.dtype == UVC_F32; a.epilogue = epi;
+  a.r_is_f32 = a.c_is_f32;
   a.force_generic = ln ? 0 : c.io->force_generic;      // (a producer that also writes the next LayerNorm exists in one form only)
   return uvc_gemm_nt(&a, c.st);
 }

@@ -57,6 +57,7 @@ def gemm_nt(A, B, C_, *, dtype, epilogue=EPI_NONE, bias=None, R=None, R2=None, a
         if t is not None and t.dtype != C_.dtype:
             raise L.UvcHipError("gemm_nt: the residual operands R / R2 have C's element type")
     a.force_generic = int(force_generic)
+    a.r_is_f32 = _is_f32(R) if R is not None else 0
     L.check(L.lib().uvc_gemm_nt(C.byref(a), L.cur_stream()), "uvc_gemm_nt")
 
 
@@ -406,10 +407,14 @@ class KeyedExpSource:
 
     def __init__(self, seed, device):
         self.seed, self.device = int(seed) & 0xFFFFFFFFFFFFFFFF, device
-        self.step, self.site = 0, 0
+        self.step, self.site = -1, 0
 
     def begin_step(self, step):
-        self.step, self.site = int(step), 0
+        """First call of an accumulation window.  A window left unfinished at an epoch boundary is followed by a new window with the SAME
+        optimiser step number (the reference restarts its window count per epoch, joint_train.py:423): its draws continue the site
+        numbering instead of replaying the key (seed, step, 0..)."""
+        if int(step) != self.step:
+            self.step, self.site = int(step), 0
 
     def __call__(self, shape):
         import torch

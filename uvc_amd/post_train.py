@@ -113,6 +113,7 @@ class Stage2Trainer:
     def begin_epoch(self, epoch: int):
         """post_train.py:326-339."""
         self.epoch = epoch
+        self._micro = 0          # `(step + 1) % k` on the epoch's loader index (:351,372): an accumulation window never straddles epochs
         self.model.train()
         self.model.block_skip_gating.requires_grad = False
         self.scheduler.step(epoch)

@@ -272,7 +272,8 @@ class Stage1Trainer:
                      g=None if self.g_opt is None else self.g_opt.param_groups[0]["lr"],
                      dual=[g["lr"] for g in self.dual_opt.param_groups]),
             progress=dict(global_step=self.global_step, epoch=self.epoch, gating_grad_list_len=len(self.gating_grad_list),
-                          enable_warmup=int(self.model.enable_warmup), args_enable_warmup=int(self.args.enable_warmup), micro=self._micro),
+                          enable_warmup=int(self.model.enable_warmup), args_enable_warmup=int(self.args.enable_warmup), micro=self._micro,
+                          noise_step=int(self.noise.step), noise_site=int(self.noise.site)),
             # Gumbel / mixup draws continue where they stopped: torch CPU + this device's generator, numpy's global RNG
             rng=dict(torch_cpu=torch.get_rng_state(), torch_cuda=torch.cuda.get_rng_state(self.model._flat.device),
                      numpy=_np_rng_state()),
@@ -309,6 +310,7 @@ class Stage1Trainer:
         self.args.enable_warmup = int(pr["args_enable_warmup"])
         self.model.block_skip_gating.requires_grad = not self.model.enable_warmup
         self._micro = int(pr.get("micro", 0))
+        self.noise.step, self.noise.site = int(pr.get("noise_step", -1)), int(pr.get("noise_site", 0))
         rng = sd.get("rng")
         if rng is not None:
             torch.set_rng_state(rng["torch_cpu"].cpu())

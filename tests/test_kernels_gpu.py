@@ -928,6 +928,39 @@ def test_gemm_nt256_matches_generic_kernel_and_float64(M, N, K):
                 torch.testing.assert_close(outs[0][0].double(), ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("ri", [8, 6, 5, 4])
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (2364, 2304, 768), (160 * 9 + 77, 768, 256), (97, 512, 320), (8192 + 19, 1000, 1536)])
+def test_gemm_nt8p_every_tile_height_matches_generic_kernel(M, N, K, ri):
+    """k_gemm_nt8p (two wave groups half a phase apart, four-slot LDS ring with counted waits) at every tile height it is built for
+    (32 * ri rows x 256 columns; force_generic = 0x100 | ri picks it at any size): bit-identical to the generic 128 x 128 kernel for
+    every epilogue -- ragged M and N, fewer rows than one tile, an odd number of k-steps per tile (K = 320: the buffer parity flips from
+    tile to tile), more tiles than workgroups, several tiles per persistent workgroup; twice in a row (a race between the LDS-DMA ring
+    and the fragment reads would show as run-to-run differences)."""
+    from uvc_amd import ops
+    A = (rnd(M, K, seed=311) * 0.5).bfloat16()
+    W = rnd(N, K, seed=312, scale=0.04).bfloat16()
+    bias = rnd(N, seed=313) * 0.1
+    gate = torch.tensor([0.3, 0.7], device=dev())
+    aux = rnd(M, N, seed=314).bfloat16()
+    R, R2 = rnd(M, N, seed=315).bfloat16(), rnd(M, N, seed=316).bfloat16()
+    cases = [(ops.EPI_NONE, {}), (ops.EPI_BIAS, dict(bias=bias)), (ops.EPI_BIAS_RESID, dict(bias=bias, R=R)),
+             (ops.EPI_BIAS_RESID_GATE, dict(bias=bias, R=R, R2=R2, gate=gate)), (ops.EPI_MUL_AUX, dict(aux=aux)),
+             (ops.EPI_BIAS_GELU_OUT, dict(bias=bias)), (ops.EPI_BIAS_GELU_GRAD, dict(bias=bias, C2=True))]
+    for epi, kw in cases:
+        outs = []
+        for fg in (0x100 | ri, 1, 0x100 | ri):
+            C1 = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+            k2 = dict(kw)
+            if k2.get("C2") is True:
+                k2["C2"] = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+            ops.gemm_nt(A, W, C1, dtype=BF16, epilogue=epi, force_generic=fg, **k2)
+            outs.append((C1, k2.get("C2")))
+        for o in (outs[0], outs[2]):
+            assert torch.equal(o[0], outs[1][0]), (epi, ri)
+            if o[1] is not None:
+                assert torch.equal(o[1], outs[1][1]), (epi, ri, "C2")
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_cast_transpose_multi_all_shadows_in_one_launch(dtype):
     """uvc_cast_transpose_multi (the per-step refresh of every weight shadow): 64 x 64 tiles with 16-byte loads / 8-byte bf16 stores where

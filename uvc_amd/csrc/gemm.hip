@@ -965,6 +965,9 @@ static int launch_nt_epi(const NtArgs& a, int epi, hipStream_t st) {
 int launch_nt256_f32(const NtArgs& a, int epi, hipStream_t st);
 int launch_nt256_bf16(const NtArgs& a, int epi, hipStream_t st);
 bool nt256_takes(const NtArgs& a, bool a_f32, bool any_size);
+int launch_nt8p_f32(const NtArgs& a, int epi, int ri, hipStream_t st);
+int launch_nt8p_bf16(const NtArgs& a, int epi, int ri, hipStream_t st);
+bool nt8p_takes(const NtArgs& a, bool a_f32);
 
 extern "C" int uvc_gemm_nt_ln_supported(int32_t M, int32_t N, int32_t K, int32_t dtype, int32_t epilogue) {
   if (dtype != UVC_BF16 || N != 192 || M < 16) return 0;      // any row count from 16 up: whether norm is fused must not depend on the batch
@@ -1024,8 +1027,22 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   if (!generic && wsn_ok(a, e, p->a_is_f32 != 0))
     return p->c_is_f32 ? launch_wsn<float>(a, e, st) : launch_wsn<bf16_t>(a, e, st);
   // (force_generic == 2 asks for kernels WITHOUT an LDS-DMA ring: the 256 x 256 kernel is one; == 3 takes it at any size)
-  if (!generic && !a.no_dma && nt256_takes(a, p->a_is_f32 != 0, p->force_generic == 3))
+  if ((p->force_generic >> 8) == 1) {                 // tuning: the 8-phase kernel with 32 * (force_generic & 255) rows per tile, at any size
+    if (!nt8p_takes(a, p->a_is_f32 != 0)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: shape not taken by the 8-phase kernel");
+    return p->c_is_f32 ? launch_nt8p_f32(a, e, p->force_generic & 255, st) : launch_nt8p_bf16(a, e, p->force_generic & 255, st);
+  }
+  // Wide GEMMs (K >= 256 against N >= 256).  Many tiles (>= 640 of 256 x 256: qkv, fc1, dfc2 of DeiT-Base): the lock-step 256 x 256 kernel -- at
+  // K = 768 the two kernels' k-loops cost the same (both wait for the L2 -> LDS latency of their requests: 64 KB in flight per CU) and its prologue
+  // is shorter (88 against 98 us for qkv; at K = 6144 the 8-phase kernel wins 542 : 607).  Fewer tiles with N a multiple of 256 (N = 768: proj,
+  // fc2, dfc1, dqkv, dproj -- 297 tiles of 256 x 256 are two rounds at 58 %): the 8-phase kernel at the tile height that fills its rounds
+  // (160 rows: 474 tiles): fc2 + residual + gate 153 -> 137 us, dfc1 129 -> 95, dqkv 98 -> 74, dproj 38 -> 32 against the 128 x 128 kernel.
+  // (force_generic == 3, "the production batch's kernels at any size": N < 1792 is what stays below 640 tiles at DeiT-Base's 25 216 rows)
+  const bool few_tiles_wide = !p->c_is_f32 && a.N % 256 == 0 && nt8p_takes(a, p->a_is_f32 != 0);
+  if (!generic && !a.no_dma && !(p->force_generic == 3 && few_tiles_wide && a.N < 1792) &&
+      nt256_takes(a, p->a_is_f32 != 0, p->force_generic == 3 || p->force_generic == 4))
     return p->c_is_f32 ? launch_nt256_f32(a, e, st) : launch_nt256_bf16(a, e, st);
+  if (!generic && !a.no_dma && few_tiles_wide && (a.M >= 2048 || p->force_generic == 3))
+    return launch_nt8p_bf16(a, e, 0, st);
   if (p->a_is_f32) {
     if ((p->lda % 8) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: lda");
     if (ws) return p->c_is_f32 ? launch_ws<float, float>(a, e, st) : launch_ws<float, bf16_t>(a, e, st);
@@ -2232,6 +2249,264 @@ static int launch_nt256(const NtArgs& a, int epi, hipStream_t st) {
 int launch_nt256_f32(const NtArgs& a, int epi, hipStream_t st) { return launch_nt256<float>(a, epi, st); }
 int launch_nt256_bf16(const NtArgs& a, int epi, hipStream_t st) { return launch_nt256<bf16_t>(a, epi, st); }
 bool nt256_takes(const NtArgs& a, bool a_f32, bool any_size) { return nt256_ok(a, a_f32, any_size); }
+
+// ================================================================================================
+//        NT on (32 RI) x 256 tiles with two wave groups half a phase apart ("8-phase" schedule)
+// ================================================================================================
+// k_gemm_nt256 keeps its eight waves in lock step: everybody reads fragments, everybody issues MFMAs, everybody waits at the one
+// barrier of a k-step -- the matrix pipe idles ~27 % of every step.  Here the workgroup's two M groups (waves 0-3 /
+// 4-7: one wave of each on every SIMD) run HALF A PHASE apart: a k-step of 64 is four phases, a phase is
+//     [fragment reads + LDS-DMA requests] s_barrier [16 MFMAs] s_barrier
+// and group 1 passes one extra barrier up front, so that while one wave of a SIMD issues its MFMA block the other one is in its
+// read / request segment (cdna_hip_programming.md 5, "the 256^2 8-phase template"; re-derived here, the example source is not in the
+// image).  A wave's 16 RI x 64 output is four quadrants: rows A0 = blocks 0 .. R0-1 / A1 = the rest, columns B0 = 0-31 / B1 = 32-63;
+// phases: (A0,B0) (A0,B1) (A1,B1) (A1,B0), so a phase reads at most one new A sub-tile and one new B sub-tile: 12 / 4 / 8 / 0 reads, and
+// the fragment registers are 32 + 16 + 16 instead of 96.
+//   * LDS: two buffers of four 16-KB slots; a slot is the image of one sub-tile OF ALL EIGHT WAVES: A'0 = rows A0 of both M groups,
+//     B'0 = columns B0 of the four N groups, B'1, A'1 likewise -- so that the slots of a k-step are read in DIFFERENT phases (0, 0, 1, 2)
+//     and each can be re-filled as soon as its phase is two phases back: per phase ONE slot of a later k-step is requested (two
+//     buffer_load ... lds per wave), four of them are in flight at every wait (vmcnt(8), never 0 inside a tile).
+//     Order of requests: phase p of k-step X asks for  p=0: B'1(X+1)  p=1: A'1(X+1)  p=2: A'0(X+2)  p=3: B'0(X+2).
+//     RAW: a slot is read one phase after the wait that covers it (wait before the phase's first barrier, read in the next phase: the
+//     staggered group's waits are half a phase later).  WAR: a slot is re-filled two or more phases after its last read (the other
+//     group's reads of phase g are complete only behind the second barrier of phase g).
+//   * image of a slot: 128 rows x 128 B, lane-linear for the DMA, 16-byte slot (row, c) <- k-chunk c ^ (row & 7) (swizzle in the source
+//     address, the same involution in the fragment address): conflict-free ds_read_b128 (k_gemm_nt256's).  RI < 8: the rows a group does
+//     not own are requested out of bounds (zeros, no memory traffic), so every wave issues the same two instructions per slot and the
+//     counted waits hold.
+//   * persistent, XCD-major tile order, the k-steps of consecutive tiles form one stream; epilogue = nt_epilogue_rows through the
+//     wave-private transpose buffer: the same bits as k_gemm_nt / k_gemm_nt256.  The epilogue drains the DMA queue once (vmcnt(0)),
+//     and the first k-step behind it skips the waits of phases 0 / 1 (everything they cover was drained; a counted wait there would
+//     wait for the epilogue's stores).
+constexpr int P8_SLOT = 128 * 128;
+constexpr int P8_BUF = 4 * P8_SLOT;
+constexpr int P8_LDS = 2 * P8_BUF + G2_EPI;    // 160 KB
+
+template <typename TC, int EPI, int RI>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt8p(NtArgs g, int tiles_m, int tiles_n, int nvirt) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  constexpr int R0 = (RI + 1) / 2, R1 = RI - R0, BM = 32 * RI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)(((size_t)(g.M - 1) * g.lda + g.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)(((size_t)(g.N - 1) * g.ldb + g.K) * 2), 0x00020000);
+  // ---- LDS-DMA: a slot is 16 wave-instructions (8 rows x 128 B each); wave w issues instructions w (image rows 8w ..: M group 0 / N
+  //      groups 0-1) and w + 8 (image rows 64 + 8w ..: M group 1 / N groups 2-3)
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+  constexpr unsigned OOB = 0x80000000u;            // beyond every buffer's range (< 2 GB): reads as zeros
+  const int rr = w * 8 + lrow;                     // row inside a group's 64-row share of an A slot
+  const unsigned laneA0 = rr < R0 * 16 ? (unsigned)((rr * g.lda + lchunk * 8) * 2) : OOB;
+  const unsigned laneA1 = rr < R1 * 16 ? (unsigned)(((R0 * 16 + rr) * g.lda + lchunk * 8) * 2) : OOB;
+  const unsigned grpA = (unsigned)(16 * RI * g.lda * 2);                                      // M group 1's rows
+  const unsigned laneB = (unsigned)((((w >> 2) * 64 + (w & 3) * 8 + lrow) * g.ldb + lchunk * 8) * 2);
+  const unsigned halfB = (unsigned)(32 * g.ldb * 2), grpB = (unsigned)(128 * g.ldb * 2);
+  // request q (0..7) of a k-step: slot q >> 1 (A'0, B'0, B'1, A'1), instruction q & 1; src = byte offset of the tile's first row + k
+  auto issue = [&](int q, unsigned srcA, unsigned srcB, int buf) {
+    char* dst = smem + buf * P8_BUF + (q >> 1) * P8_SLOT + (q & 1) * 8192 + w * 1024;
+    const int slot = q >> 1;
+    if (slot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, laneA0 + (srcA + (q & 1) * grpA), 0, 0, 0);
+    else if (slot == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, laneA1 + (srcA + (q & 1) * grpA), 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)dst, 16, laneB + (srcB + (slot - 1) * halfB + (q & 1) * grpB), 0, 0, 0);
+  };
+  // ---- fragment addresses (buffer 0, k-half 0; k-half 1 = address ^ 64)
+  const unsigned s0 = lds_addr(smem);
+  const unsigned sw0 = (unsigned)((((lane >> 4)) ^ (lane & 7)) * 16);
+  const unsigned fa0 = s0 + (unsigned)((wm * 64 + (lane & 15)) * 128) + sw0;
+  const unsigned fb0 = s0 + (unsigned)((wn * 32 + (lane & 15)) * 128) + sw0;
+  u32x4 FA[4][2], FB0[2][2], FB1[2][2];            // [row / column block][k half]
+  f32x4 acc[RI][4];
+  float alpha = g.alpha;
+  if (g.alpha_ptr) alpha *= *g.alpha_ptr;
+  float d0 = 0.f, d1 = 1.f;
+  if (EPI == UVC_EPI_BIAS_RESID_GATE) { d0 = g.dptr[0]; d1 = g.dptr[1]; }
+  float* const stg = reinterpret_cast<float*>(smem + 2 * P8_BUF) + w * (16 * 64);
+
+  const int nk = g.K / 64;                         // >= 4
+  int v = blockIdx.x, bm = 0, bn = 0;
+  while (v < nvirt && !g2_tile(v, tiles_m, tiles_n, bm, bn)) v += gridDim.x;
+  if (v >= nvirt) return;
+  unsigned voA = (unsigned)(bm * BM * g.lda * 2), voB = (unsigned)(bn * 256 * g.ldb * 2);
+  int par = 0;                                     // buffer of the current tile's k-step 0
+  // prologue: k-step 0 whole, A'0 and B'0 of k-step 1 (what the steady state has requested when a k-step begins)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) issue(q, voA, voB, 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue(q, voA + 128, voB + 128, 1);
+  wait_vm<6>();                                    // A'0, B'0, B'1 of k-step 0 have landed (this wave's parts)
+  __builtin_amdgcn_s_barrier();                    // ... everybody's
+  // The fragments of a phase are requested INSIDE the MFMA block of the phase before (behind the MFMAs that last use their registers), so a
+  // wave's segment between the two barriers of a phase is [wait for fragments requested a whole request segment ago | 16 MFMAs with the next
+  // phase's reads between them], and the segment in front of the first barrier is the two DMA requests and their counted wait alone: that is
+  // what runs beside the other group's MFMA block (an LDS-DMA request costs its wave 100-200 cycles of issue; with the 12 reads of phase 0 in
+  // the same segment it was longer than the MFMA block and set the phase time: 707 cycles per phase for 272 of MFMA issue, measured by removing
+  // one ingredient at a time).  Waits: data consumed by the MFMAs of phase c is read in phase c - 1 and waited for in phase c - 2 (the other
+  // group's wait of phase c - 2 is half a phase later): vmcnt(6) in phases 2, 3, 0, three slots in flight.
+#define P8_RD_B(DST, SLOT, BO)                                                                                       \
+  { const unsigned b0_ = fb0 + (BO), b1_ = (fb0 ^ 64u) + (BO);                                                        \
+    DST[0][0] = ds_read128<(SLOT) * P8_SLOT>(b0_); DST[0][1] = ds_read128<(SLOT) * P8_SLOT>(b1_);                      \
+    DST[1][0] = ds_read128<(SLOT) * P8_SLOT + 2048>(b0_); DST[1][1] = ds_read128<(SLOT) * P8_SLOT + 2048>(b1_); }
+#define P8_RD_A(I, SLOT, BO)                                                                                         \
+  { FA[I][0] = ds_read128_asm(fa0 + (BO), (SLOT) * P8_SLOT + (I) * 2048); FA[I][1] = ds_read128_asm((fa0 ^ 64u) + (BO), (SLOT) * P8_SLOT + (I) * 2048); }
+#define P8_MMA4(I, AI, FB, JO)                                                                                       \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                    \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                       \
+    acc[AI][(JO) + j] = MM::mma(__builtin_bit_cast(typename MM::Frag, FB[j][ks]), __builtin_bit_cast(typename MM::Frag, FA[I][ks]), acc[AI][(JO) + j]);
+  // request segment of a phase: two DMA instructions (q0, q0 + 1) of the k-step (sA, sB, sbuf), the counted wait, the first barrier
+#define P8_REQ(Q0, SA, SB, SBUF, WAIT)                                                                               \
+  issue(Q0, SA, SB, SBUF); issue(Q0 + 1, SA, SB, SBUF);                                                               \
+  if (WAIT) wait_vm<6>();                                                                                             \
+  __builtin_amdgcn_s_barrier();                                                                                       \
+  wait_lgkm<0>();                                                                                                     \
+  __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  __builtin_amdgcn_s_setprio(1);
+#define P8_END                                                                                                       \
+  __builtin_amdgcn_s_setprio(0);                                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  __builtin_amdgcn_s_barrier();                                                                                       \
+  __builtin_amdgcn_sched_barrier(0);
+  P8_RD_B(FB0, 1, 0u)
+#pragma unroll
+  for (int i = 0; i < R0; ++i) P8_RD_A(i, 0, 0u)
+  __builtin_amdgcn_sched_barrier(0);
+  if (wm == 1) __builtin_amdgcn_s_barrier();       // group 1 runs half a phase behind from here on
+  bool fresh = true;                               // phase 0's wait is needed (nothing drained the queue since the requests)
+
+  for (;;) {
+    int vn = v + gridDim.x, bmn = 0, bnn = 0;
+    while (vn < nvirt && !g2_tile(vn, tiles_m, tiles_n, bmn, bnn)) vn += gridDim.x;
+    const bool more = vn < nvirt;
+    const unsigned voAn = more ? (unsigned)(bmn * BM * g.lda * 2) : voA, voBn = more ? (unsigned)(bnn * 256 * g.ldb * 2) : voB;
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = (kt & 1) ^ par;
+      const unsigned bo = (unsigned)(buf * P8_BUF), bon = bo ^ (unsigned)P8_BUF;
+      // k-steps kt + 1 and kt + 2 of the stream: of this tile, or k-steps 0 / 1 of the next one (behind the workgroup's last tile the
+      // same instructions re-load this tile's: no branch around a DMA)
+      const bool t1 = kt + 1 >= nk, t2 = kt + 2 >= nk;
+      const unsigned sA1 = (t1 ? voAn : voA) + (unsigned)((t1 ? kt + 1 - nk : kt + 1) * 128), sB1 = (t1 ? voBn : voB) + (unsigned)((t1 ? kt + 1 - nk : kt + 1) * 128);
+      const unsigned sA2 = (t2 ? voAn : voA) + (unsigned)((t2 ? kt + 2 - nk : kt + 2) * 128), sB2 = (t2 ? voBn : voB) + (unsigned)((t2 ? kt + 2 - nk : kt + 2) * 128);
+      // ---- phase 0: (A0, B0); requests B'1 of k-step kt + 1; reads B1 of this k-step (its registers are free)
+      P8_REQ(4, sA1, sB1, buf ^ 1, fresh)
+      P8_RD_B(FB1, 2, bo)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < R0; ++i) P8_MMA4(i, i, FB0, 0)
+      P8_END
+      fresh = true;
+      // ---- phase 1: (A0, B1); requests A'1 of kt + 1; reads A1 of this k-step, row block by row block behind the MFMAs that free A0's registers
+      P8_REQ(6, sA1, sB1, buf ^ 1, false)
+#pragma unroll
+      for (int i = 0; i < R0; ++i) {
+        P8_MMA4(i, i, FB1, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < R1) P8_RD_A(i, 3, bo)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      P8_END
+      // ---- phase 2: (A1, B1); requests A'0 of kt + 2
+      P8_REQ(0, sA2, sB2, buf, true)
+#pragma unroll
+      for (int i = 0; i < R1; ++i) P8_MMA4(i, R0 + i, FB1, 2)
+      P8_END
+      // ---- phase 3: (A1, B0); requests B'0 of kt + 2; reads A0 and B0 of k-step kt + 1 (the other buffer)
+      P8_REQ(2, sA2, sB2, buf, true)
+#pragma unroll
+      for (int i = R1; i < R0; ++i) P8_RD_A(i, 0, bon)          // (registers phase 3 does not use)
+#pragma unroll
+      for (int i = 0; i < R1; ++i) {
+        P8_MMA4(i, R0 + i, FB0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        P8_RD_A(i, 0, bon)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      P8_RD_B(FB0, 1, bon)
+      P8_END
+    }
+    // ---- epilogue (16 rows x 64 columns at a time through this wave's transpose buffer)
+    wait_vm<0>();                                  // the requests of the next k-steps (in flight for 1-4 phases): drained once, here
+    fresh = false;
+    {
+      const int m0 = bm * BM, n0 = bn * 256;
+      float bias_v[OutVec<TC>::VN];
+      nt_load_bias<TC, EPI>(g, lane, n0 + wn * 64, bias_v);
+#pragma unroll
+      for (int h = 0; h < RI; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(stg_at<true>(stg, lane & 15, j * 4 + (lane >> 4))) = acc[h][j];
+        __builtin_amdgcn_wave_barrier();
+        nt_epilogue_rows<T, TC, EPI, 16, true>(g, stg, lane, m0 + wm * 16 * RI + h * 16, n0 + wn * 64, alpha, d0, d1, bias_v);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (!more) break;
+    v = vn; bm = bmn; bn = bnn; voA = voAn; voB = voBn;
+    par ^= nk & 1;
+  }
+#undef P8_RD_B
+#undef P8_RD_A
+#undef P8_MMA4
+#undef P8_REQ
+#undef P8_END
+  if (wm == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
+  wait_vm<0>();
+}
+
+static bool nt8p_ok(const NtArgs& a, bool a_f32) {
+  return !a_f32 && a.K % 64 == 0 && a.K >= 256 && a.N >= 256 && a.lda % 8 == 0 && a.ldb % 8 == 0 &&
+         (((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0 && (size_t)(a.M + 256) * a.lda * 2 < (1ull << 31) && (size_t)(a.N + 256) * a.ldb * 2 < (1ull << 31);
+}
+// rows per tile: the height (of 256 / 192 / 160 / 128) with the least work in the longest-running workgroup
+static int nt8p_pick_ri(int M, int N) {
+  const int tn = ceil_div(N, 256);
+  int best = 8; long best_cost = -1;
+  const int cand[4] = {8, 6, 5, 4};
+  for (int ri : cand) {
+    const int tm = ceil_div(M, 32 * ri);
+    const long tiles = (long)tm * tn;
+    const long rounds = (tiles + 255) / 256;
+    const long cost = rounds * (ri + 8);           // tile time ~ a + b * rows with a / b = 8 row blocks (measured at M = 25 216, N = 768: 189 / 150 / 137 / 169 us for
+                                                   // ri 8 / 6 / 5 / 4 = 2 / 2 / 2 / 3 rounds; the requests of the B slots and the latency of a k-step do not shrink with the rows)
+    if (best_cost < 0 || cost < best_cost) { best = ri; best_cost = cost; }
+  }
+  return best;
+}
+template <typename TC, int RI>
+static int launch_nt8p_ri(const NtArgs& a, int epi, hipStream_t st) {
+  const int tm = ceil_div(a.M, 32 * RI), tn = ceil_div(a.N, 256);
+  const int nvirt = ceil_div(tm, 8) * 8 * tn;
+  const int grid = nvirt < 256 ? nvirt : 256;
+#define P8_CASE(E) case E: UVC_MAX_LDS(P8_LDS, k_gemm_nt8p<TC, E, RI>); k_gemm_nt8p<TC, E, RI><<<grid, 512, P8_LDS, st>>>(a, tm, tn, nvirt); break;
+  switch (epi) {
+    P8_CASE(UVC_EPI_NONE) P8_CASE(UVC_EPI_BIAS) P8_CASE(UVC_EPI_BIAS_GELU) P8_CASE(UVC_EPI_BIAS_RESID)
+    P8_CASE(UVC_EPI_BIAS_RESID_GATE) P8_CASE(UVC_EPI_DGELU) P8_CASE(UVC_EPI_BIAS_GELU_OUT) P8_CASE(UVC_EPI_BIAS_GELU_GRAD) P8_CASE(UVC_EPI_MUL_AUX)
+    default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
+  }
+#undef P8_CASE
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+template <typename TC>
+static int launch_nt8p(const NtArgs& a, int epi, int ri, hipStream_t st) {
+  if (ri <= 0) ri = nt8p_pick_ri(a.M, a.N);
+  if constexpr (sizeof(TC) == 4) return launch_nt8p_ri<TC, 8>(a, epi, st);     // float32 C (resid_f32 A/B mode, patch embedding): the 256-row tile only
+  else switch (ri) {
+    case 8: return launch_nt8p_ri<TC, 8>(a, epi, st);
+    case 6: return launch_nt8p_ri<TC, 6>(a, epi, st);
+    case 5: return launch_nt8p_ri<TC, 5>(a, epi, st);
+    default: return launch_nt8p_ri<TC, 4>(a, epi, st);
+  }
+}
+int launch_nt8p_f32(const NtArgs& a, int epi, int ri, hipStream_t st) { return launch_nt8p<float>(a, epi, ri, st); }
+int launch_nt8p_bf16(const NtArgs& a, int epi, int ri, hipStream_t st) { return launch_nt8p<bf16_t>(a, epi, ri, st); }
+bool nt8p_takes(const NtArgs& a, bool a_f32) { return nt8p_ok(a, a_f32); }
 
 // ================================================================================================
 //                                            TN (wgrad)

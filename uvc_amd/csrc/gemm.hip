@@ -168,9 +168,35 @@ template <typename TC, int EPI> __device__ __forceinline__ void nt_load_bias(con
 #pragma unroll
   for (int e = 0; e < VN; ++e) bias_v[e] = (has_bias && n + e < g.N) ? g.bias[n + e] : 0.f;
 }
-template <typename T, typename TC, int EPI, int ROWS = 32, bool SWZ = false>
+// Operand rows of an epilogue (R, R2, aux) requested AHEAD of the rows they meet: the epilogue of a big tile is a chain of [transpose 16 rows
+// through LDS | load their operands | arithmetic | store]; with the loads inside the chain every 16-row step was a memory round trip (dfc2 x GELU'
+// of DeiT-Base: 24 us of epilogue per 256 x 256 tile against 16 us of k-loop).  bf16 C only (16 bytes = the lane's 8 columns); a lane whose
+// columns are not a whole aligned vector (ragged N, odd leading dimensions) keeps loading in place.
+template <int NIT> struct EpiPre { u32x4 r[NIT], r2[NIT], ax[NIT]; };
+template <int EPI> struct EpiOperands {
+  static constexpr bool R = EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE, R2 = EPI == UVC_EPI_BIAS_RESID_GATE,
+                        AUX = EPI == UVC_EPI_DGELU || EPI == UVC_EPI_MUL_AUX;
+  static constexpr int COUNT = (R ? 1 : 0) + (R2 ? 1 : 0) + (AUX ? 1 : 0);
+};
+template <int EPI, int ROWS>
+__device__ __forceinline__ void nt_epilogue_prefetch(const NtArgs& g, int lane, int mrow0, int ncol0, EpiPre<ROWS / 8>& P) {
+  const int cc = (lane & 7) * 8, n = ncol0 + cc;
+  const bool nfull = (n + 8 <= g.N) && ((g.ldc % 8) == 0);
+#pragma unroll
+  for (int it = 0; it < ROWS / 8; ++it) {
+    const int m = mrow0 + it * 8 + (lane >> 3);
+    if (m < g.M && nfull) {
+      const size_t mo = (size_t)m;
+      if (EpiOperands<EPI>::R && (g.ldr % 8) == 0) P.r[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(g.R) + mo * g.ldr + n);
+      if (EpiOperands<EPI>::R2 && (g.ldr % 8) == 0) P.r2[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(g.R2) + mo * g.ldr + n);
+      if (EpiOperands<EPI>::AUX && (g.ldaux % 8) == 0) P.ax[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(g.aux) + mo * g.ldaux + n);
+    }
+  }
+}
+template <typename T, typename TC, int EPI, int ROWS = 32, bool SWZ = false, bool PRE = false>
 __device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, float* stg, int lane, int mrow0, int ncol0, float alpha, float d0, float d1,
-                                                 const float* bias_v) {
+                                                 const float* bias_v, const EpiPre<ROWS / 8>* pre = nullptr) {
+  static_assert(!PRE || (sizeof(TC) == 2 && sizeof(T) == 2), "operand prefetch: bf16 C and operands only");
   constexpr int VN = OutVec<TC>::VN;
   constexpr int LPR = 64 / VN;                  // lanes per 64-column row
   constexpr int RPI = 64 / LPR;                 // rows per wave instruction
@@ -196,7 +222,7 @@ __device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, float* stg, in
       if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) {
         const TC* rp = reinterpret_cast<const TC*>(g.R) + mo * g.ldr + n;
         float rv[VN];
-        if (nfull && (g.ldr % VN) == 0) load_vec<TC, VN>(rp, rv);
+        if (nfull && (g.ldr % VN) == 0) { if constexpr (PRE) Resid<TC>::get(pre->r[it], rv); else load_vec<TC, VN>(rp, rv); }
         else {
 #pragma unroll
           for (int e = 0; e < VN; ++e) rv[e] = (n + e < g.N) ? ElemIO<TC>::load(rp + e) : 0.f;
@@ -207,7 +233,7 @@ __device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, float* stg, in
       if (EPI == UVC_EPI_BIAS_RESID_GATE) {
         const TC* rp = reinterpret_cast<const TC*>(g.R2) + mo * g.ldr + n;
         float rv[VN];
-        if (nfull && (g.ldr % VN) == 0) load_vec<TC, VN>(rp, rv);
+        if (nfull && (g.ldr % VN) == 0) { if constexpr (PRE) Resid<TC>::get(pre->r2[it], rv); else load_vec<TC, VN>(rp, rv); }
         else {
 #pragma unroll
           for (int e = 0; e < VN; ++e) rv[e] = (n + e < g.N) ? ElemIO<TC>::load(rp + e) : 0.f;
@@ -218,7 +244,7 @@ __device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, float* stg, in
       if (EPI == UVC_EPI_DGELU || EPI == UVC_EPI_MUL_AUX) {
         const T* ap = reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n;
         float av[VN];
-        if (nfull && (g.ldaux % VN) == 0) load_vec<T, VN>(ap, av);
+        if (nfull && (g.ldaux % VN) == 0) { if constexpr (PRE) Resid<TC>::get(pre->ax[it], av); else load_vec<T, VN>(ap, av); }
         else {
 #pragma unroll
           for (int e = 0; e < VN; ++e) av[e] = (n + e < g.N) ? ElemIO<T>::load(ap + e) : 0.f;
@@ -1814,6 +1840,27 @@ extern "C" int uvc_gemm_nt_lnbwd(const uvc_gemm_lnbwd_args* p, void* stream) {
 //   * One PERSISTENT workgroup per CU walks its tiles (numbered XCD-major: block b runs on XCD b % 8, so all N tiles of an M tile
 //     share an L2); the first two k-steps of the next tile are requested during the last two steps of the current one, so only the
 //     first tile of a workgroup pays the operand latency and the epilogue is the only gap between tiles.
+// Epilogue of a wave's NH x 16 accumulator rows (acc[h][0..3], rows MROW0 + 16 h .., columns NCOL0 .. + 63) through its swizzled 4-KB transpose
+// buffer `stg`, 16 rows at a time; with a bf16 C the operand rows (R / R2 / aux) of step h + PD are requested when step h is done (PD steps in
+// flight; PD1 with one operand, PD2 with two: 8 registers per operand and step).  Same arithmetic and stores as every other user of nt_epilogue_rows: same bits.
+#define NT_EPILOGUE_TILE(NH, MROW0, NCOL0, PD1, PD2)                                                                                 \
+  {                                                                                                                           \
+    constexpr bool PRE_ = sizeof(TC) == 2 && EpiOperands<EPI>::COUNT > 0;                                                     \
+    constexpr int PD_ = EpiOperands<EPI>::COUNT >= 2 ? (PD2) : (PD1);                                                              \
+    EpiPre<2> pre_[PD_];                                                                                                      \
+    if constexpr (PRE_) {                                                                                                     \
+      _Pragma("unroll") for (int h = 0; h < PD_ && h < (NH); ++h) nt_epilogue_prefetch<EPI, 16>(g, lane, (MROW0) + h * 16, (NCOL0), pre_[h]); \
+    }                                                                                                                         \
+    _Pragma("unroll") for (int h = 0; h < (NH); ++h) {                                                                        \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                           \
+        *reinterpret_cast<f32x4*>(stg_at<true>(stg, lane & 15, j * 4 + (lane >> 4))) = acc[h][j];                            \
+      __builtin_amdgcn_wave_barrier();                                                                                        \
+      nt_epilogue_rows<T, TC, EPI, 16, true, PRE_>(g, stg, lane, (MROW0) + h * 16, (NCOL0), alpha, d0, d1, bias_v, &pre_[h % PD_]); \
+      if constexpr (PRE_) { if (h + PD_ < (NH)) nt_epilogue_prefetch<EPI, 16>(g, lane, (MROW0) + (h + PD_) * 16, (NCOL0), pre_[h % PD_]); } \
+      __builtin_amdgcn_wave_barrier();                                                                                        \
+    }                                                                                                                         \
+  }
+
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_OPB = 256 * 128;              // bytes of one operand tile image (256 rows x 128 B)
 constexpr int G2_STAGE = 2 * G2_OPB;           // A image + B image
@@ -1953,15 +2000,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt256(NtArgs g, int tiles_m, in
       const int m0 = bm * G2_BM, n0 = bn * G2_BN;
       float bias_v[OutVec<TC>::VN];
       nt_load_bias<TC, EPI>(g, lane, n0 + wn * 64, bias_v);
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(stg_at<true>(stg, lane & 15, j * 4 + (lane >> 4))) = acc[h][j];
-        __builtin_amdgcn_wave_barrier();
-        nt_epilogue_rows<T, TC, EPI, 16, true>(g, stg, lane, m0 + wm * 128 + h * 16, n0 + wn * 64, alpha, d0, d1, bias_v);
-        __builtin_amdgcn_wave_barrier();
-      }
+      NT_EPILOGUE_TILE(8, m0 + wm * 128, n0 + wn * 64, 2, 1)      // (256 registers: two fragment sets are live across the epilogue)
     }
     if (!more) break;
     v = vn; bm = bmn; bn = bnn; voA = voAn; voB = voBn;
@@ -2436,15 +2475,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt8p(NtArgs g, int tiles_m, int
       const int m0 = bm * BM, n0 = bn * 256;
       float bias_v[OutVec<TC>::VN];
       nt_load_bias<TC, EPI>(g, lane, n0 + wn * 64, bias_v);
-#pragma unroll
-      for (int h = 0; h < RI; ++h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(stg_at<true>(stg, lane & 15, j * 4 + (lane >> 4))) = acc[h][j];
-        __builtin_amdgcn_wave_barrier();
-        nt_epilogue_rows<T, TC, EPI, 16, true>(g, stg, lane, m0 + wm * 16 * RI + h * 16, n0 + wn * 64, alpha, d0, d1, bias_v);
-        __builtin_amdgcn_wave_barrier();
-      }
+      NT_EPILOGUE_TILE(RI, m0 + wm * 16 * RI, n0 + wn * 64, 4, 2)
     }
     if (!more) break;
     v = vn; bm = bmn; bn = bnn; voA = voAn; voB = voBn;

@@ -92,26 +92,31 @@ __global__ void k_head_scores(const double* __restrict__ ws64, uvc_dims d, float
 }
 
 // ---------------------------------------------------------------------------- ranks
-// rank[i] = #{ j : v[j] < v[i]  or (v[j] == v[i] and j < i) }.  One block per layer; groups of at
-// most a few thousand elements are staged in LDS (F <= 8192).
-__global__ __launch_bounds__(1024) void k_rank(const float* __restrict__ sc1, const float* __restrict__ sc2,
-                                               const float* __restrict__ sc3, uvc_dims d,
-                                               int32_t* __restrict__ rank1, int32_t* __restrict__ rankh,
-                                               int32_t* __restrict__ rank3) {
+// rank[i] = #{ j : v[j] < v[i]  or (v[j] == v[i] and j < i) }.  Block (c, l): 256 of layer l's F fc2-column scores against all F
+// (staged in LDS, F <= 8192; every lane of a wave reads the same sh[j]: a broadcast); block (0, l) also ranks the D proj columns inside
+// their heads and the H heads.  (One block per layer, as in rounds 1-3, was 12 blocks on 256 CUs: 372 us per launch at DeiT-Base's F = 3072.)
+__global__ __launch_bounds__(256) void k_rank(const float* __restrict__ sc1, const float* __restrict__ sc2,
+                                              const float* __restrict__ sc3, uvc_dims d,
+                                              int32_t* __restrict__ rank1, int32_t* __restrict__ rankh,
+                                              int32_t* __restrict__ rank3) {
   extern __shared__ float sh[];
-  const int l = blockIdx.x;
+  const int l = blockIdx.y;
   // W3 columns
   for (int i = threadIdx.x; i < d.F; i += blockDim.x) sh[i] = sc3[l * d.F + i];
   __syncthreads();
-  for (int i = threadIdx.x; i < d.F; i += blockDim.x) {
-    const float v = sh[i];
-    int rk = 0;
-    for (int j = 0; j < d.F; ++j) {
-      const float u = sh[j];
-      rk += (u < v) || (u == v && j < i);
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.F) {
+      const float v = sh[i];
+      int rk = 0;
+      for (int j = 0; j < d.F; ++j) {
+        const float u = sh[j];
+        rk += (u < v) || (u == v && j < i);
+      }
+      rank3[l * d.F + i] = rk;
     }
-    rank3[l * d.F + i] = rk;
   }
+  if (blockIdx.x != 0) return;
   __syncthreads();
   // W1 columns inside each head
   for (int i = threadIdx.x; i < d.D; i += blockDim.x) sh[i] = sc1[l * d.D + i];
@@ -454,7 +459,7 @@ extern "C" int uvc_rank(const float* scores1, const float* scores2, const float*
   if (int e = check_dims(d)) return e;
   if (!scores1 || !scores2 || !scores3 || !rank1 || !rankh || !rank3) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_rank: null pointer");
   const size_t sh = sizeof(float) * (size_t)(d.F > d.D ? d.F : d.D);
-  k_rank<<<d.L, 1024, sh, (hipStream_t)stream>>>(scores1, scores2, scores3, d, rank1, rankh, rank3);
+  k_rank<<<dim3((d.F + 255) / 256, d.L), 256, sh, (hipStream_t)stream>>>(scores1, scores2, scores3, d, rank1, rankh, rank3);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

@@ -153,7 +153,9 @@ def test_gemm_nt_ksplit_streaming_kernel_matches_generic(K, M):
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("M,N1,N2", [(1576, 576, 192), (403, 192, 768), (3001, 768, 192), (64, 1000, 192), (5000, 128, 128), (40, 8, 16), (4133, 192, 192),
-                                     (2500, 3072, 768), (1210, 768, 3072), (999, 2304, 768)])     # the last three: DeiT-Base (256 x 256 tiles)
+                                     (2500, 3072, 768), (1210, 768, 3072), (999, 2304, 768), (25216, 768, 768), (70, 1024, 768)])
+                                     # the last five: 256 x 256 tiles (DeiT-Base; r4: k_gemm_tn8p -- splits that are not whole 64-row k-steps, a split of one
+                                     # k-step, the full batch-128 row count with 28 splits of 9 tiles)
 def test_gemm_tn(dtype, M, N1, N2):
     from uvc_amd import ops
     A, B = rnd(M, N1, seed=11), rnd(M, N2, seed=12)
@@ -169,9 +171,10 @@ def test_gemm_tn(dtype, M, N1, N2):
         cs = torch.ones(N1, device=dev())
         ops.gemm_tn(At, Bt, Cc, ws, dtype=dtype, alpha=2.0, alpha_ptr=alpha, beta=1.0, colsum_out=cs)
         ref = C0.double() + Aeff.double().t() @ Bt.double()
-        t = dict(rtol=2e-5, atol=2e-4) if dtype == F32 else dict(rtol=2e-2, atol=5e-2)
+        # (float32: the rounding of an M-term sum of O(1) products grows with M -- the bound is the 4 k-row one scaled)
+        t = dict(rtol=2e-5, atol=2e-4 * max(1.0, M / 4000.0)) if dtype == F32 else dict(rtol=2e-2, atol=5e-2)
         torch.testing.assert_close(Cc.double(), ref, **t)
-        torch.testing.assert_close(cs.double(), 1 + Aeff.double().sum(0), rtol=1e-4, atol=2e-3)   # fused bias gradient
+        torch.testing.assert_close(cs.double(), 1 + Aeff.double().sum(0), rtol=1e-4, atol=2e-3 * max(1.0, M / 4000.0))   # fused bias gradient
     # determinism: two runs bit-identical
     C1, C2 = torch.empty(N1, N2, device=dev()), torch.empty(N1, N2, device=dev())
     ops.gemm_tn(to_t(A, dtype), to_t(B, dtype), C1, ws, dtype=dtype)

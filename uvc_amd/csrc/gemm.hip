@@ -2983,6 +2983,200 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
   }
 }
 
+// ---- 256 x 256 weight-gradient tiles with two wave groups half a phase apart (k_gemm_nt8p's schedule, transposing reads).
+// k_gemm_tn_dma keeps its eight waves in lock step: [wait | barrier | 24 transposing fragment reads | wait | 32 MFMAs] per 32 rows, the read
+// latency in front of every MFMA block (0.82-0.86 PFLOP/s on DeiT-Base's shapes).  Here a k-step is 64 rows of the split, a wave's 128 x 64
+// block of the tile is four quadrants as in k_gemm_nt8p -- (A0, B0) (A0, B1) (A1, B1) (A1, B0), 16 MFMAs each -- the M groups w1 = 0 / 1 run
+// half a phase apart, the fragments of a phase are requested inside the MFMA block of the phase before, and the operand rows go HBM / L2 -> LDS
+// by buffer_load ... lds into two buffers of four 16-KB slots (A'0, B'0, B'1, A'1: read in phases 0, 0, 1, 2; one slot of a later k-step
+// requested per phase; vmcnt(6) in phases 2, 3, 0).  A slot is 64 rows (of M) x 128 columns: [row][16 chunks of 16 B], chunk c of row r holds
+// the columns of global chunk c ^ 2 (r & 7) -- the eight rows a 32-lane group of ds_read_b64_tr_b16 touches land in eight different 32-byte
+// bank groups (the padded rows of k_gemm_tn_dma, without the pad slots).  Rows past the split's end are requested past the buffer
+// descriptor's range and arrive as zeros, so a split need not be a whole number of k-steps.  The bias gradient (column sums of A: an
+// all-ones operand against the A fragments) is spread over the four waves of a row group, two column blocks each.  Same k order per
+// accumulator as k_gemm_tn_dma: the partial tiles are bit-identical.
+constexpr int T8_SLOT = 64 * 256, T8_BUF = 4 * T8_SLOT, T8_LDS = 2 * T8_BUF;       // 128 KB
+
+template <int OFF> __device__ __forceinline__ u32x2 ds_tr16_off(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+struct T8Frag { u32x2 lo, hi; };
+__device__ __forceinline__ bf16x8 t8_frag(const T8Frag& f) {
+  return __builtin_bit_cast(bf16x8, u32x4{f.lo[0], f.lo[1], f.hi[0], f.hi[1]});
+}
+
+__global__ __launch_bounds__(512, 2) void k_gemm_tn8p(TnArgs g) {
+  typedef Mma<bf16_t> MM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w1 = w >> 2, w2 = w & 3;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {                                                       // (tile, split) -> XCD-major order, as k_gemm_tn_dma
+    const int tiles = gridDim.x * gridDim.y, total = tiles * gridDim.z;
+    if (g.xcd_remap && tiles > 1 && total <= 256) {
+      const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
+      const int L = xcd * q + (xcd < r ? xcd : r) + slot;
+      const int t = L % tiles;
+      bz = L / tiles; bx = t % gridDim.x; by = t / gridDim.x;
+    }
+  }
+  const int n10 = bx * 256, n20 = by * 256;
+  const int mbeg = bz * g.rows_per_split;
+  const int mend = min(g.M, mbeg + g.rows_per_split);
+  const int nk = (mend - mbeg + 63) / 64;
+  const bool do_cs = g.bpart != nullptr && by == 0;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)((size_t)mend * g.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)((size_t)mend * g.ldb * 2), 0x00020000);
+  // ---- LDS-DMA: a slot is 16 wave-instructions of 4 rows x 256 B; wave w issues instructions w (rows 4w ..) and w + 8 (rows 32 + 4w ..)
+  unsigned laneA0, laneA1, laneB0, laneB1;
+  {
+    const int r = 4 * w + (lane >> 4), cg = (lane & 15) ^ (2 * (r & 7));        // global chunk this lane fetches
+    const int colA = (cg >> 3) * 128 + (cg & 7) * 8, colB = (cg >> 2) * 64 + (cg & 3) * 8;
+    laneA0 = (unsigned)((r * g.lda + n10 + colA) * 2); laneA1 = laneA0 + 128;
+    laneB0 = (unsigned)((r * g.ldb + n20 + colB) * 2); laneB1 = laneB0 + 64;
+  }
+  const unsigned hiA = (unsigned)(32 * g.lda * 2), hiB = (unsigned)(32 * g.ldb * 2);
+  // request q (0..7) of the k-step whose first row is m: slot q >> 1 (A'0, B'0, B'1, A'1), instruction q & 1
+  auto issue = [&](int q, int m, int buf) {
+    char* dst = smem + buf * T8_BUF + (q >> 1) * T8_SLOT + (q & 1) * 8192 + w * 1024;
+    const int slot = q >> 1;
+    const unsigned ra = (unsigned)(m * g.lda * 2), rb = (unsigned)(m * g.ldb * 2);
+    if (slot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, laneA0 + (ra + (q & 1) * hiA), 0, 0, 0);
+    else if (slot == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, laneA1 + (ra + (q & 1) * hiA), 0, 0, 0);
+    else if (slot == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)dst, 16, laneB0 + (rb + (q & 1) * hiB), 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)dst, 16, laneB1 + (rb + (q & 1) * hiB), 0, 0, 0);
+  };
+  // ---- fragment addresses (buffer 0, rows 0-31 of the slot, first of the two reads; + 4096: rows + 16; + 8192: rows 32-63)
+  const unsigned s0 = lds_addr(smem);
+  unsigned fa[4], fb[2];
+  {
+    const int il = lane & 15, gq = lane >> 4;
+    const int R = 4 * gq + (il >> 2), sw = R & 7, b = (il >> 1) & 1, half = il & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = s0 + (unsigned)(R * 256 + ((((w1 * 4 + i) ^ sw) * 2 + b) * 16) + half * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = s0 + (unsigned)(R * 256 + ((((w2 * 2 + j) ^ sw) * 2 + b) * 16) + half * 8);
+  }
+  T8Frag FA[4][2], FB0[2][2], FB1[2][2];
+  f32x4 acc[8][4], cs[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  cs[0] = f32x4{0.f, 0.f, 0.f, 0.f}; cs[1] = cs[0];
+  const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const typename MM::Frag ones = __builtin_bit_cast(typename MM::Frag, ones_u);
+
+#define T8_RD(F, ADDR, SLOT, KS) { F.lo = ds_tr16_off<(SLOT) * T8_SLOT + (KS) * 8192>(ADDR); F.hi = ds_tr16_off<(SLOT) * T8_SLOT + (KS) * 8192 + 4096>(ADDR); }
+#define T8_RD_B(DST, SLOT, BO)                                                                                        \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) { T8_RD(DST[j][0], fb[j] + (BO), SLOT, 0) T8_RD(DST[j][1], fb[j] + (BO), SLOT, 1) }
+#define T8_RD_A(I, SLOT, BO) { T8_RD(FA[I][0], fa[I] + (BO), SLOT, 0) T8_RD(FA[I][1], fa[I] + (BO), SLOT, 1) }
+#define T8_MMA4(I, AI, FB, JO)                                                                                        \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                     \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
+    acc[AI][(JO) + j] = MM::mma(t8_frag(FB[j][ks]), t8_frag(FA[I][ks]), acc[AI][(JO) + j]);
+#define T8_CS(U, I) { cs[U] = MM::mma(ones, t8_frag(FA[I][0]), cs[U]); cs[U] = MM::mma(ones, t8_frag(FA[I][1]), cs[U]); }
+#define T8_REQ(Q0, M, SBUF, WAIT)                                                                                     \
+  issue(Q0, M, SBUF); issue(Q0 + 1, M, SBUF);                                                                          \
+  if (WAIT) wait_vm<6>();                                                                                              \
+  __builtin_amdgcn_s_barrier();                                                                                        \
+  wait_lgkm<0>();                                                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  __builtin_amdgcn_s_setprio(1);
+#define T8_END                                                                                                        \
+  __builtin_amdgcn_s_setprio(0);                                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  __builtin_amdgcn_s_barrier();                                                                                        \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // prologue: k-step 0 whole, A'0 and B'0 of k-step 1
+#pragma unroll
+  for (int q = 0; q < 8; ++q) issue(q, mbeg, 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue(q, mbeg + 64, 1);
+  wait_vm<6>();
+  __builtin_amdgcn_s_barrier();
+  T8_RD_B(FB0, 1, 0u)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) T8_RD_A(i, 0, 0u)
+  __builtin_amdgcn_sched_barrier(0);
+  if (w1 == 1) __builtin_amdgcn_s_barrier();      // group 1 runs half a phase behind from here on
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const unsigned bo = (unsigned)(buf * T8_BUF), bon = bo ^ (unsigned)T8_BUF;
+    const int m1 = mbeg + (kt + 1) * 64, m2 = m1 + 64;   // (past the split's end: out of the descriptors' range, zeros nobody multiplies)
+    // ---- phase 0: (A0, B0); requests B'1 of k-step kt + 1; reads B1 of this k-step
+    T8_REQ(4, m1, buf ^ 1, true)
+    T8_RD_B(FB1, 2, bo)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T8_MMA4(i, i, FB0, 0)
+    if (do_cs) {
+      if (w2 == 0) { T8_CS(0, 0) T8_CS(1, 1) }
+      else if (w2 == 1) { T8_CS(0, 2) T8_CS(1, 3) }
+    }
+    T8_END
+    // ---- phase 1: (A0, B1); requests A'1 of kt + 1; reads A1 behind the MFMAs that free A0's registers
+    T8_REQ(6, m1, buf ^ 1, false)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      T8_MMA4(i, i, FB1, 2)
+      __builtin_amdgcn_sched_barrier(0);
+      T8_RD_A(i, 3, bo)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    T8_END
+    // ---- phase 2: (A1, B1); requests A'0 of kt + 2
+    T8_REQ(0, m2, buf, true)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T8_MMA4(i, 4 + i, FB1, 2)
+    if (do_cs) {
+      if (w2 == 2) { T8_CS(0, 0) T8_CS(1, 1) }
+      else if (w2 == 3) { T8_CS(0, 2) T8_CS(1, 3) }
+    }
+    T8_END
+    // ---- phase 3: (A1, B0); requests B'0 of kt + 2; reads A0 and B0 of k-step kt + 1 (the other buffer)
+    T8_REQ(2, m2, buf, true)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      T8_MMA4(i, 4 + i, FB0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      T8_RD_A(i, 0, bon)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    T8_RD_B(FB0, 1, bon)
+    T8_END
+  }
+#undef T8_RD
+#undef T8_RD_B
+#undef T8_RD_A
+#undef T8_MMA4
+#undef T8_CS
+#undef T8_REQ
+#undef T8_END
+  if (w1 == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+  wait_vm<0>();
+  wait_lgkm<0>();
+  if (do_cs && (lane >> 4) == 0) {                // every row of cs[u] holds the column sums of n1 = .. + (lane & 15)
+    float* bp = g.bpart + (size_t)bz * g.N1 + n10 + w1 * 128 + (w2 >> 1) * 64 + (w2 & 1) * 32 + (lane & 15);
+    bp[0] = cs[0][0]; bp[16] = cs[1][0];
+  }
+  float* P = g.part + (size_t)bz * g.N1 * g.N2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n1 = n10 + w1 * 128 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n2 = n20 + w2 * 64 + j * 16 + (lane >> 4) * 4;
+      *reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];
+    }
+  }
+}
+
 // sum the split-M partial tiles (and partial column sums) in a fixed order.  VEC = 4: 16-byte accesses, 4 slices in flight
 template <int VEC>
 __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ part, float* __restrict__ C, int n, int ldc,
@@ -3023,7 +3217,7 @@ static int tn_config(int N1, int N2) {
   // 5 = 256 x 256 (LDS-DMA kernel, bf16 operands): DeiT-Base's shapes.  131 flop per operand byte through LDS against 108 for 192 x 256; the
   // split-M kernels are bound by the L2 -> LDS rate of their 32-row stages (pipe 31 % busy at 0.75 PFLOP/s).  Wide matrices only: at
   // DeiT-Tiny / Small widths the 192-wide tiles divide the shapes and leave more splits.
-  if (N1 % 256 == 0 && N2 % 256 == 0 && (N1 / 256) * (N2 / 256) >= 16) return 5;
+  if (N1 % 256 == 0 && N2 % 256 == 0 && (N1 / 256) * (N2 / 256) >= 9) return 5;     // (r4: k_gemm_tn8p; 9 tiles = DeiT-Base's dW_proj)
   if (N1 % 192 == 0 && N2 % 256 == 0) return 1;
   if (N1 % 256 == 0 && N2 % 192 == 0) return 2;
   if (N1 % 192 == 0 && N2 % 192 == 0 && (N1 / 192) * (N2 / 192) >= 2) return 3;   // a single 192x192 tile would need 256 splits
@@ -3059,6 +3253,8 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   int64_t need; int splits;
   uvc_gemm_tn_workspace_bytes(p->M, p->N1, p->N2, &need, &splits);
   if (p->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: workspace too small");
+  if ((size_t)(p->M + 256) * (p->lda > p->ldb ? p->lda : p->ldb) * 2 >= (1ull << 31) && p->dtype == UVC_BF16 && tn_config(p->N1, p->N2) == 5)
+    return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_tn: operand beyond 2 GB (32-bit buffer offsets of the 256 x 256 kernel)");
   int cfg = (p->dtype == UVC_BF16 && p->lda % 8 == 0 && p->ldb % 8 == 0) ? tn_config(p->N1, p->N2) : 0;
   if (cfg == 4 && p->a_is_f32) cfg = 0;                      // the 96x192 tile exists as an LDS-DMA (bf16 operands) kernel only
   if (cfg == 5 && p->a_is_f32) cfg = (p->N1 % 192 == 0 && p->N2 % 256 == 0) ? 1 : (p->N1 % 256 == 0 && p->N2 % 192 == 0) ? 2 : 0;
@@ -3097,7 +3293,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
       else if (cfg == 1) TN_DMA_ONE(192, 256, 2, 4)
       else if (cfg == 2) TN_DMA_ONE(256, 192, 4, 2)
       else if (cfg == 4) TN_DMA_ONE(96, 192, 2, 4)
-      else if (cfg == 5) TN_DMA_ONE(256, 256, 2, 4)
+      else if (cfg == 5) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p); k_gemm_tn8p<<<grid, 512, T8_LDS, st>>>(a); }
       else TN_DMA_ONE(192, 192, 2, 4)
 #undef TN_DMA_ONE
 #undef TN_BIG

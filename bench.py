@@ -290,6 +290,9 @@ def main():
         tr = Stage2Trainer(a, device=f"cuda:{local}", distributed=world > 1, world_size=world)
         stage2_checkpoint_state(tr.model)
         tr.mlp_widths = tr.model.set_mlp_compaction() if args.compact_mlp else tr.model.set_mlp_compaction(False)
+        # (the masks were set after the trainer derived its tables from the checkpoint: derive the pruned-head table again)
+        tr.head_keep = tr.model.set_head_skipping() if args.compact_mlp else tr.model.set_head_skipping(False)
+        tr.model.skip_pruned_head_grads = bool(args.compact_mlp) and tr.head_keep is not None
         tr.begin_epoch(a.warmup_epochs + 1)
     else:
         from uvc_amd.stage1 import Stage1Trainer, default_args

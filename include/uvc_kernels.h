@@ -95,10 +95,13 @@ typedef struct uvc_attn_args {
   float* delta;      /* scratch [B,H,N]    backward only */
   int32_t B, N, H, head_dim, dtype;
   float scale;
-  const int32_t* head_keep;  /* forward only, optional device [H]: heads with 0 are skipped and their slice of o is written as zeros.
+  const int32_t* head_keep;  /* optional device [H].  Forward: heads with 0 are skipped and their slice of o is written as zeros.
                                 For inference on a pruned model whose attn.proj input columns of that head are all zero (masked),
                                 which makes the skip exact.  Not for training: the reference's clip norm includes the gradients of
-                                masked proj columns, which need the head's output. */
+                                masked proj columns, which need the head's output.
+                                Backward: dq / dk / dv of heads with 0 are written as zeros without being computed -- exact when dout is
+                                zero on the head's 64 columns, i.e. when attn.proj's input columns of that head are zero in the weights
+                                the dgrad used (Stage-2 masked fine-tuning) */
 } uvc_attn_args;
 int uvc_attention_fwd(const uvc_attn_args* args, void* stream);
 int uvc_attention_bwd(const uvc_attn_args* args, void* stream);
@@ -114,7 +117,7 @@ typedef struct uvc_attn_tok_args {
   void* dqkv;        /* T [B, N, 3, H, 64] backward output */
   int32_t B, N, H, head_dim, ntok, dtype;
   float scale;
-  const int32_t* head_keep;  /* forward only, optional device [H], as in uvc_attn_args */
+  const int32_t* head_keep;  /* optional device [H], forward and backward as in uvc_attn_args */
 } uvc_attn_tok_args;
 int uvc_attention_tok_fwd(const uvc_attn_tok_args* args, void* stream);
 int uvc_attention_tok_bwd(const uvc_attn_tok_args* args, void* stream);

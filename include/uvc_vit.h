@@ -113,7 +113,8 @@ typedef struct uvc_vit_io {
   void* side_stream;
   const uvc_mlp_compact* mlp_compact;  /* HOST [L] or NULL; entries with width 0 or width == hidden run dense */
   const int32_t* head_keep;            /* device [L, H] or NULL: no-grad forwards skip the attention of heads marked 0 (their
-                                          attn.proj input columns are masked to zero, so the result is unchanged); ignored when training */
+                                          attn.proj input columns are masked to zero, so the result is unchanged); training forwards ignore it, backward
+                                          uses it when head_keep_bwd is set */
   int32_t full_tail;                   /* 0 (default): the last block that runs computes everything behind its qkv projection on the class /
                                           distillation token rows only -- the only rows of it that reach the head (:507-526), so no output of the
                                           step changes (uvc_attention_tok_*); 1: all rows, as the reference executes it */
@@ -129,7 +130,13 @@ typedef struct uvc_vit_io {
   int32_t force_generic;               /* tests / A-B runs: passed to every uvc_gemm_nt of the pass (uvc_gemm_nt_args.force_generic: 1 = the generic
                                           LDS-tiled kernel everywhere, 2 = register-staged streaming kernels instead of the LDS-DMA rings);
                                           1 also runs every dgrad + LayerNorm backward as the unfused pair, 2 runs uvc_gemm_nt_lnbwd's
-                                          register-staged variant.  0 = kernels picked by shape */
+                                          register-staged variant; 3 = the production batch's wide-tile kernels at any row count.  0 = kernels
+                                          picked by shape */
+  int32_t head_keep_bwd;               /* 1: uvc_vit_backward skips dq / dk / dv of the heads head_keep marks 0 (written as zeros).  Exact when the
+                                          64 attn.proj input columns of such a head are zero IN THE WEIGHTS the forward and the dgrad used (Stage-2:
+                                          post_train.py:343-346 multiplies weight by mask before every step): dL/d(attention output) of the head is then
+                                          exactly zero and so are its dq, dk, dv.  The forward still computes the head (dW_proj of the masked columns
+                                          needs its output: the reference's clip norm sees it).  0: every head's backward runs */
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

@@ -209,6 +209,31 @@ def test_attention_fwd_bwd(dtype, B, N, H):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+def test_attention_backward_head_keep(dtype):
+    """uvc_attention_bwd with head_keep: heads marked 0 get dq = dk = dv = 0 without being computed -- what the full computation gives
+    when dout is zero on those heads' columns (Stage-2: masked attn.proj input columns); the other heads are untouched."""
+    from uvc_amd import ops
+    B, N, H = 3, 197, 3
+    T = ops.tdtype(dtype)
+    qkv = to_t(rnd(B, N, 3 * H * 64, seed=151), dtype)
+    dout = to_t(rnd(B, N, H * 64, seed=152), dtype)
+    dout.view(B, N, H, 64)[:, :, 1] = 0                    # head 1 is the pruned one
+    o = torch.empty(B, N, H * 64, device=dev(), dtype=T)
+    lse = torch.empty(B, H, N, device=dev())
+    ops.attention_fwd(qkv, o, lse, B, N, H, dtype)
+    keep = torch.tensor([1, 0, 1], device=dev(), dtype=torch.int32)
+    outs = []
+    for hk in (None, keep):
+        dqkv = torch.full((B, N, 3 * H * 64), float("nan"), device=dev(), dtype=T)
+        delta = torch.empty(B, H, N, device=dev())
+        ops.attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype, head_keep=hk)
+        outs.append(dqkv)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[1].view(B, N, 3, H, 64)[:, :, :, 1].abs().max()) == 0.0
+    assert float(outs[1].view(B, N, 3, H, 64)[:, :, :, 0].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 def test_attention_forward_head_keep(dtype):
     """Inference-only head skipping: heads marked 0 get an all-zero output slice, the others are untouched."""
     from uvc_amd import ops

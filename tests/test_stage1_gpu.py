@@ -71,7 +71,7 @@ def run_scenario(name, precision, rtol, check_masks=True):
         # bf16 gradient stream that leaves ~1e-3: its absolute floor is the rounding of the stream (9 % against 6 % depending on
         # which kernels produced the last block's stream), not a relative quantity
         gate_atol = np.where(np.array(names)[ok] == "block_skip_gating", 0.0 if precision == "fp32" else 3e-4, 0.0)
-        close(got[ok], ref[ok], 3e-3 if precision == "fp32" else 8e-2, 1e-6 + gate_atol, pre + "grad_abs_sum")
+        close(got[ok], ref[ok], 3e-3 if precision == "fp32" else 4e-2, 1e-6 + gate_atol, pre + "grad_abs_sum")
         psum = np.array([float(pmap[n].data.double().abs().sum()) for n in names])
         # AdamW's first steps move every element by ~lr * g/(|g|+eps): elements with |g| ~ eps amplify
         # 1e-7-level gradient differences, hence 1e-4 (fp32) / 1e-3 (bf16) on the per-tensor checksums

@@ -225,3 +225,25 @@ def test_eval_forward_skipping_pruned_heads_and_units_is_exact(precision):
     assert torch.equal(out_skip, out_heads_dense)
     tol = dict(rtol=1e-5, atol=1e-5) if precision == "fp32" else dict(rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(out_skip, out_dense, **tol)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_backward_skipping_pruned_heads_is_exact(precision):
+    """Stage-2 training step with uvc_vit_io.head_keep_bwd (Stage2Trainer's default): dq / dk / dv of the heads whose 64 attn.proj input columns
+    are masked are written as zeros instead of being computed -- every gradient, the clip norm and the loss equal the step that computes them
+    (their dL/d(attention output) is exactly zero: post_train.py:343-346 masks the weights the dgrad uses)."""
+    name = "stage2_tiny8"
+    res = []
+    for skip in (True, False):
+        r, cfg, tr = build(name, precision, compact=1)
+        assert tr.head_keep is not None and int((tr.head_keep == 0).sum()) > 0 and tr.model.skip_pruned_head_grads
+        tr.model.skip_pruned_head_grads = skip
+        x_all, y_all = SC.make_inputs(r)
+        tr.begin_epoch(r["epoch_of_step"][0])
+        out = tr.step(torch.from_numpy(x_all[0]).cuda(), torch.from_numpy(y_all[0]).cuda(), zero_grad=False)
+        torch.cuda.synchronize()
+        res.append((float(out["loss"]), float(out["gnorm"]), {n: p.grad.detach().clone() for n, p in tr.model.named_parameters() if p.grad is not None}))
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    assert res[0][2].keys() == res[1][2].keys()
+    for n in res[0][2]:
+        assert torch.equal(res[0][2][n], res[1][2][n]), n

@@ -40,7 +40,7 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     # share of the algorithmic bytes that are WRITES, by key prefix: what HBM delivers depends on the mix (hbm_ceiling_gbs below)
     WFRAC = {"ln_fwd": 1 / 3, "qkv": 0.75, "attn_fwd": 0.25, "attn_tok_fwd": 0.0, "attn_tok_bwd": 0.6, "proj+resid+norm2": 0.5, "proj+resid": 0.4,
              "fc1": 8 / 9, "fc2+resid+gate+norm1": 3 / 11, "fc2+resid+gate": 0.2, "teacher mlp_fused+norm1": 0.6, "teacher mlp_fused": 0.5,
-             "dfc2": 4 / 9, "dfc1+ln2_bwd": 1 / 8, "dqkv+ln1_bwd": 1 / 8, "dfc1": 0.2, "dqkv": 0.25, "ln_bwd": 0.2, "dproj": 0.5, "attn_bwd": 0.25,
+             "dfc2": 4 / 9, "dfc1+ln2_bwd": 1 / 8, "dqkv+ln1_bwd": 1 / 8, "dfc1": 0.2, "dqkv": 0.25, "ln_bwd": 0.2, "dproj": 0.5, "attn_bwd": 0.375,
              "dW": 0.15, "clip+adamw": 0.45}
 
     def add(key, rocprof, calls, nbytes, flops, fn, wfrac=None):
@@ -136,7 +136,9 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     do = rn(B, N, D).to(bf)
     dq = torch.empty(B, N, 3 * D, device=dev, dtype=bf)
     dl = torch.empty(B, H, N, device=dev)
-    add("attn_bwd (dq + dkv)", "k_attn_bwd", Lf, 12 * u, afl * 2.5, lambda: ops.attention_bwd(qkv3, o, lse, do, dq, dl, B, N, H, dt))
+    # algorithmic bytes: every operand ONCE for the pair of kernels -- q, k, v, dO, O read (5 u), dq, dk, dv written (3 u); the dq and the dk / dv
+    # kernel each read q, k, v, dO, so the pair MOVES 12 u (PMC: 470 MB against 310 algorithmic at DeiT-Tiny batch 512)
+    add("attn_bwd (dq + dkv)", "k_attn_bwd", Lf, 8 * u, afl * 2.5, lambda: ops.attention_bwd(qkv3, o, lse, do, dq, dl, B, N, H, dt))
     # ---- backward, weight-gradient stream (each entry = the split-M GEMM + its fixed-order reduction)
     ws = torch.empty(max(ops.gemm_tn_workspace_bytes(M, F, D), ops.gemm_tn_workspace_bytes(M, D, F), ops.gemm_tn_workspace_bytes(M, 3 * D, D), ops.gemm_tn_workspace_bytes(M, D, D)) // 4, device=dev)
     C1, C2, C3, C4 = torch.empty(D, F, device=dev), torch.empty(F, D, device=dev), torch.empty(D, D, device=dev), torch.empty(3 * D, D, device=dev)

@@ -364,6 +364,11 @@ __global__ __launch_bounds__(512) void k_attn_bwd_dq(AttnArgs a) {
   const T* ob = reinterpret_cast<const T*>(a.o) + (size_t)b * a.N * ldo + h * HD;
   const T* dob = reinterpret_cast<const T*>(a.dout) + (size_t)b * a.N * ldo + h * HD;
   T* dqb = reinterpret_cast<T*>(a.dqkv) + (size_t)b * a.N * ldq + h * HD;
+  if (a.head_keep && a.head_keep[h] == 0) {                 // pruned head (see uvc_attn_args.head_keep): dO is exactly zero, so is dq
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < a.N * 16; i += blockDim.x) Store4<T>::st(dqb + (size_t)(i >> 4) * ldq + (i & 15) * 4, z);
+    return;
+  }
   stage_rows2<T>(sK, kb, ldq, sV, vb, ldq, a.N, NP);
   __syncthreads();
   const int nqt = (a.N + 15) / 16;
@@ -436,6 +441,14 @@ __global__ __launch_bounds__(512) void k_attn_bwd_dkv(AttnArgs a) {
   const T* dob = reinterpret_cast<const T*>(a.dout) + (size_t)b * a.N * ldo + h * HD;
   T* dkb = reinterpret_cast<T*>(a.dqkv) + (size_t)b * a.N * ldq + (a.H + h) * HD;
   T* dvb = dkb + a.H * HD;
+  if (a.head_keep && a.head_keep[h] == 0) {                 // pruned head: dk = dv = 0 exactly
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < a.N * 16; i += blockDim.x) {
+      Store4<T>::st(dkb + (size_t)(i >> 4) * ldq + (i & 15) * 4, z);
+      Store4<T>::st(dvb + (size_t)(i >> 4) * ldq + (i & 15) * 4, z);
+    }
+    return;
+  }
   stage_rows2<T>(sQ, qb, ldq, sDO, dob, ldo, a.N, NP);
   for (int i = threadIdx.x; i < NP; i += blockDim.x) {      // lse pre-multiplied by log2(e); +inf on padded queries -> p = 0
     sLse[i] = i < a.N ? a.lse[((size_t)b * a.H + h) * a.N + i] * 1.44269504088896340736f : INFINITY;

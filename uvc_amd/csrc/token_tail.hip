@@ -156,6 +156,16 @@ __global__ __launch_bounds__(NTH) void k_attn_tok_bwd(TokArgs a) {
   const T* qkv = reinterpret_cast<const T*>(a.qkv);
   const T* dout = reinterpret_cast<const T*>(a.dout);
   T* dqkv = reinterpret_cast<T*>(a.dqkv);
+  if (a.head_keep && a.head_keep[h] == 0) {                           // pruned head (training, masked attn.proj): its dout slice is exactly zero
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int i = tid; i < a.N * 24; i += NTH) {
+      const int n = i / 24, which = (i >> 3) % 3, c = i & 7;
+      Row<T>::store8(dqkv + (((size_t)b * a.N + n) * 3 + which) * Dm + h * HD + c * 8, v);
+    }
+    return;
+  }
   stage_kv<T>(a, b, h, sK, sV);
   for (int i = tid; i < a.ntok * HD; i += NTH) {
     const int t = i / HD, d = i % HD;
@@ -227,7 +237,7 @@ int tok_check(const uvc_attn_tok_args* p, bool bwd) {
 
 template <typename T> int tok_launch(const uvc_attn_tok_args* p, bool bwd, hipStream_t st) {
   TokArgs a;
-  a.qkv = p->qkv; a.o = p->o; a.dout = p->dout; a.dqkv = p->dqkv; a.head_keep = bwd ? nullptr : p->head_keep;
+  a.qkv = p->qkv; a.o = p->o; a.dout = p->dout; a.dqkv = p->dqkv; a.head_keep = p->head_keep;
   a.B = p->B; a.N = p->N; a.H = p->H; a.ntok = p->ntok; a.scale = p->scale;
   const size_t sh = tok_lds<T>(bwd);
   if (bwd) UVC_MAX_LDS(sh, k_attn_tok_bwd<T>);

@@ -269,7 +269,9 @@ int dgrad_ln_bwd(Ctx& c, const void* A, const void* Wt, int K, const void* x, in
 int attn(const Ctx& c, const BlockBufs& b, bool bwd, int layer = -1) {
   uvc_attn_args a;
   memset(&a, 0, sizeof(a));
-  if (!bwd && layer >= 0 && !c.io->training && c.io->head_keep) a.head_keep = c.io->head_keep + (size_t)layer * c.d.H;
+  // no-grad forwards skip pruned heads; a BACKWARD skips them when the caller says their attn.proj input columns are masked in the
+  // weights (uvc_vit_io.head_keep_bwd: Stage-2): dO of such a head is exactly zero, so dq / dk / dv are written as zeros
+  if (layer >= 0 && c.io->head_keep && (bwd ? c.io->head_keep_bwd != 0 : !c.io->training)) a.head_keep = c.io->head_keep + (size_t)layer * c.d.H;
   a.qkv = b.qkv; a.o = b.o; a.lse = b.lse; a.dout = c.w.dH; a.dqkv = c.w.dqkv; a.delta = c.w.delta;
   a.B = c.d.B; a.N = c.d.N; a.H = c.d.H; a.head_dim = 64; a.dtype = c.d.dtype; a.scale = 0.125f;
   return bwd ? uvc_attention_bwd(&a, c.st) : uvc_attention_fwd(&a, c.st);
@@ -278,7 +280,7 @@ int attn(const Ctx& c, const BlockBufs& b, bool bwd, int layer = -1) {
 int attn_tok(const Ctx& c, const BlockBufs& b, bool bwd, int layer = -1) {
   uvc_attn_tok_args a;
   memset(&a, 0, sizeof(a));
-  if (!bwd && layer >= 0 && !c.io->training && c.io->head_keep) a.head_keep = c.io->head_keep + (size_t)layer * c.d.H;
+  if (layer >= 0 && c.io->head_keep && (bwd ? c.io->head_keep_bwd != 0 : !c.io->training)) a.head_keep = c.io->head_keep + (size_t)layer * c.d.H;
   a.qkv = b.qkv; a.o = c.w.tail.oc; a.dout = c.w.tail.dOc; a.dqkv = c.w.dqkv;
   a.B = c.d.B; a.N = c.d.N; a.H = c.d.H; a.head_dim = 64; a.ntok = c.d.ntok; a.dtype = c.d.dtype; a.scale = 0.125f;
   return bwd ? uvc_attention_tok_bwd(&a, c.st) : uvc_attention_tok_fwd(&a, c.st);
@@ -644,14 +646,14 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     TRY(tn(c, gB, gf, tail ? t.oc : b.o, G + q[4], G + q[5], rows, d.D, d.D, nullptr, 0, 0, bGB));
     TRY(guard_overwrite(c, BUF_DQKV));
     if (tail) {
-      TRY(attn_tok(c, b, true));            // writes all of dqkv: dq is zero off the token rows, dk / dv are dense
+      TRY(attn_tok(c, b, true, l));         // writes all of dqkv: dq is zero off the token rows, dk / dv are dense
       // the full-row stream of dL/dx1 that the LayerNorm1 backward adds: zero but for the token rows
       TRY(guard_overwrite(c, BUF_GB));
       const hipError_t he = hipMemsetAsync(w.gB, 0, (size_t)d.M * d.D * d.tsz, hs);
       if (he != hipSuccess) return uvc_set_error(he, __FILE__, __LINE__);
       TRY(scatter_tok(c, t.gBc, w.gB, d.tsz));
     } else
-    TRY(attn(c, b, true));
+    TRY(attn(c, b, true, l));
     const bool fuse1 = lnb_fused_ok(c, 3 * d.D);
     if (!fuse1) TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));
     TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], d.qkv_bias ? G + q[3] : nullptr, d.M, 3 * d.D, d.D, nullptr, 0, 0, BUF_DQKV));

@@ -55,7 +55,7 @@ class uvc_vit_io(C.Structure):
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
                 ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
                 ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("fused_train_mlp", C.c_int32), ("patches_in", C.c_void_p),
-                ("fuse_next_ln", C.c_int32), ("force_generic", C.c_int32)]
+                ("fuse_next_ln", C.c_int32), ("force_generic", C.c_int32), ("head_keep_bwd", C.c_int32)]
 
 
 class uvc_mlp_compact(C.Structure):
@@ -537,7 +537,11 @@ class DistilledVisionTransformer(nn.Module):
         io.gate_mode, io.gate_eps = self._gate_mode(), float(self.eps)
         io.accumulate = 1.0 if self.grad_accumulate else 0.0
         io.mlp_compact = C.addressof(self._mlp_compact) if self._mlp_compact is not None else None
-        io.head_keep = L.ptr(self._head_keep) if (self._head_keep is not None and not training) else None
+        # eval forwards skip pruned heads; a training pass hands the table over for the BACKWARD only (uvc_vit_io.head_keep_bwd), and only when
+        # the trainer vouches that the masks are applied to the weights every step (Stage2Trainer sets skip_pruned_head_grads)
+        skip_bwd = bool(training and getattr(self, "skip_pruned_head_grads", False))
+        io.head_keep = L.ptr(self._head_keep) if (self._head_keep is not None and (not training or skip_bwd)) else None
+        io.head_keep_bwd = int(skip_bwd and self._head_keep is not None)
         io.full_tail = int(getattr(self, "full_tail", _FULL_TAIL_DEFAULT))
         io.fused_train_mlp = int(getattr(self, "fused_train_mlp", _FUSED_TRAIN_MLP_DEFAULT))
         io.fuse_next_ln = int(getattr(self, "fuse_next_ln", _FUSE_NEXT_LN_DEFAULT))

@@ -103,8 +103,11 @@ def attention_fwd(qkv, o, lse, B, N, H, dtype, head_keep=None):
     L.check(L.lib().uvc_attention_fwd(C.byref(a), L.cur_stream()), "uvc_attention_fwd")
 
 
-def attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype):
+def attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype, head_keep=None):
     a = _attn_args(qkv, o, lse, B, N, H, dtype, dout, dqkv, delta)
+    if head_keep is not None:
+        _chk(head_keep)
+        a.head_keep = L.ptr(head_keep)
     L.check(L.lib().uvc_attention_bwd(C.byref(a), L.cur_stream()), "uvc_attention_bwd")
 
 

@@ -95,7 +95,11 @@ class Stage2Trainer:
         self.total_param = count_mask(model)
         # structured sparsity: MLP hidden units whose fc1 row and fc2 column are masked out are skipped, not multiplied
         self.mlp_widths = model.set_mlp_compaction(multiple=getattr(args, "compact_multiple", 256)) if getattr(args, "compact_mlp", 1) else None
-        self.head_keep = model.set_head_skipping() if getattr(args, "compact_mlp", 1) else None     # eval forwards only
+        self.head_keep = model.set_head_skipping() if getattr(args, "compact_mlp", 1) else None     # eval forwards skip pruned heads ...
+        # ... and training BACKWARDS skip their dq / dk / dv: step() multiplies the weights by the masks before every forward (:343-346), so
+        # dL/d(attention output) of a head whose 64 attn.proj input columns are masked is exactly zero (the forward keeps the head: the
+        # reference's clip norm sees dW_proj of the masked columns, which needs its output)
+        model.skip_pruned_head_grads = self.head_keep is not None
         # post_training(): DDP, scaled learning rate, timm optimiser + schedule (:289-301)
         self.ddp = DistributedDataParallel(model, message_size=250000000, gradient_predivide_factor=1.0) if distributed else None
         args.train_batch_size = args.train_batch_size // args.gradient_accumulation_steps

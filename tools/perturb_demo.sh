@@ -1,5 +1,5 @@
 #!/bin/bash
-# Shows once that tests/test_streaming_batch_gpu.py goes red when a streaming kernel is wrong.
+# Shows once that tests/test_streaming_batch_gpu.py (r3) and tests/test_wide_models_gpu.py (r4) go red when a production kernel is wrong.
 #   here (build container):  tools/perturb_demo.sh build     -> tools/perturb/libuvc_hip_{ws,lnbwd}.so (git-ignored; they travel with gpurun)
 #   on the GPU box:          tools/perturb_demo.sh run       -> gpurun_out/perturb_demo.txt
 # The perturbed libraries are built from sed-edited COPIES of gemm.hip under /tmp: the product source carries no test switch.
@@ -13,7 +13,20 @@ if [ "${1:-}" = build ]; then
   sed 's|\*reinterpret_cast<f32x4\*>(stg + li \* EPW + j \* 16 + gq \* 4) = c;|*reinterpret_cast<f32x4*>(stg + li * EPW + j * 16 + gq * 4) = c * 1.02f;|' "$R/uvc_amd/csrc/gemm.hip" > /tmp/perturb/gemm_ws.hip
   # 2. k_gemm_wsn_lnbwd_dma: dx of the fused dgrad + LayerNorm backward scaled by 1.02
   sed 's|o\[e\] = rstd \* (c0\[e\] - c1 - xh \* c2);   |o[e] = 1.02f * rstd * (c0[e] - c1 - xh * c2);   |' "$R/uvc_amd/csrc/gemm.hip" > /tmp/perturb/gemm_lnbwd.hip
-  for v in ws lnbwd; do
+  # 3. (r4) the wide-tile NT kernels of DeiT-Small / Base (k_gemm_nt256 and k_gemm_nt8p share NT_EPILOGUE_TILE): staged accumulator x 1.02
+  sed 's|(stg_at<true>(stg, lane \& 15, j \* 4 + (lane >> 4))) = acc\[h\]\[j\];  |(stg_at<true>(stg, lane \& 15, j * 4 + (lane >> 4))) = acc[h][j] * 1.02f;|' "$R/uvc_amd/csrc/gemm.hip" > /tmp/perturb/gemm_wide.hip
+  # 4. (r4) k_gemm_row384_lnbwd (D = 384 dgrad + LayerNorm backward on a row tile): dx x 1.02
+  sed 's|o\[e\] = R.rstd \* (gy\[i\]\[e\] - c1 - ((xv\[i\]\[e\] - R.mean) \* R.rstd) \* c2);|o[e] = 1.02f * R.rstd * (gy[i][e] - c1 - ((xv[i][e] - R.mean) * R.rstd) * c2);|' "$R/uvc_amd/csrc/gemm.hip" > /tmp/perturb/gemm_row384.hip
+  # 5. (r4) k_gemm_tn8p (256 x 256 weight-gradient tiles of DeiT-Base): partial tile x 1.02
+  python3 - "$R/uvc_amd/csrc/gemm.hip" /tmp/perturb/gemm_tn8p.hip <<'PY'
+import sys
+s = open(sys.argv[1]).read()
+i = s.index("void k_gemm_tn8p(TnArgs g)")
+j = s.index("*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];", i)
+s = s[:j] + "*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j] * 1.02f;" + s[j + len("*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];"):]
+open(sys.argv[2], "w").write(s)
+PY
+  for v in ws lnbwd wide row384 tn8p; do
     cmp -s /tmp/perturb/gemm_$v.hip "$R/uvc_amd/csrc/gemm.hip" && { echo "perturbation $v did not apply"; exit 1; }
     sed -i 's|#include "common.h"|#include "'"$R"'/uvc_amd/csrc/common.h"|; s|#include "../../include/uvc_kernels.h"|#include "'"$R"'/include/uvc_kernels.h"|' /tmp/perturb/gemm_$v.hip
     /opt/rocm/bin/hipcc $FLAGS -c /tmp/perturb/gemm_$v.hip -o /tmp/perturb/gemm_$v.o || exit 1
@@ -33,8 +46,15 @@ cp "$R/uvc_amd/libuvc_hip.so" /tmp/libuvc_hip_good.so
     echo; echo "## perturbed: $v (k_gemm_ws output x 1.02 | k_gemm_wsn_lnbwd_dma dx x 1.02) -- expected: FAILED"
     (cd "$R" && python -m pytest tests/test_streaming_batch_gpu.py -q -x -k "matches_oracle_at_streaming_batch and not fp32" 2>&1 | grep -E "AssertionError|passed|failed|assert " | cut -c1-600 | head -8)
   done
+  echo; echo "# tests/test_wide_models_gpu.py::test_wide_model_step_matches_oracle_on_production_kernels (DeiT-Small batch 24, DeiT-Base batch 12 with the wide tiles forced)"
+  for v in wide row384 tn8p; do
+    cp "$R/tools/perturb/libuvc_hip_$v.so" "$R/uvc_amd/libuvc_hip.so"
+    echo; echo "## perturbed: $v (wide NT tiles x 1.02 | k_gemm_row384_lnbwd dx x 1.02 | k_gemm_tn8p partial tiles x 1.02) -- expected: FAILED"
+    (cd "$R" && python -m pytest tests/test_wide_models_gpu.py -q -k "matches_oracle_on_production_kernels" 2>&1 | grep -E "AssertionError|passed|failed|assert " | cut -c1-600 | head -8)
+  done
   cp /tmp/libuvc_hip_good.so "$R/uvc_amd/libuvc_hip.so"
   echo; echo "## unperturbed library -- expected: passed"
   (cd "$R" && python -m pytest tests/test_streaming_batch_gpu.py -q -x -k "matches_oracle_at_streaming_batch and not fp32" 2>&1 | grep -E "passed|failed")
+  (cd "$R" && python -m pytest tests/test_wide_models_gpu.py -q -k "matches_oracle_on_production_kernels" 2>&1 | grep -E "passed|failed")
 } > "$OUT" 2>&1
 cat "$OUT"

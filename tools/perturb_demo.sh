@@ -17,13 +17,13 @@ if [ "${1:-}" = build ]; then
   sed 's|(stg_at<true>(stg, lane \& 15, j \* 4 + (lane >> 4))) = acc\[h\]\[j\];  |(stg_at<true>(stg, lane \& 15, j * 4 + (lane >> 4))) = acc[h][j] * 1.02f;|' "$R/uvc_amd/csrc/gemm.hip" > /tmp/perturb/gemm_wide.hip
   # 4. (r4) k_gemm_row384_lnbwd (D = 384 dgrad + LayerNorm backward on a row tile): dx x 1.02
   sed 's|o\[e\] = R.rstd \* (gy\[i\]\[e\] - c1 - ((xv\[i\]\[e\] - R.mean) \* R.rstd) \* c2);|o[e] = 1.02f * R.rstd * (gy[i][e] - c1 - ((xv[i][e] - R.mean) * R.rstd) * c2);|' "$R/uvc_amd/csrc/gemm.hip" > /tmp/perturb/gemm_row384.hip
-  # 5. (r4) k_gemm_tn8p (256 x 256 weight-gradient tiles of DeiT-Base): partial tile x 1.02
+  # 5. (r4) k_gemm_tn8p (256 x 256 weight-gradient tiles of DeiT-Base): partial tile x 1.03
   python3 - "$R/uvc_amd/csrc/gemm.hip" /tmp/perturb/gemm_tn8p.hip <<'PY'
 import sys
 s = open(sys.argv[1]).read()
 i = s.index("void k_gemm_tn8p(TnArgs g)")
 j = s.index("*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];", i)
-s = s[:j] + "*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j] * 1.02f;" + s[j + len("*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];"):]
+s = s[:j] + "*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j] * 1.03f;" + s[j + len("*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];"):]
 open(sys.argv[2], "w").write(s)
 PY
   for v in ws lnbwd wide row384 tn8p; do
@@ -49,7 +49,7 @@ cp "$R/uvc_amd/libuvc_hip.so" /tmp/libuvc_hip_good.so
   echo; echo "# tests/test_wide_models_gpu.py::test_wide_model_step_matches_oracle_on_production_kernels (DeiT-Small batch 24, DeiT-Base batch 12 with the wide tiles forced)"
   for v in wide row384 tn8p; do
     cp "$R/tools/perturb/libuvc_hip_$v.so" "$R/uvc_amd/libuvc_hip.so"
-    echo; echo "## perturbed: $v (wide NT tiles x 1.02 | k_gemm_row384_lnbwd dx x 1.02 | k_gemm_tn8p partial tiles x 1.02) -- expected: FAILED"
+    echo; echo "## perturbed: $v (wide NT tiles x 1.02 | k_gemm_row384_lnbwd dx x 1.02 | k_gemm_tn8p partial tiles x 1.03 (a leaf kernel: below the 2.5 % per-tensor bound a scaling is inside the bf16 noise the bound admits)) -- expected: FAILED"
     (cd "$R" && python -m pytest tests/test_wide_models_gpu.py -q -k "matches_oracle_on_production_kernels" 2>&1 | grep -E "AssertionError|passed|failed|assert " | cut -c1-600 | head -8)
   done
   cp /tmp/libuvc_hip_good.so "$R/uvc_amd/libuvc_hip.so"

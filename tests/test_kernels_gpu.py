@@ -153,7 +153,8 @@ def test_gemm_nt_ksplit_streaming_kernel_matches_generic(K, M):
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("M,N1,N2", [(1576, 576, 192), (403, 192, 768), (3001, 768, 192), (64, 1000, 192), (5000, 128, 128), (40, 8, 16), (4133, 192, 192),
-                                     (2500, 3072, 768), (1210, 768, 3072), (999, 2304, 768), (25216, 768, 768), (70, 1024, 768)])
+                                     (2500, 3072, 768), (1210, 768, 3072), (999, 2304, 768), (25216, 768, 768), (70, 1024, 768),
+                                     (3000, 384, 1536), (2999, 1536, 384), (5001, 384, 1152), (3000, 1152, 384), (2000, 384, 384)])
                                      # the last five: 256 x 256 tiles (DeiT-Base; r4: k_gemm_tn8p -- splits that are not whole 64-row k-steps, a split of one
                                      # k-step, the full batch-128 row count with 28 splits of 9 tiles)
 def test_gemm_tn(dtype, M, N1, N2):
@@ -180,6 +181,14 @@ def test_gemm_tn(dtype, M, N1, N2):
     ops.gemm_tn(to_t(A, dtype), to_t(B, dtype), C1, ws, dtype=dtype)
     ops.gemm_tn(to_t(A, dtype), to_t(B, dtype), C2, ws, dtype=dtype)
     assert torch.equal(C1, C2)
+    if dtype == BF16:
+        # variant 1: the two-group schedule (k_gemm_tn8p) on the 192-wide tiles too: same k order per accumulator as the ring kernel -> same bits
+        C3, cs0, cs1 = torch.empty(N1, N2, device=dev()), torch.zeros(N1, device=dev()), torch.zeros(N1, device=dev())
+        ops.gemm_tn(to_t(A, dtype), to_t(B, dtype), C1, ws, dtype=dtype, colsum_out=cs0, variant=2)
+        ops.gemm_tn(to_t(A, dtype), to_t(B, dtype), C3, ws, dtype=dtype, colsum_out=cs1, variant=1)
+        assert torch.equal(C1, C3) and torch.equal(cs0, cs1)
+        ops.gemm_tn(to_t(A, dtype), to_t(B, dtype), C3, ws, dtype=dtype, colsum_out=cs1, variant=0)
+        assert torch.equal(C1, C3) and torch.equal(cs0, cs1)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])

@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--batch", type=int, default=0)
     a = ap.parse_args()
-    D, F, B = {"base": (768, 3072, 128), "small": (384, 1536, 256), "t2t": (384, 1152, 128)}[a.model]
+    D, F, B = {"base": (768, 3072, 128), "small": (384, 1536, 256), "t2t": (384, 1152, 128), "tiny": (192, 768, 512)}[a.model]
     B = a.batch or B
     M = B * 197
     dev, bf = "cuda", torch.bfloat16
@@ -65,7 +65,8 @@ def main():
         Cw = torch.empty(n1, n2, device=dev)
         ws = torch.empty(ops.gemm_tn_workspace_bytes(M, n1, n2) // 4, device=dev)
         t = timeit(lambda: ops.gemm_tn(Ag, Bg, Cw, ws, dtype=ops.UVC_BF16), a.iters)
-        print(f"{name:22s} {M:7d} {n1:6d} {n2:6d} {t:12.1f} {2.0 * M * n1 * n2 / t / 1e6:8.1f}")
+        t1 = timeit(lambda: ops.gemm_tn(Ag, Bg, Cw, ws, dtype=ops.UVC_BF16, variant=1), a.iters)
+        print(f"{name:22s} {M:7d} {n1:6d} {n2:6d} {t:12.1f} {2.0 * M * n1 * n2 / t / 1e6:8.1f}   variant 1: {t1:8.1f} us {2.0 * M * n1 * n2 / t1 / 1e6:8.1f}")
 
 
 if __name__ == "__main__":

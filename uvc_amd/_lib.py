@@ -51,7 +51,7 @@ class uvc_gemm_tn_args(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_int64), ("alpha_ptr", C.c_void_p), ("colsum_out", C.c_void_p), ("alpha", C.c_float),
                 ("beta", C.c_float)] + \
-               [(n, C.c_int32) for n in ("M", "N1", "N2", "lda", "ldb", "ldc", "dtype", "a_is_f32")]
+               [(n, C.c_int32) for n in ("M", "N1", "N2", "lda", "ldb", "ldc", "dtype", "a_is_f32", "variant")]
 
 
 class uvc_attn_args(C.Structure):

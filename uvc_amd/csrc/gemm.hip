@@ -3007,8 +3007,12 @@ __device__ __forceinline__ bf16x8 t8_frag(const T8Frag& f) {
   return __builtin_bit_cast(bf16x8, u32x4{f.lo[0], f.lo[1], f.hi[0], f.hi[1]});
 }
 
+// RI / RJ: 16-column blocks of N1 / N2 per wave (2 x 4 waves): tiles 256 x 256 (8, 4), 192 x 256 (6, 4), 256 x 192 (8, 3), 192 x 192 (6, 3).  The slot
+// images keep their 64 x 128 shape; the columns a narrower tile does not have are requested out of range (zeros, no traffic).
+template <int RI, int RJ>
 __global__ __launch_bounds__(512, 2) void k_gemm_tn8p(TnArgs g) {
   typedef Mma<bf16_t> MM;
+  constexpr int R0 = (RI + 1) / 2, R1 = RI - R0, J0 = (RJ + 1) / 2, J1 = RJ - J0, B1 = 32 * RI, B2 = 64 * RJ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3024,7 +3028,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn8p(TnArgs g) {
       bz = L / tiles; bx = t % gridDim.x; by = t / gridDim.x;
     }
   }
-  const int n10 = bx * 256, n20 = by * 256;
+  const int n10 = bx * B1, n20 = by * B2;
   const int mbeg = bz * g.rows_per_split;
   const int mend = min(g.M, mbeg + g.rows_per_split);
   const int nk = (mend - mbeg + 63) / 64;
@@ -3035,9 +3039,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn8p(TnArgs g) {
   unsigned laneA0, laneA1, laneB0, laneB1;
   {
     const int r = 4 * w + (lane >> 4), cg = (lane & 15) ^ (2 * (r & 7));        // global chunk this lane fetches
-    const int colA = (cg >> 3) * 128 + (cg & 7) * 8, colB = (cg >> 2) * 64 + (cg & 3) * 8;
-    laneA0 = (unsigned)((r * g.lda + n10 + colA) * 2); laneA1 = laneA0 + 128;
-    laneB0 = (unsigned)((r * g.ldb + n20 + colB) * 2); laneB1 = laneB0 + 64;
+    const int ca = cg & 7, cb = cg & 3;                                          // chunk inside a row group's / column group's share of the slot
+    const int colA = (cg >> 3) * (16 * RI) + ca * 8, colB = (cg >> 2) * (16 * RJ) + cb * 8;
+    constexpr unsigned OOB = 0x80000000u;
+    laneA0 = ca < 2 * R0 ? (unsigned)((r * g.lda + n10 + colA) * 2) : OOB;
+    laneA1 = ca < 2 * R1 ? (unsigned)((r * g.lda + n10 + colA + 16 * R0) * 2) : OOB;
+    laneB0 = cb < 2 * J0 ? (unsigned)((r * g.ldb + n20 + colB) * 2) : OOB;
+    laneB1 = cb < 2 * J1 ? (unsigned)((r * g.ldb + n20 + colB + 16 * J0) * 2) : OOB;
   }
   const unsigned hiA = (unsigned)(32 * g.lda * 2), hiB = (unsigned)(32 * g.ldb * 2);
   // request q (0..7) of the k-step whose first row is m: slot q >> 1 (A'0, B'0, B'1, A'1), instruction q & 1
@@ -3062,24 +3070,35 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn8p(TnArgs g) {
     for (int j = 0; j < 2; ++j) fb[j] = s0 + (unsigned)(R * 256 + ((((w2 * 2 + j) ^ sw) * 2 + b) * 16) + half * 8);
   }
   T8Frag FA[4][2], FB0[2][2], FB1[2][2];
-  f32x4 acc[8][4], cs[2];
+  f32x4 acc[RI][RJ], cs[2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < RJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   cs[0] = f32x4{0.f, 0.f, 0.f, 0.f}; cs[1] = cs[0];
   const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   const typename MM::Frag ones = __builtin_bit_cast(typename MM::Frag, ones_u);
 
 #define T8_RD(F, ADDR, SLOT, KS) { F.lo = ds_tr16_off<(SLOT) * T8_SLOT + (KS) * 8192>(ADDR); F.hi = ds_tr16_off<(SLOT) * T8_SLOT + (KS) * 8192 + 4096>(ADDR); }
-#define T8_RD_B(DST, SLOT, BO)                                                                                        \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) { T8_RD(DST[j][0], fb[j] + (BO), SLOT, 0) T8_RD(DST[j][1], fb[j] + (BO), SLOT, 1) }
+#define T8_RD_B(DST, SLOT, BO, NJ)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < (NJ); ++j) { T8_RD(DST[j][0], fb[j] + (BO), SLOT, 0) T8_RD(DST[j][1], fb[j] + (BO), SLOT, 1) }
 #define T8_RD_A(I, SLOT, BO) { T8_RD(FA[I][0], fa[I] + (BO), SLOT, 0) T8_RD(FA[I][1], fa[I] + (BO), SLOT, 1) }
-#define T8_MMA4(I, AI, FB, JO)                                                                                        \
+#define T8_MMA4(I, AI, FB, JO, NJ)                                                                                    \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                     \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
+  _Pragma("unroll") for (int j = 0; j < (NJ); ++j)                                                                     \
     acc[AI][(JO) + j] = MM::mma(t8_frag(FB[j][ks]), t8_frag(FA[I][ks]), acc[AI][(JO) + j]);
 #define T8_CS(U, I) { cs[U] = MM::mma(ones, t8_frag(FA[I][0]), cs[U]); cs[U] = MM::mma(ones, t8_frag(FA[I][1]), cs[U]); }
+  // column sums: wave w2 of a row group takes the column blocks 2 w2, 2 w2 + 1 of its RI; HALF = 0: blocks in A0 (phase 0), 1: in A1 (phase 2)
+#define T8_CS_PHASE(HALF)                                                                                             \
+  if (do_cs) {                                                                                                         \
+    _Pragma("unroll") for (int W = 0; W < 4; ++W)                                                                      \
+      if (w2 == W) {                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                \
+          const int gi = 2 * W + u;                                                                                    \
+          if (gi < RI && (gi >= R0) == ((HALF) == 1)) { if (u == 0) T8_CS(0, gi - (HALF) * R0) else T8_CS(1, gi - (HALF) * R0) }  \
+        }                                                                                                              \
+      }                                                                                                                \
+  }
 #define T8_REQ(Q0, M, SBUF, WAIT)                                                                                     \
   issue(Q0, M, SBUF); issue(Q0 + 1, M, SBUF);                                                                          \
   if (WAIT) wait_vm<6>();                                                                                              \
@@ -3100,9 +3119,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn8p(TnArgs g) {
   for (int q = 0; q < 4; ++q) issue(q, mbeg + 64, 1);
   wait_vm<6>();
   __builtin_amdgcn_s_barrier();
-  T8_RD_B(FB0, 1, 0u)
+  T8_RD_B(FB0, 1, 0u, J0)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) T8_RD_A(i, 0, 0u)
+  for (int i = 0; i < R0; ++i) T8_RD_A(i, 0, 0u)
   __builtin_amdgcn_sched_barrier(0);
   if (w1 == 1) __builtin_amdgcn_s_barrier();      // group 1 runs half a phase behind from here on
   for (int kt = 0; kt < nk; ++kt) {
@@ -3111,44 +3130,40 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn8p(TnArgs g) {
     const int m1 = mbeg + (kt + 1) * 64, m2 = m1 + 64;   // (past the split's end: out of the descriptors' range, zeros nobody multiplies)
     // ---- phase 0: (A0, B0); requests B'1 of k-step kt + 1; reads B1 of this k-step
     T8_REQ(4, m1, buf ^ 1, true)
-    T8_RD_B(FB1, 2, bo)
+    T8_RD_B(FB1, 2, bo, J1)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) T8_MMA4(i, i, FB0, 0)
-    if (do_cs) {
-      if (w2 == 0) { T8_CS(0, 0) T8_CS(1, 1) }
-      else if (w2 == 1) { T8_CS(0, 2) T8_CS(1, 3) }
-    }
+    for (int i = 0; i < R0; ++i) T8_MMA4(i, i, FB0, 0, J0)
+    T8_CS_PHASE(0)
     T8_END
     // ---- phase 1: (A0, B1); requests A'1 of kt + 1; reads A1 behind the MFMAs that free A0's registers
     T8_REQ(6, m1, buf ^ 1, false)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      T8_MMA4(i, i, FB1, 2)
+    for (int i = 0; i < R0; ++i) {
+      T8_MMA4(i, i, FB1, J0, J1)
       __builtin_amdgcn_sched_barrier(0);
-      T8_RD_A(i, 3, bo)
+      if (i < R1) T8_RD_A(i, 3, bo)
       __builtin_amdgcn_sched_barrier(0);
     }
     T8_END
     // ---- phase 2: (A1, B1); requests A'0 of kt + 2
     T8_REQ(0, m2, buf, true)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) T8_MMA4(i, 4 + i, FB1, 2)
-    if (do_cs) {
-      if (w2 == 2) { T8_CS(0, 0) T8_CS(1, 1) }
-      else if (w2 == 3) { T8_CS(0, 2) T8_CS(1, 3) }
-    }
+    for (int i = 0; i < R1; ++i) T8_MMA4(i, R0 + i, FB1, J0, J1)
+    T8_CS_PHASE(1)
     T8_END
     // ---- phase 3: (A1, B0); requests B'0 of kt + 2; reads A0 and B0 of k-step kt + 1 (the other buffer)
     T8_REQ(2, m2, buf, true)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      T8_MMA4(i, 4 + i, FB0, 0)
+    for (int i = R1; i < R0; ++i) T8_RD_A(i, 0, bon)            // (registers phase 3 does not use)
+#pragma unroll
+    for (int i = 0; i < R1; ++i) {
+      T8_MMA4(i, R0 + i, FB0, 0, J0)
       __builtin_amdgcn_sched_barrier(0);
       T8_RD_A(i, 0, bon)
       __builtin_amdgcn_sched_barrier(0);
     }
-    T8_RD_B(FB0, 1, bon)
+    T8_RD_B(FB0, 1, bon, J0)
     T8_END
   }
 #undef T8_RD
@@ -3156,22 +3171,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn8p(TnArgs g) {
 #undef T8_RD_A
 #undef T8_MMA4
 #undef T8_CS
+#undef T8_CS_PHASE
 #undef T8_REQ
 #undef T8_END
   if (w1 == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
   wait_vm<0>();
   wait_lgkm<0>();
   if (do_cs && (lane >> 4) == 0) {                // every row of cs[u] holds the column sums of n1 = .. + (lane & 15)
-    float* bp = g.bpart + (size_t)bz * g.N1 + n10 + w1 * 128 + (w2 >> 1) * 64 + (w2 & 1) * 32 + (lane & 15);
-    bp[0] = cs[0][0]; bp[16] = cs[1][0];
+    float* bp = g.bpart + (size_t)bz * g.N1 + n10 + w1 * (16 * RI) + w2 * 32 + (lane & 15);       // column blocks 2 w2, 2 w2 + 1
+    if (2 * w2 < RI) bp[0] = cs[0][0];
+    if (2 * w2 + 1 < RI) bp[16] = cs[1][0];
   }
   float* P = g.part + (size_t)bz * g.N1 * g.N2;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int n1 = n10 + w1 * 128 + i * 16 + (lane & 15);
+  for (int i = 0; i < RI; ++i) {
+    const int n1 = n10 + w1 * (16 * RI) + i * 16 + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n2 = n20 + w2 * 64 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < RJ; ++j) {
+      const int n2 = n20 + w2 * (16 * RJ) + j * 16 + (lane >> 4) * 4;
       *reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];
     }
   }
@@ -3293,7 +3310,13 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
       else if (cfg == 1) TN_DMA_ONE(192, 256, 2, 4)
       else if (cfg == 2) TN_DMA_ONE(256, 192, 4, 2)
       else if (cfg == 4) TN_DMA_ONE(96, 192, 2, 4)
-      else if (cfg == 5) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p); k_gemm_tn8p<<<grid, 512, T8_LDS, st>>>(a); }
+      else if (cfg == 5) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<8, 4>); k_gemm_tn8p<8, 4><<<grid, 512, T8_LDS, st>>>(a); }
+      else if (p->variant == 1 && cfg == 1) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<6, 4>); k_gemm_tn8p<6, 4><<<grid, 512, T8_LDS, st>>>(a); }
+      else if (p->variant == 1 && cfg == 2) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<8, 3>); k_gemm_tn8p<8, 3><<<grid, 512, T8_LDS, st>>>(a); }
+      // 192 x 192 tiles (dW_qkv of DeiT-Tiny / Small, every block weight of T2T-ViT-14): the two-group schedule by default -- 45.9 -> 40.9 us at
+      // 100 864 x 576 x 192, 67.6 -> 55.6 at 50 432 x 1152 x 384, 44 -> 37 on T2T's three shapes; bit-identical partial tiles (variant 2: the ring kernel).
+      // The 192 x 256 / 256 x 192 tiles measured equal on both kernels and stay on the ring kernel (variant 1 moves them).
+      else if (p->variant != 2 && cfg == 3) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<6, 3>); k_gemm_tn8p<6, 3><<<grid, 512, T8_LDS, st>>>(a); }
       else TN_DMA_ONE(192, 192, 2, 4)
 #undef TN_DMA_ONE
 #undef TN_BIG

@@ -69,7 +69,7 @@ def gemm_tn_workspace_bytes(M, N1, N2) -> int:
 
 
 def gemm_tn(A, B, C_, workspace, *, dtype, alpha=1.0, alpha_ptr=None, beta=0.0, M=None, N1=None, N2=None, lda=None,
-            ldb=None, colsum_out=None):
+            ldb=None, colsum_out=None, variant=0):
     """C[N1,N2] = beta*C + alpha * A[M,N1]^T . B[M,N2]  (+ optional colsum_out[N1] = beta*old + alpha*colsum(A))."""
     _chk(A, B, C_, workspace, alpha_ptr, colsum_out)
     a = L.uvc_gemm_tn_args()
@@ -83,6 +83,7 @@ def gemm_tn(A, B, C_, workspace, *, dtype, alpha=1.0, alpha_ptr=None, beta=0.0, 
     a.ldb = ldb if ldb is not None else a.N2
     a.ldc = a.N2
     a.dtype, a.a_is_f32 = dtype, _is_f32(A)
+    a.variant = int(variant)
     L.check(L.lib().uvc_gemm_tn(C.byref(a), L.cur_stream()), "uvc_gemm_tn")
 
 

@@ -2041,37 +2041,66 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
   const int wm = w >> 2, wn = w & 3;
   const int sub = lane & (LPR - 1), rg = lane / LPR;
 
-  // ---- LDS-DMA of a k-step: 16 wave-instructions of A rows, 48 of W rows (8 rows x 128 B each); wave w issues w, w + 8, ...
+  // ---- main loop: k_gemm_nt8p's schedule (two wave groups half a phase apart, the fragments of a phase requested inside the MFMA block of the
+  //      phase before, four LDS slots per k-step read in phases 0, 0, 1, 2) on the 128 x 384 tile: a wave's 64 x 96 block is the quadrants
+  //      A0 / A1 = row blocks 0-1 / 2-3, B0 / B1 = column blocks 0-2 / 3-5 (12 MFMAs a phase).  Slots of a k-step: A'0 (64 rows: the A0 rows of
+  //      both M groups, 8 KB), B'0 (192 rows of W: the B0 columns of the four N groups, 24 KB), B'1, A'1 = 64 KB, two buffers (the result tile
+  //      and the row pass reuse them behind the loop).  A wave issues 1 / 3 / 3 / 1 DMA instructions for them; waits counted accordingly.
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)(((size_t)(g.M - 1) * g.K + g.K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.W), 0, (int)((size_t)R3_BN * g.K * 2), 0x00020000);
+  constexpr int SZA = 64 * 128, SZB = 192 * 128, OFF_A0 = 0, OFF_B0 = SZA, OFF_B1 = SZA + SZB, OFF_A1 = SZA + 2 * SZB;
+  static_assert(2 * SZA + 2 * SZB == R3_STAGE, "a k-step's four slots fill a stage");
   const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;         // slot (row, c) <- k-chunk c ^ (row & 7)
-  const unsigned laneAB = (unsigned)(((w * 8 + lrow) * g.K + lchunk * 8) * 2);
-  const unsigned step64 = (unsigned)(64 * g.K * 2);
-  auto issue1 = [&](int t, unsigned voA, int kt, int st) {
-    char* base = smem + st * R3_STAGE + w * 1024;
-    const unsigned kb = (unsigned)(kt * R3_BK * 2);
-    if (t < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + t * 8192), 16, laneAB + (voA + kb + t * step64), 0, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(base + R3_OPA + (t - 2) * 8192), 16, laneAB + (kb + (t - 2) * step64), 0, 0, 0);
+  unsigned laneA[2], laneB[2][3];
+  {
+    const int ra = w * 8 + lrow;                                  // image row of an A slot: M group ra >> 5, row ra & 31 of its 32
+#pragma unroll
+    for (int h = 0; h < 2; ++h) laneA[h] = (unsigned)((((ra >> 5) * 64 + h * 32 + (ra & 31)) * g.K + lchunk * 8) * 2);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int rb = (w + 8 * q) * 8 + lrow;                      // image row of a W slot: N group rb / 48, column rb % 48 of its 48
+#pragma unroll
+      for (int h = 0; h < 2; ++h) laneB[h][q] = (unsigned)((((rb / 48) * 96 + h * 48 + rb % 48) * g.K + lchunk * 8) * 2);
+    }
+  }
+  // request item IT (0 = A'0, 1 = B'0, 2 = B'1, 3 = A'1) of the k-step at byte offset kb of the rows, into buffer buf
+  auto issue_item = [&](int it, unsigned voA, unsigned kb, int buf) {
+    char* base = smem + buf * R3_STAGE + w * 1024;
+    if (it == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + OFF_A0), 16, laneA[0] + (voA + kb), 0, 0, 0);
+    else if (it == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + OFF_A1), 16, laneA[1] + (voA + kb), 0, 0, 0);
+    else {
+      const int h = it - 1;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(base + (h ? OFF_B1 : OFF_B0) + q * 8192), 16, laneB[h][q] + kb, 0, 0, 0);
+    }
   };
   const unsigned s0 = lds_addr(smem);
   const unsigned sw0 = (unsigned)((((lane >> 4)) ^ (lane & 7)) * 16);
-  const unsigned fa0 = s0 + (unsigned)((wm * 64 + (lane & 15)) * 128) + sw0;
-  const unsigned fb0 = s0 + (unsigned)(R3_OPA + (wn * 96 + (lane & 15)) * 128) + sw0;
-  auto rdfrags = [&](R3Frags& F, int st, int ks) {
-    const unsigned a = (fa0 ^ (unsigned)(ks * 64)) + (unsigned)(st * R3_STAGE), b = (fb0 ^ (unsigned)(ks * 64)) + (unsigned)(st * R3_STAGE);
-    F.b[0] = ds_read128<0 * 2048>(b); F.b[1] = ds_read128<1 * 2048>(b); F.b[2] = ds_read128<2 * 2048>(b);
-    F.b[3] = ds_read128<3 * 2048>(b); F.b[4] = ds_read128<4 * 2048>(b); F.b[5] = ds_read128<5 * 2048>(b);
-    F.a[0] = ds_read128<0 * 2048>(a); F.a[1] = ds_read128<1 * 2048>(a); F.a[2] = ds_read128<2 * 2048>(a); F.a[3] = ds_read128<3 * 2048>(a);
-  };
-  auto tie = [&](R3Frags& F) {
-    asm volatile("" : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.a[2]), "+v"(F.a[3]),
-                      "+v"(F.b[0]), "+v"(F.b[1]), "+v"(F.b[2]), "+v"(F.b[3]), "+v"(F.b[4]), "+v"(F.b[5]));
-  };
+  const unsigned fa0 = s0 + (unsigned)((wm * 32 + (lane & 15)) * 128) + sw0;       // inside an A slot; k-half 1 = address ^ 64
+  const unsigned fb0 = s0 + (unsigned)((wn * 48 + (lane & 15)) * 128) + sw0;       // inside a W slot
+  u32x4 FA[2][2], FB0[3][2], FB1[3][2];
   f32x4 acc[4][6];
-  auto mfma_row = [&](const R3Frags& F, int i) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) acc[i][j] = MM::mma(__builtin_bit_cast(typename MM::Frag, F.b[j]), __builtin_bit_cast(typename MM::Frag, F.a[i]), acc[i][j]);
-  };
+#define R8_RD_B(DST, OFF, BO)                                                                                         \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                      \
+    DST[j][0] = ds_read128_asm(fb0 + (BO), (OFF) + j * 2048); DST[j][1] = ds_read128_asm((fb0 ^ 64u) + (BO), (OFF) + j * 2048); }
+#define R8_RD_A(I, OFF, BO) { FA[I][0] = ds_read128_asm(fa0 + (BO), (OFF) + (I) * 2048); FA[I][1] = ds_read128_asm((fa0 ^ 64u) + (BO), (OFF) + (I) * 2048); }
+#define R8_MMA6(I, AI, FB, JO)                                                                                        \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                     \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                        \
+    acc[AI][(JO) + j] = MM::mma(__builtin_bit_cast(typename MM::Frag, FB[j][ks]), __builtin_bit_cast(typename MM::Frag, FA[I][ks]), acc[AI][(JO) + j]);
+#define R8_REQ(IT, KB, SBUF, NWAIT)                                                                                   \
+  issue_item(IT, voA, KB, SBUF);                                                                                       \
+  if ((NWAIT) >= 0) wait_vm<((NWAIT) < 0 ? 0 : (NWAIT))>();                                                            \
+  __builtin_amdgcn_s_barrier();                                                                                        \
+  wait_lgkm<0>();                                                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  __builtin_amdgcn_s_setprio(1);
+#define R8_END                                                                                                        \
+  __builtin_amdgcn_s_setprio(0);                                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  __builtin_amdgcn_s_barrier();                                                                                        \
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- LayerNorm backward state of this lane: columns (sub + 32 i) * 4 .. + 3, i = 0..2 (k_ln_bwd_v<.., 3, 32>'s map)
   f32x4 gam[NV4], dgam[NV4], dbet[NV4];
@@ -2091,51 +2120,59 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
   for (int bm = blockIdx.x; bm < tiles_m; bm += gridDim.x) {
     const unsigned voA = (unsigned)(bm * R3_BM * g.K * 2);
     __syncthreads();                                              // the last tile's row pass is done with the stages
+    // prologue: k-step 0 whole, A'0 and B'0 of k-step 1
 #pragma unroll
-    for (int t = 0; t < 8; ++t) issue1(t, voA, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) issue1(t, voA, 1, 1);
-    wait_vm<8>();
+    for (int it = 0; it < 4; ++it) issue_item(it, voA, 0u, 0);
+    issue_item(0, voA, 128u, 1); issue_item(1, voA, 128u, 1);
+    wait_vm<5>();                                                 // A'0, B'0, B'1 of k-step 0 have landed (A'1: 1, A'0 + B'0 of k-step 1: 4 in flight)
     __builtin_amdgcn_s_barrier();
-    R3Frags F0, F1;
-    rdfrags(F0, 0, 0);
-    wait_lgkm<0>();
-    tie(F0);
+    R8_RD_B(FB0, OFF_B0, 0u)
+    R8_RD_A(0, OFF_A0, 0u) R8_RD_A(1, OFF_A0, 0u)
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs half a phase behind through the k-loop
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kt = 0; kt < nk; ++kt) {
-      const int st = kt & 1;
-      rdfrags(F1, st, 1);
+      const int buf = kt & 1;
+      const unsigned bo = (unsigned)(buf * R3_STAGE), bon = bo ^ (unsigned)R3_STAGE;
+      // k-steps kt + 1, kt + 2 (behind the last ones: k-steps 0 / 1 of the same tile again -- no branch around a DMA; nobody multiplies them)
+      const unsigned kb1 = (unsigned)((kt + 1 < nk ? kt + 1 : kt + 1 - nk) * 128), kb2 = (unsigned)((kt + 2 < nk ? kt + 2 : kt + 2 - nk) * 128);
+      // phase 0: (A0, B0); requests B'1 of kt + 1 (3); reads B1.  In flight behind the wait: A'0 + B'0 + B'1 of kt + 1 = 7
+      R8_REQ(2, kb1, buf ^ 1, 7)
+      R8_RD_B(FB1, OFF_B1, bo)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mfma_row(F0, i);
+      R8_MMA6(0, 0, FB0, 0) R8_MMA6(1, 1, FB0, 0)
+      R8_END
+      // phase 1: (A0, B1); requests A'1 of kt + 1 (1); reads A1 behind the MFMAs that free A0's registers
+      R8_REQ(3, kb1, buf ^ 1, -1)
+      R8_MMA6(0, 0, FB1, 3)
       __builtin_amdgcn_sched_barrier(0);
-      wait_lgkm<0>();
-      tie(F1);
-      wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
+      R8_RD_A(0, OFF_A1, bo)
       __builtin_amdgcn_sched_barrier(0);
-      // the stage freed now receives k-step kt + 2 (behind the last k-steps: k-steps 0 / 1 of the same tile again -- no branch around a DMA;
-      // they have landed before the result tile is written over them)
-      const int kk = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
-      mfma_row(F1, 0);
+      R8_MMA6(1, 1, FB1, 3)
       __builtin_amdgcn_sched_barrier(0);
-      rdfrags(F0, st ^ 1, 0);
+      R8_RD_A(1, OFF_A1, bo)
+      R8_END
+      // phase 2: (A1, B1); requests A'0 of kt + 2 (1).  In flight: B'1 + A'1 of kt + 1, A'0 of kt + 2 = 5
+      R8_REQ(0, kb2, buf, 5)
+      R8_MMA6(0, 2, FB1, 3) R8_MMA6(1, 3, FB1, 3)
+      R8_END
+      // phase 3: (A1, B0); requests B'0 of kt + 2 (3); reads A0 and B0 of kt + 1.  In flight: A'1 of kt + 1, A'0 + B'0 of kt + 2 = 5
+      R8_REQ(1, kb2, buf, 5)
+      R8_MMA6(0, 2, FB0, 0)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 1; i < 4; ++i) {
-        issue1(3 * (i - 1), voA, kk, st);
-        issue1(3 * (i - 1) + 1, voA, kk, st);
-        if (i < 3) issue1(3 * (i - 1) + 2, voA, kk, st);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(F1, i);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      wait_lgkm<0>();
-      tie(F0);
+      R8_RD_A(0, OFF_A0, bon)
+      __builtin_amdgcn_sched_barrier(0);
+      R8_MMA6(1, 3, FB0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      R8_RD_A(1, OFF_A0, bon)
+      R8_RD_B(FB0, OFF_B0, bon)
+      R8_END
     }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                    // pairs with group 1's last barrier: the groups are level again
+    wait_lgkm<0>();
     wait_vm<0>();
     __syncthreads();                                              // every wave is done with the stages and nothing is in flight into them
     // ---- the tile, rounded to bf16 (what k_gemm_nt stores), row-major in LDS: lane (li, gq) of acc[i][j] = row i * 16 + li, columns j * 16 + 4 gq ..
@@ -2228,6 +2265,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
       }
     }
   }
+#undef R8_RD_B
+#undef R8_RD_A
+#undef R8_MMA6
+#undef R8_REQ
+#undef R8_END
   // ---- this workgroup's partial row [2 D + 2]: the two row groups of a wave, then the eight waves in a fixed order
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem + 2 * R3_STAGE);

@@ -1,0 +1,11 @@
+#!/bin/bash
+# bench.py lines of the other BASELINE models and of Stage-2 (one JSON each, with their own roofline / top_kernels):
+#   tools/model_benches.sh <tag>   -> gpurun_out/<tag>/bench_<model>_b<batch>.json, bench_stage2_b512.json
+TAG=${1:-rX}; R=$(pwd); OUT=$R/gpurun_out/$TAG; mkdir -p "$OUT"
+for cfg in "deit_base_patch16_224 128" "deit_base_patch16_224 256" "deit_small_patch16_224 256" "t2t_vit_14 128"; do
+  set -- $cfg
+  timeout 600 python bench.py --no_cpu_baseline --model_type $1 --batch $2 --steps 40 --warmup 10 > "$OUT/bench_$1_b$2.json" 2> "$OUT/bench_$1_b$2.err"
+  python -c "import json,sys; d=json.load(open('$OUT/bench_$1_b$2.json')); print('$1', $2, d['value'], d['ms_per_step'], d['step_frac_of_bf16_mfma_peak'])"
+done
+timeout 600 python bench.py --stage 2 --no_cpu_baseline --steps 40 --warmup 10 > "$OUT/bench_stage2_b512.json" 2> "$OUT/bench_stage2.err"
+python -c "import json; d=json.load(open('$OUT/bench_stage2_b512.json')); print('stage2', d['value'], d['ms_per_step'])"

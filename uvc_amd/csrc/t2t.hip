@@ -349,11 +349,30 @@ __global__ __launch_bounds__(256) void k_performer_kv(const float* kqv, const fl
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   const int tile_end = (sp + 1) * tps < ntile ? (sp + 1) * tps : ntile;
+  // the k / v rows of the NEXT tile travel in registers under the arithmetic of the current one: with the loads in front of the barrier every
+  // tile of the loop paid an HBM round trip with three workgroups per CU to cover it
+  f32x4 rk[4], rv[4];
+  auto fetch = [&](int tile) {
+    const int t0 = tile * PT;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+      const bool ok = tile < tile_end && t0 + r < T;
+      rk[it] = ok ? ld4(base + (int64_t)(t0 + r) * 192 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rv[it] = ok ? ld4(base + 128 + (int64_t)(t0 + r) * 192 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  fetch(sp * tps);
   for (int tile = sp * tps; tile < tile_end; ++tile) {
     const int t0 = tile * PT;
     __syncthreads();
-    load_tile_kqv(base, t0, T, sk, tid);
-    load_tile_kqv(base + 128, t0, T, sv, tid);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+      *reinterpret_cast<f32x4*>(&sk[r][c4]) = rk[it];
+      *reinterpret_cast<f32x4*>(&sv[r][c4]) = rv[it];
+    }
+    fetch(tile + 1);
     __syncthreads();
     float p[8];
     prm8(sk, sw, t, mg, p);

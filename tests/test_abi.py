@@ -66,3 +66,33 @@ def test_t2t_host_side_tables():
     want = {k[len("tokens_to_token."):]: v for k, v in OT.param_shapes(cfg).items() if k.startswith("tokens_to_token.")}
     got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert got == want and m.num_patches == 196
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_c_structs(tmp_path):
+    """Every ctypes.Structure the Python host passes through the C-ABI (uvc_amd/_lib.py, model_distilled.py) against the struct of the same name in
+    include/*.h: gcc compiles a probe that prints sizeof and the offsetof of every field the mirror declares -- a field added to a header but not
+    to its mirror (or in another place) shifts everything behind it, and nothing but a GPU run would notice."""
+    import subprocess
+    from uvc_amd import _lib, model_distilled as MD
+    mirrors = [getattr(_lib, n) for n in dir(_lib) if n.startswith("uvc_") and isinstance(getattr(_lib, n), type) and issubclass(getattr(_lib, n), ctypes.Structure)]
+    mirrors += [getattr(MD, n) for n in ("uvc_vit_cfg", "uvc_vit_offsets", "uvc_vit_shadow_offsets", "uvc_vit_io", "uvc_mlp_compact")]
+    assert len(mirrors) >= 15
+    lines = ['#include <stdio.h>', '#include <stddef.h>']
+    lines += [f'#include "{os.path.basename(h)}"' for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))]
+    lines.append("int main(void) {")
+    for m in mirrors:
+        lines.append(f'  printf("{m.__name__} sizeof %zu\\n", sizeof({m.__name__}));')
+        for f in m._fields_:
+            lines.append(f'  printf("{m.__name__} {f[0]} %zu\\n", offsetof({m.__name__}, {f[0]}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    r = subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True).stdout
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out.splitlines()}
+    for m in mirrors:
+        assert got[(m.__name__, "sizeof")] == ctypes.sizeof(m), (m.__name__, got[(m.__name__, "sizeof")], ctypes.sizeof(m))
+        for f in m._fields_:
+            assert got[(m.__name__, f[0])] == getattr(m, f[0]).offset, (m.__name__, f[0])

@@ -106,6 +106,12 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     else:
         add("fc2+resid+gate", "k_gemm", Lf, 4 * u + 3 * ru, 2.0 * M * D * F,
             lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=xr, R2=gr_, gate=gate), wfrac=ru / (4 * u + 3 * ru))
+    if with_teacher and not tiny:
+        # wider models: the teacher's MLP is two GEMMs (the fused kernel exists for D = 192 only): fc1 + GELU (one output), fc2 + residual
+        add("teacher fc1+gelu", "k_gemm", Lf, 5 * u, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(xb, W1, uu, dtype=dt, epilogue=ops.EPI_BIAS_GELU_OUT, bias=bF), wfrac=0.8)
+        add("teacher fc2+resid", "k_gemm", Lf, 4 * u + 2 * ru, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=xr), wfrac=ru / (4 * u + 2 * ru))
     if tiny and with_teacher:
         add("teacher mlp_fused+norm1", "k_mlp_fused", Lf, u + 2 * ru, 4.0 * M * D * F,
             lambda: ops.mlp_fused_fwd(xr, gam, bet, W1, bF, W2, bD, o32, next_gamma=gam, next_beta=bet, next_h=y), wfrac=(ru + u) / (u + 2 * ru))

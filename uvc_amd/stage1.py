@@ -260,6 +260,8 @@ class Stage1Trainer:
         mm, opt = self.minimax, self.optimizer
         return dict(
             format="uvc_amd.stage1.v1",
+            # numerics the run was made with: the bf16 mode rounds the residual stream to bf16 unless resid_f32
+            numerics=dict(precision=str(self.args.precision), residual_stream="float32" if (getattr(self.model, "precision", "") == "fp32" or getattr(self.model, "resid_f32", False)) else "bf16"),
             model=self.model.state_dict(),
             uvc=dict(s=mm.s.data.clone(), r=mm.r.data.clone(), y=mm.y.data.clone(), p=mm.p.data.clone(), z=mm.z.data.clone(),
                      gate_momentum=mm._gate_momentum.clone(), gate_gsum=mm._gate_gsum.clone(), gate_counters=mm._gate_counters.clone(),

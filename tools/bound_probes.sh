@@ -1,0 +1,35 @@
+#!/bin/bash
+# Upper-bound probes for the two byte items VERDICT r3 next #5 asks to MEASURE before building:
+#   (a) teacher qkv projected inside its attention kernel   -> library variant "noteacherqkv": the no-grad forward (the teacher) skips its qkv GEMM
+#       altogether (attention reads whatever the buffer holds): what the step would gain if that GEMM cost NOTHING
+#   (b) fc1 stores ONE tensor instead of GELU(a) and GELU'(a) -> variant "onegelu": the training fc1 writes GELU(a) only, the backward reads the stale
+#       GELU' buffer: same kernels, same reads, one 155-MB write per layer less -- what a one-tensor scheme would gain BEFORE paying for its recomputation
+# Both variants compute wrong numbers on purpose; they are timing probes built from sed-edited COPIES of vit_engine.hip (the product source carries no switch).
+#   here:            tools/bound_probes.sh build   -> tools/perturb/libuvc_hip_{noteacherqkv,onegelu}.so
+#   on the GPU box:  tools/bound_probes.sh run     -> gpurun_out/bound_probes.txt  (alternating same-box A/B through tools/exp_ab.sh)
+set -u
+R=$(cd "$(dirname "$0")/.." && pwd)
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wno-unused-value -Wno-unused-result -I$R/include -I$R/uvc_amd/csrc"
+if [ "${1:-}" = build ]; then
+  python -m uvc_amd.build > /dev/null || exit 1
+  mkdir -p /tmp/perturb "$R/tools/perturb"
+  sed 's|^    TRY(nt(c, b.h1, 0, wmat(c, q\[2\], c.soff.blk_w\[l\]\[0\]), b.qkv, 0, d.M, 3 \* d.D, d.D,|    if (io->training) TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D,|' "$R/uvc_amd/csrc/vit_engine.hip" > /tmp/perturb/vit_noteacherqkv.hip
+  sed 's|TRY(nt(c, h2, 0, w1, ga, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_GRAD, b1, nullptr, nullptr, nullptr, nullptr, gu));|TRY(nt(c, h2, 0, w1, gu, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_OUT, b1));|' "$R/uvc_amd/csrc/vit_engine.hip" > /tmp/perturb/vit_onegelu.hip
+  for v in noteacherqkv onegelu; do
+    cmp -s /tmp/perturb/vit_$v.hip "$R/uvc_amd/csrc/vit_engine.hip" && { echo "variant $v did not apply"; exit 1; }
+    sed -i 's|#include "common.h"|#include "'"$R"'/uvc_amd/csrc/common.h"|; s|#include "../../include/|#include "'"$R"'/include/|' /tmp/perturb/vit_$v.hip
+    /opt/rocm/bin/hipcc $FLAGS -c /tmp/perturb/vit_$v.hip -o /tmp/perturb/vit_$v.o || exit 1
+    objs=$(ls "$R"/uvc_amd/csrc/build/*.o | grep -v '/vit_engine.o$')
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/tools/perturb/libuvc_hip_$v.so" $objs /tmp/perturb/vit_$v.o || exit 1
+  done
+  ls -la "$R/tools/perturb"
+  exit 0
+fi
+OUT=$R/gpurun_out/bound_probes.txt
+mkdir -p "$R/gpurun_out"
+export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$R}
+{
+  echo "# same-box alternating A/B, DeiT-Tiny batch 512, 60 steps each: <variant> <img/s> <ms per step> <sum of stand-alone kernel ms>"
+  for v in noteacherqkv onegelu; do echo "## $v"; bash "$R/tools/exp_ab.sh" $v; done
+} > "$OUT" 2>&1
+cat "$OUT"

@@ -222,9 +222,10 @@ int uvc_distill_loss(const uvc_loss_args* args, void* stream);
 
 /* clip_grad_norm_(max_norm) + AdamW over flat float32 buffers (joint_train.py:428-429;
  * torch.optim.AdamW(lr, betas, eps, weight_decay) semantics, decoupled decay).
- * uvc_grad_sqnorm accumulates sum(g^2) of a segment into sq[0] (call once per segment after zeroing);
+ * uvc_grad_sqnorm accumulates sum(g^2) of a segment into sq[0] (accumulate = 0 for the first segment) and leaves sqrt(sq[0]) -- the
+ * total norm so far, clip_grad_norm_'s return value -- in sq[1]: sq is float[2];
  * uvc_adamw_step applies clip coefficient min(1, max_norm/(sqrt(sq[0])+1e-6)) read on the device. */
-int uvc_grad_sqnorm(const float* g, int64_t n, float* partial /*[1024]*/, float* sq, int32_t accumulate, void* stream);
+int uvc_grad_sqnorm(const float* g, int64_t n, float* partial /*[1024]*/, float* sq /*[2]*/, int32_t accumulate, void* stream);
 typedef struct uvc_adamw_args {
   float* p; const float* g; float* m; float* v;
   void* p_shadow;        /* optional bf16 copy of p (GEMM operands), same layout */

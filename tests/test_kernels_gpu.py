@@ -450,20 +450,21 @@ def test_clip_adamw_matches_torch():
     opt = torch.optim.AdamW([P], lr=3e-4, weight_decay=0.05)
     p, m, v = p0.clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
     shadow = torch.empty(n, device=dev(), dtype=torch.bfloat16)
-    partial, sq, gn = torch.empty(1024, device=dev()), torch.empty(1, device=dev()), torch.empty(1, device=dev())
+    partial, sq, gn = torch.empty(1024, device=dev()), torch.empty(2, device=dev()), torch.empty(1, device=dev())
     for step in range(1, 4):
         g = g0 * step
         P.grad = g.clone()
         tn = torch.nn.utils.clip_grad_norm_([P], 1.0)
         opt.step()
         ops.grad_sqnorm(g, partial, sq)
+        torch.testing.assert_close(sq[1], tn, rtol=1e-5, atol=0)            # the norm clip_grad_norm_ returns, left by the reduction itself
         ops.adamw_step(p, g, m, v, sq, lr=3e-4, step=step, p_shadow=shadow, gnorm_out=gn)
         torch.testing.assert_close(gn[0], tn, rtol=1e-5, atol=0)
         torch.testing.assert_close(p, P.data, rtol=2e-6, atol=1e-7)
         torch.testing.assert_close(shadow.float(), P.data.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-3)
     gg = g0.clone()
     ops.scale_by_clip(gg, sq, 1.0)
-    torch.testing.assert_close(gg, g0 * min(1.0, 1.0 / (float(sq.sqrt()) + 1e-6)), rtol=1e-6, atol=0)
+    torch.testing.assert_close(gg, g0 * min(1.0, 1.0 / (float(sq[0].sqrt()) + 1e-6)), rtol=1e-6, atol=0)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])

@@ -142,7 +142,7 @@ def main():
         n = 5717440
         p, g, m, v = (torch.randn(n, device=dev) for _ in range(4))
         v.abs_()
-        part, sq = torch.empty(1024, device=dev), torch.zeros(1, device=dev)
+        part, sq = torch.empty(1024, device=dev), torch.zeros(2, device=dev)
         rec("grad_sqnorm", timeit(lambda: ops.grad_sqnorm(g, part, sq)), n * 4)
         rec("adamw", timeit(lambda: ops.adamw_step(p, g, m, v, sq, lr=1e-4, step=3)), n * 28)
     print(f"{'kernel':40s} {'ms':>8s} {'GB/s':>9s} {'TFLOP/s':>8s}")

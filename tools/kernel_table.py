@@ -156,7 +156,7 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     n = 5717440 if tiny else L * (4 * D * D + 2 * D * F)
     p, gr, m, v = (rn(n) for _ in range(4))
     v.abs_()
-    pp, sq = torch.empty(1024, device=dev), torch.zeros(1, device=dev)
+    pp, sq = torch.empty(1024, device=dev), torch.zeros(2, device=dev)
     add("clip+adamw", "k_adamw", 1, n * 28, 0, lambda: (ops.grad_sqnorm(gr, pp, sq), ops.adamw_step(p, gr, m, v, sq, lr=1e-4, step=3)))
     return rows
 

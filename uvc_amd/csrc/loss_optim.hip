@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void k_sqnorm_final(const float* partial, int 
   float s = 0.f;
   for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
   s = block_reduce(s, sh, false);
-  if (threadIdx.x == 0) sq[0] = (accumulate ? sq[0] : 0.f) + s;
+  if (threadIdx.x == 0) {
+    const float t = (accumulate ? sq[0] : 0.f) + s;
+    sq[0] = t;
+    sq[1] = sqrtf(t);                              // the total norm so far: what clip_grad_norm_ returns, without a launch of its own
+  }
 }
 
 // FLAGS: per-element byte, bit 0 = apply weight decay, bit 1 = frozen (no gradient reached it: untouched, like a

@@ -18,6 +18,19 @@ class SoftTargetCrossEntropy(torch.nn.Module):
         raise L.UvcHipError("SoftTargetCrossEntropy runs fused inside uvc_amd.losses.DistillationLoss on the HIP path")
 
 
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """The cached scalar 1.0 the trainers pass to ``loss.backward(...)``: autograd then builds no ones_like(loss) (a fill launch per
+    step) and ``_LossFunction.backward`` recognises it by its storage and skips the multiply by 1 (another launch).  Any other
+    gradient -- a plain ``loss.backward()``, a scaled loss -- takes the general path, same values."""
+    key = str(device)
+    if key not in _UNIT:
+        _UNIT[key] = torch.ones((), device=device)
+    return _UNIT[key]
+
+
 class _LossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, o, o_kd, y, teacher, alpha, tau, kind):
@@ -36,6 +49,9 @@ class _LossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         d_o, d_k = ctx.saved_tensors
+        u = _UNIT.get(str(g.device))
+        if u is not None and g.data_ptr() == u.data_ptr():          # d(loss) = 1: the stored gradients are the answer
+            return d_o, (None if ctx.same else d_k), None, None, None, None, None
         if ctx.same:
             return d_o * g, None, None, None, None, None, None
         return d_o * g, d_k * g, None, None, None, None, None

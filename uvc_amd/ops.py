@@ -229,7 +229,10 @@ def distill_loss(o, o_kd, y_soft, teacher, loss, d_o, d_okd, row_scratch, alpha,
 
 
 def grad_sqnorm(g, partial, sq, accumulate=False, n=None):
+    """sq: float32[2] -- sq[0] = sum of squares (accumulated over calls with accumulate=True), sq[1] = its square root."""
     _chk(g, partial, sq)
+    if sq.numel() < 2:
+        raise L.UvcHipError("grad_sqnorm: sq must hold 2 floats (sum of squares, norm)")
     L.check(L.lib().uvc_grad_sqnorm(L.ptr(g), n if n is not None else g.numel(), L.ptr(partial), L.ptr(sq),
                                     int(accumulate), L.cur_stream()), "uvc_grad_sqnorm")
 

@@ -26,18 +26,21 @@ def clip_grad_norm_(model_or_params, max_norm: float):
         raise L.UvcHipError("clip_grad_norm_: pass the uvc_amd model (or the generator from model.parameters() wrapped by FusedAdamW)")
     segs = _live_segments(model)
     st = _clip_state(model)
-    first = True
+    st["slot"] = (st["slot"] + 1) % st["ring"].shape[0]
+    st["sq"] = st["ring"][st["slot"]]              # [sum of squares, its square root]: a fresh slot per call, so the returned norm stays valid
+    first = True                                    # for the next 63 steps without a copy (the reference returns a new tensor per call)
     for off, n in segs:
         ops.grad_sqnorm(model._flat_grad[off:off + n], st["partial"], st["sq"], accumulate=not first)
         first = False
     st["armed"] = float(max_norm)
-    return torch.sqrt(st["sq"][0])
+    return st["sq"][1]                              # written by the reduction kernel: no sqrt launch
 
 
 def _clip_state(model):
     if not hasattr(model, "_clip"):
         dev = model._flat.device
-        model._clip = dict(partial=torch.empty(1024, device=dev), sq=torch.zeros(1, device=dev), armed=None,
+        ring = torch.zeros(64, 2, device=dev)
+        model._clip = dict(partial=torch.empty(1024, device=dev), ring=ring, slot=0, sq=ring[0], armed=None,
                            gnorm=torch.zeros(1, device=dev))
     return model._clip
 

@@ -23,7 +23,7 @@ import torch
 
 from .ddp import DistributedDataParallel
 from .joint_train import count_mask, save_model
-from .losses import DistillationLoss, SoftTargetCrossEntropy
+from .losses import DistillationLoss, SoftTargetCrossEntropy, unit_gradient
 from .model_distilled import DistilledVisionTransformer
 from .optim import clip_grad_norm_, create_optimizer
 from .scheduler import create_scheduler
@@ -133,7 +133,7 @@ class Stage2Trainer:
         loss = self.criterion(x, outputs, y)
         if self.accum > 1:
             loss = loss / self.accum                                                                # :365-366
-        loss.backward()
+        loss.backward(unit_gradient(loss.device))
         self._micro += 1
         if self._micro % self.accum != 0:                                                           # :372: the backward added into .grad
             return dict(loss=loss.detach() * self.accum, outputs=outputs, stepped=False)

@@ -13,7 +13,7 @@ import torch
 from . import _lib as L
 from .ddp import DistributedDataParallel
 from .joint_train import count_mask, get_uvc_layers, register_masks
-from .losses import DistillationLoss, SoftTargetCrossEntropy
+from .losses import DistillationLoss, SoftTargetCrossEntropy, unit_gradient
 from .model_distilled import DistilledVisionTransformer
 from .optim import FusedAdamW, clip_grad_norm_
 from .scheduler import PresetLRScheduler, WarmupCosineSchedule, WarmupLinearSchedule
@@ -193,7 +193,7 @@ class Stage1Trainer:
         loss = self.criterion(x, outputs, y)
         if self.accum > 1:
             loss = loss / self.accum                                                                # :413-414
-        loss.backward()
+        loss.backward(unit_gradient(loss.device))       # d(loss) = 1 without a ones_like fill or a multiply by it (losses.unit_gradient)
         self._micro += 1
         if self._micro % self.accum != 0:                                                           # :417
             return dict(loss=loss.detach() * self.accum, outputs=outputs, stepped=False)

@@ -49,9 +49,9 @@ def uvc_optimizer(optimizer, minimax_model, s_optimizer, r_optimizer, gating_opt
         if (global_step + 1) % gating_interval == 0:
             gating_grad_list = []
         mm.gating_list_len = len(gating_grad_list)
-    snap = mm._flat.clone()                         # s,r,y,p,z of THIS step (device-side copy, no sync)
+    snap = mm._flat.clone()                         # s,r,y,p,z and the reported resource of THIS step (one device-side copy, no sync)
     n2, nH = mm.n_layers * 2, mm.n_layers * mm.num_heads
-    cur = DeviceValue(mm._out[0:1].clone(), scalar=True)
+    cur = DeviceValue(snap[snap.numel() - 4:snap.numel() - 3], scalar=True)
     s_v = DeviceValue(snap[0:n2].view(mm.n_layers, 2))
     r_v = DeviceValue(snap[n2:n2 + nH].view(mm.n_layers, mm.num_heads))
     g_v = DeviceValue(gate.detach().clone()) if gate is not None else None

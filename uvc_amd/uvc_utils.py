@@ -109,9 +109,11 @@ class UVC_CP_MiniMax(nn.Module):
             raise ValueError(f"attn.proj in_features {D} != num_heads*head_size {num_heads}*{head_size}")
         self.dims = L.uvc_dims(n_layers, num_heads, head_size, D, F)
         H = num_heads
-        # one contiguous block: s[L,2] r[L,H] y[L,2] p[L,H] z[1]  (a single async D2H can read all)
+        # one contiguous block: s[L,2] r[L,H] y[L,2] p[L,H] z[1] out[4]  (a single async D2H -- and the per-step snapshot, one copy -- reads all;
+        # out = what uvc_dual_step reports: [0] the current resource)
         n = n_layers * (4 + 2 * H) + 1
-        self._flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self._flat = torch.zeros(n + 4, device=dev, dtype=torch.float32)
+        self._out = self._flat[n:n + 4]
         o = 0
 
         def take(shape):
@@ -161,7 +163,6 @@ class UVC_CP_MiniMax(nn.Module):
         self._gate_momentum = torch.zeros(n_layers, 2, **f32)
         self._gate_gsum = torch.zeros(n_layers, 2, **f32)
         self._gate_counters = torch.zeros(2, **i32)
-        self._out = torch.zeros(4, **f32)
         self._res_out = torch.zeros(1, **f32)
         self._tables = None
         self._table_key = None

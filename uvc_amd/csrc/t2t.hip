@@ -264,135 +264,11 @@ int bwd_grid(int rows) { const int n = (rows + 3) / 4; return n < 1024 ? n : 102
 //                                  Performer linear attention
 // ================================================================================================
 constexpr int PE = 64, PM = 32, PT = 64, PKV = 65 * 32;
-// LDS row strides in floats: 64-wide tiles 68, 32-wide tiles 36 -- rows stay 16-byte aligned, so the inner products read four
-// consecutive elements per ds_read_b128 (the scalar-read form was LDS-bound: 9 reads for 8 FMAs), and both strides are 4 x odd:
-// a wave's lanes reading 16 bytes each from consecutive rows cover all 64 banks exactly once.
-constexpr int S64 = 68, S32 = 36;
+// (token_performer.py:31-69; kernel_ratio 0.5: m = 32 random features of the 64-wide k / q)
+constexpr int S64 = 68;              // LDS row stride (floats) of a [token][64] tile written and read as 16-byte pieces (4 x odd: conflict-free for both)
 #define SQRT_M 5.656854249492381f
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float c) { c += a[0] * b[0]; c += a[1] * b[1]; c += a[2] * b[2]; c += a[3] * b[3]; return c; }
-
-__device__ __forceinline__ void load_w(const float* w, float (*sw)[S64], int tid) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it) { const int idx = (tid + it * 256) * 4; *reinterpret_cast<f32x4*>(&sw[idx >> 6][idx & 63]) = ld4(w + idx); }
-}
-// [64 tokens][64] float32 tile of kqv (row stride 192) -> LDS; rows at or beyond T are zero
-__device__ __forceinline__ void load_tile_kqv(const float* base, int t0, int T, float (*s)[S64], int tid) {
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t0 + r < T) v = ld4(base + (int64_t)(t0 + r) * 192 + c4);
-    *reinterpret_cast<f32x4*>(&s[r][c4]) = v;
-  }
-}
-// [64 tokens][64] tile of a dense gradient stream [B*T, 64] (float32 or bf16) -> LDS
-template <typename TG>
-__device__ __forceinline__ void load_tile_g(const TG* base, int t0, int T, float (*s)[S64], int tid) {
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t0 + r < T) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = ElemIO<TG>::load(base + (int64_t)(t0 + r) * 64 + c4 + e);
-    }
-    *reinterpret_cast<f32x4*>(&s[r][c4]) = v;
-  }
-}
-__device__ __forceinline__ void load_kv(const float* kv, float (*skv)[S32], int tid) {
-  for (int idx = tid * 4; idx < PKV; idx += 1024) *reinterpret_cast<f32x4*>(&skv[idx >> 5][idx & 31]) = ld4(kv + idx);
-}
-// positive random features (token_performer.py:31-43): thread (token t, feature group mg) -> 8 of the 32 features
-__device__ __forceinline__ void prm8(const float (*sx)[S64], const float (*sw)[S64], int t, int mg, float (&p)[8]) {
-  float d[8], xx = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) d[j] = 0.f;
-#pragma unroll 4
-  for (int i = 0; i < PE; i += 4) {
-    const f32x4 x = ld4(&sx[t][i]);
-    xx = dot4(x, x, xx);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] = dot4(x, ld4(&sw[mg * 8 + j][i]), d[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) p[j] = expf(d[j] - 0.5f * xx) / SQRT_M;
-}
-// acc[j] += x * row[j], j < 8, row = 8 consecutive floats (two 16-byte broadcast reads)
-__device__ __forceinline__ void axpy8(float x, const float* row, float (&acc)[8]) {
-  const f32x4 a = ld4(row), b = ld4(row + 4);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { acc[j] += x * a[j]; acc[4 + j] += x * b[j]; }
-}
-__device__ __forceinline__ void st8(float* row, const float (&v)[8]) {
-  *reinterpret_cast<f32x4*>(row) = f32x4{v[0], v[1], v[2], v[3]};
-  *reinterpret_cast<f32x4*>(row + 4) = f32x4{v[4], v[5], v[6], v[7]};
-}
-// sum_m a[m] * b[m] over the 32 features of two 36-stride rows
-__device__ __forceinline__ float dot32(const float* a, const float* b) {
-  float c = 0.f;
-#pragma unroll
-  for (int m = 0; m < PM; m += 4) c = dot4(ld4(a + m), ld4(b + m), c);
-  return c;
-}
-
-// kptv / ksum partials of one (image, split): sum_t v_t kp_t^T and sum_t kp_t over the split's token tiles
-__global__ __launch_bounds__(256) void k_performer_kv(const float* kqv, const float* w, float* part, int T, int S, int tps) {
-  __shared__ __attribute__((aligned(16))) float sw[PM][S64], sk[PT][S64], sv[PT][S64], skp[PT][S32];
-  const int tid = threadIdx.x, b = blockIdx.x / S, sp = blockIdx.x % S;
-  const int ntile = (T + PT - 1) / PT;
-  const int t = tid & 63, mg = tid >> 6;
-  const float* base = kqv + (int64_t)b * T * 192;
-  load_w(w, sw, tid);
-  float acc[8], ks = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  const int tile_end = (sp + 1) * tps < ntile ? (sp + 1) * tps : ntile;
-  // the k / v rows of the NEXT tile travel in registers under the arithmetic of the current one: with the loads in front of the barrier every
-  // tile of the loop paid an HBM round trip with three workgroups per CU to cover it
-  f32x4 rk[4], rv[4];
-  auto fetch = [&](int tile) {
-    const int t0 = tile * PT;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
-      const bool ok = tile < tile_end && t0 + r < T;
-      rk[it] = ok ? ld4(base + (int64_t)(t0 + r) * 192 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      rv[it] = ok ? ld4(base + 128 + (int64_t)(t0 + r) * 192 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  fetch(sp * tps);
-  for (int tile = sp * tps; tile < tile_end; ++tile) {
-    const int t0 = tile * PT;
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
-      *reinterpret_cast<f32x4*>(&sk[r][c4]) = rk[it];
-      *reinterpret_cast<f32x4*>(&sv[r][c4]) = rv[it];
-    }
-    fetch(tile + 1);
-    __syncthreads();
-    float p[8];
-    prm8(sk, sw, t, mg, p);
-    if (t0 + t >= T) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) p[j] = 0.f;
-    }
-    st8(&skp[t][mg * 8], p);
-    __syncthreads();
-#pragma unroll 16
-    for (int tt = 0; tt < PT; ++tt) axpy8(sv[tt][t], &skp[tt][mg * 8], acc);
-    if (tid < PM)
-#pragma unroll 8
-      for (int tt = 0; tt < PT; ++tt) ks += skp[tt][tid];
-  }
-  float* o = part + (int64_t)blockIdx.x * PKV;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[t * PM + mg * 8 + j] = acc[j];
-  if (tid < PM) o[64 * PM + tid] = ks;
-}
 
 __global__ void k_part_reduce(const float* part, float* out, int S) {
   const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
@@ -402,174 +278,415 @@ __global__ void k_part_reduce(const float* part, float* out, int S) {
   out[(int64_t)b * PKV + e] = t;
 }
 
-template <typename TO>
-__global__ __launch_bounds__(256) void k_performer_q(const float* kqv, const float* w, const float* kptv, TO* att, int T, int ntile) {
-  __shared__ __attribute__((aligned(16))) float sw[PM][S64], sq[PT][S64], skv[65][S32], sqp[PT][S32], sden[4][PT];
-  const int tid = threadIdx.x, b = blockIdx.x / ntile, t0 = (blockIdx.x % ntile) * PT;
-  const int t = tid & 63, mg = tid >> 6;
-  load_w(w, sw, tid);
-  load_tile_kqv(kqv + (int64_t)b * T * 192 + 64, t0, T, sq, tid);
-  load_kv(kptv + (int64_t)b * PKV, skv, tid);
-  __syncthreads();
-  float p[8], pd = 0.f;
-  prm8(sq, sw, t, mg, p);
-  st8(&sqp[t][mg * 8], p);
+// ------------------------------------------------------------------------------------------------
+// (r4) The forward on the matrix pipe: v_mfma_f32_16x16x4_f32 (exact float32 products, float32 accumulation; twice the unpacked VALU rate, and the
+// operands sit in registers -- the VALU form of rounds 2-3 issued 9 LDS reads per 32 FMAs and was bound by them: 283 -> 135 us forward, 660 -> 281 us
+// backward at 128 x 3136 tokens).  Lane (i = lane & 15, g = lane >> 4) of the MFMA
+// supplies A[i][k] and B[k][i] for k = 4 step + g and holds D[4 g + r][i], r < 4.  A contraction index may be permuted at will as long as both
+// operands agree; a 64-float row is taken as four 16-byte reads at columns 16 q + 4 g (value 4 q + e <-> column 16 q + 4 g + e): the four lane groups
+// read adjacent 16-byte pieces, 64-byte segments per row from global memory.
+// ------------------------------------------------------------------------------------------------
+constexpr int SV = 80, SP = 48;      // LDS row strides (floats) of tiles read by COLUMNS with one float per lane: 16 mod 64, so rows 4 s + g of the four lane groups
+                                     // fall on distinct banks (SV: [token][64], SP: [token][32])
+template <typename T> struct St4;                   // four consecutive outputs: 16 bytes of float32 / 8 bytes of bf16 (round-to-nearest-even, as ElemIO)
+template <> struct St4<float> { static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; } };
+template <> struct St4<bf16_t> {
+  static __device__ __forceinline__ void st(bf16_t* p, f32x4 v) { u32x2 r; r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]); *reinterpret_cast<u32x2*>(p) = r; }
+};
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void frag64(const float* row, int g, float (&f)[16]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) pd += p[j] * skv[64][mg * 8 + j];
-  sden[mg][t] = pd;
-  __syncthreads();
-  const int n = t;
-#pragma unroll 2
-  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {
-    const float num = dot32(sqp[tt], skv[n]);
-    const float den = ((sden[0][tt] + sden[1][tt]) + (sden[2][tt] + sden[3][tt])) + 1e-8f;
-    if (t0 + tt < T) ElemIO<TO>::store(att + ((int64_t)b * T + t0 + tt) * PE + n, num / den);
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = ld4(row + 16 * q + 4 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[4 * q + e] = v[e];
   }
 }
+// positive random features of 16 tokens, transposed: p[ft][r] = feature 16 ft + 4 g + r of token (lane & 15); wf = the lane's W fragments (row 16 ft + i),
+// xf = the token's row fragment (token_performer.py:31-43)
+__device__ __forceinline__ void prm_t(const float (&wf)[2][16], const float (&xf)[16], float (&p)[2][4]) {
+  f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+  float xx = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    c0 = mfma4(wf[0][s], xf[s], c0);
+    c1 = mfma4(wf[1][s], xf[s], c1);
+    xx += xf[s] * xf[s];
+  }
+  xx += __shfl_xor(xx, 16, 64);
+  xx += __shfl_xor(xx, 32, 64);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { p[0][r] = expf(c0[r] - 0.5f * xx) / SQRT_M; p[1][r] = expf(c1[r] - 0.5f * xx) / SQRT_M; }
+}
 
-// q side of the backward: dq, and the (image, split) partials of dkptv / dksum
-template <typename TG>
-__global__ __launch_bounds__(256) void k_performer_bwd_q(const float* kqv, const float* w, const float* kptv, const TG* datt, TG* dkqv, float* part,
-                                                         int T, int S, int tps) {
-  __shared__ __attribute__((aligned(16))) float sw[PM][S64], sq[PT][S64], sdy[PT][S64], skv[65][S32], sqp[PT][S32], sden[4][PT], sdden[PT];
+// kptv / ksum partials of one (image, split): wave w computes kp of tokens 16 w .. of a 64-token tile (W kp-fragments in registers, the k rows straight from
+// global memory, one tile ahead), then the [16 w ..][32] block of sum_t v_t kp_t^T with v^T as the A operand (column reads of the v tile) and kp as B
+__global__ __launch_bounds__(256) void k_performer_kv_mfma(const float* kqv, const float* w, float* part, int T, int S, int tps) {
+  __shared__ __attribute__((aligned(16))) float sv[PT][SV], skp[PT][SP], sred[4][PM];
   const int tid = threadIdx.x, b = blockIdx.x / S, sp = blockIdx.x % S;
   const int ntile = (T + PT - 1) / PT;
-  const int t = tid & 63, mg = tid >> 6;
-  load_w(w, sw, tid);
-  load_kv(kptv + (int64_t)b * PKV, skv, tid);
-  __syncthreads();
-  float wc[PM];                                                         // column t of w: dq[.][t] = sum_m g[.][m] * w[m][t]
+  const int lane = tid & 63, wv = tid >> 6, i = lane & 15, g = lane >> 4;
+  const float* base = kqv + (int64_t)b * T * 192;
+  float wf[2][16];
+  frag64(w + i * 64, g, wf[0]);
+  frag64(w + (16 + i) * 64, g, wf[1]);
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float ks[2][4];
 #pragma unroll
-  for (int m = 0; m < PM; ++m) wc[m] = sw[m][t];
-  float acc[8], dks = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int r = 0; r < 4; ++r) ks[0][r] = ks[1][r] = 0.f;
   const int tile_end = (sp + 1) * tps < ntile ? (sp + 1) * tps : ntile;
+  float xk[16];
+  f32x4 rv[4];
+  auto fetch = [&](int tile) {                        // next tile: the wave's k fragments and the workgroup's v rows, in registers under this tile's arithmetic
+    const int t0 = tile * PT;
+    const bool okk = tile < tile_end && t0 + 16 * wv + i < T;
+    if (okk) frag64(base + (int64_t)(t0 + 16 * wv + i) * 192, g, xk);
+    else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xk[e] = 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+      rv[it] = (tile < tile_end && t0 + r < T) ? ld4(base + 128 + (int64_t)(t0 + r) * 192 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  fetch(sp * tps);
   for (int tile = sp * tps; tile < tile_end; ++tile) {
     const int t0 = tile * PT;
-    __syncthreads();
-    load_tile_kqv(kqv + (int64_t)b * T * 192 + 64, t0, T, sq, tid);
-    load_tile_g<TG>(datt + (int64_t)b * T * 64, t0, T, sdy, tid);
-    __syncthreads();
-    {                                                                  // P1: qp and the denominator
-      float p[8], pd = 0.f;
-      prm8(sq, sw, t, mg, p);
+    __syncthreads();                                  // the column reads of the tile before are done
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { if (t0 + t >= T) p[j] = 0.f; pd += p[j] * skv[64][mg * 8 + j]; }
-      st8(&sqp[t][mg * 8], p);
-      sden[mg][t] = pd;
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+      *reinterpret_cast<f32x4*>(&sv[r][c4]) = rv[it];
     }
-    __syncthreads();
-#pragma unroll 2
-  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                  // P2: dnum (in place over dy), dden; thread (n = t, 16 tokens)
-      const float num = dot32(sqp[tt], skv[t]);
-      const float den = ((sden[0][tt] + sden[1][tt]) + (sden[2][tt] + sden[3][tt])) + 1e-8f;
-      const float dy = sdy[tt][t];
-      const float dot = wave_sum(dy * num);
-      sdy[tt][t] = dy / den;
-      if (t == 0) sdden[tt] = -dot / (den * den);
+    float p[2][4];
+    prm_t(wf, xk, p);
+    if (t0 + 16 * wv + i >= T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[0][r] = p[1][r] = 0.f;
     }
-    __syncthreads();
-#pragma unroll 8
-    for (int tt = 0; tt < PT; ++tt) axpy8(sdy[tt][t], &sqp[tt][mg * 8], acc);     // P4: dkptv[n][m] += dnum[tt][n] qp[tt][m]
-    if (tid < PM)
-#pragma unroll 8
-      for (int tt = 0; tt < PT; ++tt) dks += sdden[tt] * sqp[tt][tid];
-    __syncthreads();
-    {                                                                  // P3: g = dqp * qp in place over qp; thread (token t, 8 features)
-      float dqp[8];
-      const float dd = sdden[t];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dqp[j] = dd * skv[64][mg * 8 + j];
-#pragma unroll 2
-      for (int n = 0; n < PE; n += 4) {
-        const f32x4 dn = ld4(&sdy[t][n]);
+    for (int ft = 0; ft < 2; ++ft) {
+      *reinterpret_cast<f32x4*>(&skp[16 * wv + i][16 * ft + 4 * g]) = f32x4{p[ft][0], p[ft][1], p[ft][2], p[ft][3]};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) axpy8(dn[e], &skv[n + e][mg * 8], dqp);
-      }
-      const f32x4 q0 = ld4(&sqp[t][mg * 8]), q1 = ld4(&sqp[t][mg * 8 + 4]);
-      float gq[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { gq[j] = q0[j] * dqp[j]; gq[4 + j] = q1[j] * dqp[4 + j]; }
-      st8(&sqp[t][mg * 8], gq);
+      for (int r = 0; r < 4; ++r) ks[ft][r] += p[ft][r];
     }
+    fetch(tile + 1);
     __syncthreads();
-#pragma unroll 2
-  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                  // P5: dq[tt][i] = sum_m g (w[m][i] - q[tt][i]); thread (i = t, 16 tokens)
-      float a = 0.f, gs = 0.f;
 #pragma unroll
-      for (int m = 0; m < PM; m += 4) {
-        const f32x4 gm = ld4(&sqp[tt][m]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a += gm[e] * wc[m + e]; gs += gm[e]; }
-      }
-      if (t0 + tt < T) ElemIO<TG>::store(dkqv + ((int64_t)b * T + t0 + tt) * 192 + 64 + t, a - sq[tt][t] * gs);
+    for (int s = 0; s < 16; ++s) {                    // tokens 4 s + g
+      const float a = sv[4 * s + g][16 * wv + i];
+      acc[0] = mfma4(a, skp[4 * s + g][i], acc[0]);
+      acc[1] = mfma4(a, skp[4 * s + g][16 + i], acc[1]);
     }
   }
   float* o = part + (int64_t)blockIdx.x * PKV;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[t * PM + mg * 8 + j] = acc[j];
-  if (tid < PM) o[64 * PM + tid] = dks;
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[(16 * wv + 4 * g + r) * PM + 16 * ft + i] = acc[ft][r];
+      float v = ks[ft][r];                            // sum over the wave's 16 token columns, then over the four waves in a fixed order
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) v += __shfl_xor(v, x, 64);
+      if (i == 0) sred[wv][16 * ft + 4 * g + r] = v;
+    }
+  __syncthreads();
+  if (tid < PM) o[64 * PM + tid] = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
 }
 
-// k / v side of the backward, one 64-token tile per workgroup
-template <typename TG>
-__global__ __launch_bounds__(256) void k_performer_bwd_k(const float* kqv, const float* w, const float* dkptv, const TG* dskip, TG* dkqv, int T, int ntile) {
-  __shared__ __attribute__((aligned(16))) float sw[PM][S64], sk[PT][S64], sv[PT][S64], sdk[65][S32], skp[PT][S32];
+// attention rows of one 64-token tile: wave w takes tokens 16 w ..: qp^T by MFMA (q rows straight from global memory), the denominator from the lane's own
+// features, num^T[n][token] = sum_m kptv[n][m] qp[token][m] with the qp fragment as it lies in the registers (B operand) and kptv as A
+template <typename TO>
+__global__ __launch_bounds__(256) void k_performer_q_mfma(const float* kqv, const float* w, const float* kptv, TO* att, int T, int ntile) {
+  __shared__ __attribute__((aligned(16))) float so[PT][S64];
   const int tid = threadIdx.x, b = blockIdx.x / ntile, t0 = (blockIdx.x % ntile) * PT;
-  const int t = tid & 63, mg = tid >> 6;
-  const float* base = kqv + (int64_t)b * T * 192;
-  load_w(w, sw, tid);
-  load_tile_kqv(base, t0, T, sk, tid);
-  load_tile_kqv(base + 128, t0, T, sv, tid);
-  load_kv(dkptv + (int64_t)b * PKV, sdk, tid);
-  __syncthreads();
-  {
-    float p[8];
-    prm8(sk, sw, t, mg, p);
-    st8(&skp[t][mg * 8], p);
+  const int lane = tid & 63, wv = tid >> 6, i = lane & 15, g = lane >> 4;
+  const float* kv = kptv + (int64_t)b * PKV;
+  float wf[2][16], xq[16];
+  frag64(w + i * 64, g, wf[0]);
+  frag64(w + (16 + i) * 64, g, wf[1]);
+  const int tok = t0 + 16 * wv + i;
+  if (tok < T) frag64(kqv + ((int64_t)b * T + tok) * 192 + 64, g, xq);
+  else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) xq[e] = 0.f;
   }
-  __syncthreads();
-#pragma unroll 2
-  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                    // dv[tt][n] = sum_m kp[tt][m] dkptv[n][m] (+ skip gradient)
-    float a = dot32(skp[tt], sdk[t]);
-    if (t0 + tt < T) {
-      const int64_t r = (int64_t)b * T + t0 + tt;
-      if (dskip) a += ElemIO<TG>::load(dskip + r * 64 + t);
-      ElemIO<TG>::store(dkqv + r * 192 + 128 + t, a);
+  f32x4 akv[4][2];                                     // kptv[16 et + i][16 ft + 4 g ..]: the A operand, contraction index m = 16 ft + 4 g + r <-> step 4 ft + r
+#pragma unroll
+  for (int et = 0; et < 4; ++et)
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) akv[et][ft] = ld4(kv + (16 * et + i) * PM + 16 * ft + 4 * g);
+  const f32x4 ksum0 = ld4(kv + 64 * PM + 4 * g), ksum1 = ld4(kv + 64 * PM + 16 + 4 * g);
+  float p[2][4];
+  prm_t(wf, xq, p);
+  float den = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) den += p[0][r] * ksum0[r];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) den += p[1][r] * ksum1[r];
+  den += __shfl_xor(den, 16, 64);
+  den += __shfl_xor(den, 32, 64);
+  den += 1e-8f;
+#pragma unroll
+  for (int et = 0; et < 4; ++et) {
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c = mfma4(akv[et][ft][r], p[ft][r], c);
+    *reinterpret_cast<f32x4*>(&so[16 * wv + i][16 * et + 4 * g]) = f32x4{c[0] / den, c[1] / den, c[2] / den, c[3] / den};
+  }
+  __builtin_amdgcn_wave_barrier();                     // rows 16 w .. of `so` belong to this wave alone
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int r = 16 * wv + 4 * ps + g;
+    const f32x4 v = ld4(&so[r][4 * i]);
+    if (t0 + r < T) {
+      St4<TO>::st(att + ((int64_t)b * T + t0 + r) * PE + 4 * i, v);
     }
   }
-  __syncthreads();
-  {                                                                    // g = dkp * kp in place; thread (token t, 8 features)
-    float dkp[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dkp[j] = sdk[64][mg * 8 + j];
-#pragma unroll 2
-    for (int n = 0; n < PE; n += 4) {
-      const f32x4 vv = ld4(&sv[t][n]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) axpy8(vv[e], &sdk[n + e][mg * 8], dkp);
-    }
-    const f32x4 k0 = ld4(&skp[t][mg * 8]), k1 = ld4(&skp[t][mg * 8 + 4]);
-    float gk[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { gk[j] = k0[j] * dkp[j]; gk[4 + j] = k1[j] * dkp[4 + j]; }
-    st8(&skp[t][mg * 8], gk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// (r4) The backward on the matrix pipe.  Every product below keeps the TOKEN as the MFMA column (lane & 15), so a lane's values of one step are the B
+// operand of the next as they lie in the registers: qp^T -> num^T -> dnum^T -> dqp^T -> g^T -> dq^T; only the two sums over tokens (dkptv, dksum) cross
+// the lanes, through LDS tiles read by columns.  Operand fragments of the small matrices (W, kptv, their transposes) are loaded once per workgroup.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Ld4;
+template <> struct Ld4<float> { static __device__ __forceinline__ f32x4 ld(const float* p) { return ld4(p); } };
+template <> struct Ld4<bf16_t> {
+  static __device__ __forceinline__ f32x4 ld(const bf16_t* p) {
+    const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
   }
-  __syncthreads();
-  float wc[PM];
+};
+// A-operand fragments of a [64][32] matrix M (kptv / dkptv): direct (contraction over the 32 columns: a[et][ft] = M[16 et + i][16 ft + 4 g ..]) and
+// transposed (contraction over the 64 rows: aT[mt][4 et + r] = M[16 et + 4 g + r][16 mt + i])
+__device__ __forceinline__ void kv_frags(const float* M, int i, int g, f32x4 (&a)[4][2], float (&aT)[2][16]) {
 #pragma unroll
-  for (int m = 0; m < PM; ++m) wc[m] = sw[m][t];
-#pragma unroll 2
-  for (int tt = mg * 16; tt < mg * 16 + 16; ++tt) {                    // dk[tt][i] = sum_m g (w[m][i] - k[tt][i])
-    float a = 0.f, gs = 0.f;
+  for (int et = 0; et < 4; ++et) {
 #pragma unroll
-    for (int m = 0; m < PM; m += 4) {
-      const f32x4 gm = ld4(&skp[tt][m]);
+    for (int ft = 0; ft < 2; ++ft) a[et][ft] = ld4(M + (16 * et + i) * PM + 16 * ft + 4 * g);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a += gm[e] * wc[m + e]; gs += gm[e]; }
+    for (int r = 0; r < 4; ++r) {
+      aT[0][4 * et + r] = M[(16 * et + 4 * g + r) * PM + i];
+      aT[1][4 * et + r] = M[(16 * et + 4 * g + r) * PM + 16 + i];
     }
-    if (t0 + tt < T) ElemIO<TG>::store(dkqv + ((int64_t)b * T + t0 + tt) * 192 + t, a - sk[tt][t] * gs);
+  }
+}
+// W^T fragments for dx^T[dim][token] = sum_m w[m][dim] g[token][m]: wT[dt][4 mt + r] = w[16 mt + 4 g + r][16 dt + i]
+__device__ __forceinline__ void wt_frags(const float* w, int i, int g, float (&wT)[4][8]) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wT[dt][4 * mt + r] = w[(16 * mt + 4 * g + r) * 64 + 16 * dt + i];
+}
+// c[et][r] = value of (token 16 wv + i, column 16 et + 4 g + r) -> rows of `dst` (row stride ld elements), through the wave's own 16 rows of `so`
+template <typename TO>
+__device__ __forceinline__ void rows_out(float (*so)[S64], int wv, int i, int g, const f32x4 (&c)[4], TO* dst, int ld, int t0, int T) {
+#pragma unroll
+  for (int et = 0; et < 4; ++et) *reinterpret_cast<f32x4*>(&so[16 * wv + i][16 * et + 4 * g]) = c[et];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int r = 16 * wv + 4 * ps + g;
+    const f32x4 v = ld4(&so[r][4 * i]);
+    if (t0 + r < T) St4<TO>::st(dst + (int64_t)(t0 + r) * ld + 4 * i, v);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+// x^T-side gradient of the random features: dx[token][dim] = sum_m g[token][m] w[m][dim] - x[token][dim] sum_m g[token][m]  (g = dp * p; xf = the token's row fragment)
+__device__ __forceinline__ void prm_bwd_t(const float (&wT)[4][8], const float (&gq)[2][4], const float (&xf)[16], f32x4 (&dx)[4]) {
+  float gs = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) gs += gq[0][r];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) gs += gq[1][r];
+  gs += __shfl_xor(gs, 16, 64);
+  gs += __shfl_xor(gs, 32, 64);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c = mfma4(wT[dt][4 * mt + r], gq[mt][r], c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dx[dt][r] = c[r] - xf[4 * dt + r] * gs;
+  }
+}
+
+template <typename TG>
+__global__ __launch_bounds__(256) void k_performer_bwd_q_mfma(const float* kqv, const float* w, const float* kptv, const TG* datt, TG* dkqv, float* part,
+                                                              int T, int S, int tps) {
+  __shared__ __attribute__((aligned(16))) float sdn[PT][SV], sqp[PT][SP], so[PT][S64], sred[4][PM];
+  const int tid = threadIdx.x, b = blockIdx.x / S, sp = blockIdx.x % S;
+  const int ntile = (T + PT - 1) / PT;
+  const int lane = tid & 63, wv = tid >> 6, i = lane & 15, g = lane >> 4;
+  const float* kv = kptv + (int64_t)b * PKV;
+  float wf[2][16], akT[2][16], wT[4][8];
+  f32x4 ak[4][2];
+  frag64(w + i * 64, g, wf[0]);
+  frag64(w + (16 + i) * 64, g, wf[1]);
+  kv_frags(kv, i, g, ak, akT);
+  wt_frags(w, i, g, wT);
+  const f32x4 ksum0 = ld4(kv + 64 * PM + 4 * g), ksum1 = ld4(kv + 64 * PM + 16 + 4 * g);
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float dks[2][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dks[0][r] = dks[1][r] = 0.f;
+  const int tile_end = (sp + 1) * tps < ntile ? (sp + 1) * tps : ntile;
+  for (int tile = sp * tps; tile < tile_end; ++tile) {
+    const int t0 = tile * PT, tok = t0 + 16 * wv + i;
+    const bool live = tok < T;
+    float xq[16];
+    f32x4 dy[4];
+    if (live) {
+      frag64(kqv + ((int64_t)b * T + tok) * 192 + 64, g, xq);
+#pragma unroll
+      for (int et = 0; et < 4; ++et) dy[et] = Ld4<TG>::ld(datt + ((int64_t)b * T + tok) * 64 + 16 * et + 4 * g);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xq[e] = 0.f;
+#pragma unroll
+      for (int et = 0; et < 4; ++et) dy[et] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float p[2][4];
+    prm_t(wf, xq, p);
+    if (!live) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[0][r] = p[1][r] = 0.f;
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) den += p[0][r] * ksum0[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) den += p[1][r] * ksum1[r];
+    den += __shfl_xor(den, 16, 64);
+    den += __shfl_xor(den, 32, 64);
+    den += 1e-8f;
+    float dot = 0.f;                                   // sum_n dy num
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c = mfma4(ak[et][ft][r], p[ft][r], c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dot += dy[et][r] * c[r]; dy[et][r] = dy[et][r] / den; }       // dy becomes dnum
+    }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    const float dden = -dot / (den * den);
+    __syncthreads();                                   // the column reads of the tile before are done
+#pragma unroll
+    for (int et = 0; et < 4; ++et) *reinterpret_cast<f32x4*>(&sdn[16 * wv + i][16 * et + 4 * g]) = dy[et];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      *reinterpret_cast<f32x4*>(&sqp[16 * wv + i][16 * ft + 4 * g]) = f32x4{p[ft][0], p[ft][1], p[ft][2], p[ft][3]};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dks[ft][r] += dden * p[ft][r];
+    }
+    float gq[2][4];                                    // g = dqp * qp,  dqp^T[m][token] = sum_n kptv[n][m] dnum[token][n] + dden ksum[m]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int et = 0; et < 4; ++et)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c = mfma4(akT[mt][4 * et + r], dy[et][r], c);
+      const f32x4 ksm = mt == 0 ? ksum0 : ksum1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gq[mt][r] = (c[r] + dden * ksm[r]) * p[mt][r];
+    }
+    f32x4 dq[4];
+    prm_bwd_t(wT, gq, xq, dq);
+    rows_out<TG>(so, wv, i, g, dq, dkqv + (int64_t)b * T * 192 + 64, 192, t0, T);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {                     // dkptv[n][m] += sum_t dnum[t][n] qp[t][m], tokens 4 s + g; wave w: rows n = 16 w ..
+      const float a = sdn[4 * s + g][16 * wv + i];
+      acc[0] = mfma4(a, sqp[4 * s + g][i], acc[0]);
+      acc[1] = mfma4(a, sqp[4 * s + g][16 + i], acc[1]);
+    }
+  }
+  float* o = part + (int64_t)blockIdx.x * PKV;
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[(16 * wv + 4 * g + r) * PM + 16 * ft + i] = acc[ft][r];
+      float v = dks[ft][r];
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) v += __shfl_xor(v, x, 64);
+      if (i == 0) sred[wv][16 * ft + 4 * g + r] = v;
+    }
+  __syncthreads();
+  if (tid < PM) o[64 * PM + tid] = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+}
+
+// k / v side: a workgroup walks `tps` consecutive 64-token tiles of one image (the operand fragments are loaded once)
+template <typename TG>
+__global__ __launch_bounds__(256) void k_performer_bwd_k_mfma(const float* kqv, const float* w, const float* dkptv, const TG* dskip, TG* dkqv, int T, int S, int tps) {
+  __shared__ __attribute__((aligned(16))) float so[PT][S64];
+  const int tid = threadIdx.x, b = blockIdx.x / S, sp = blockIdx.x % S;
+  const int ntile = (T + PT - 1) / PT;
+  const int lane = tid & 63, wv = tid >> 6, i = lane & 15, g = lane >> 4;
+  const float* dk_ = dkptv + (int64_t)b * PKV;
+  float wf[2][16], adT[2][16], wT[4][8];
+  f32x4 ad[4][2];
+  frag64(w + i * 64, g, wf[0]);
+  frag64(w + (16 + i) * 64, g, wf[1]);
+  kv_frags(dk_, i, g, ad, adT);
+  wt_frags(w, i, g, wT);
+  const f32x4 dks0 = ld4(dk_ + 64 * PM + 4 * g), dks1 = ld4(dk_ + 64 * PM + 16 + 4 * g);
+  const int tile_end = (sp + 1) * tps < ntile ? (sp + 1) * tps : ntile;
+  for (int tile = sp * tps; tile < tile_end; ++tile) {
+    const int t0 = tile * PT, tok = t0 + 16 * wv + i;
+    const bool live = tok < T;
+    const int64_t row = (int64_t)b * T + tok;
+    float xk[16], xv[16];
+    f32x4 dsk[4];
+    if (live) {
+      frag64(kqv + row * 192, g, xk);
+      frag64(kqv + row * 192 + 128, g, xv);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xk[e] = xv[e] = 0.f;
+    }
+#pragma unroll
+    for (int et = 0; et < 4; ++et) dsk[et] = (live && dskip) ? Ld4<TG>::ld(dskip + row * 64 + 16 * et + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float p[2][4];
+    prm_t(wf, xk, p);
+    f32x4 dv[4];                                       // dv^T[n][token] = sum_m dkptv[n][m] kp[token][m] (+ skip gradient)
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c = mfma4(ad[et][ft][r], p[ft][r], c);
+      dv[et] = c + dsk[et];
+    }
+    rows_out<TG>(so, wv, i, g, dv, dkqv + (int64_t)b * T * 192 + 128, 192, t0, T);
+    float gk[2][4];                                    // g = dkp * kp,  dkp^T[m][token] = sum_n dkptv[n][m] v[token][n] + dksum[m]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) c = mfma4(adT[mt][s], xv[s], c);
+      const f32x4 dsm = mt == 0 ? dks0 : dks1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gk[mt][r] = (c[r] + dsm[r]) * p[mt][r];
+    }
+    f32x4 dk[4];
+    prm_bwd_t(wT, gk, xk, dk);
+    rows_out<TG>(so, wv, i, g, dk, dkqv + (int64_t)b * T * 192, 192, t0, T);
   }
 }
 
@@ -653,12 +770,12 @@ extern "C" int uvc_performer_fwd(const uvc_performer_args* p, void* stream) {
   if (!p->att) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_performer_fwd: null att");
   hipStream_t st = (hipStream_t)stream;
   const int ntile = (p->T + PT - 1) / PT, S = splits_of(p->B, p->T), tps = PTPS;
-  k_performer_kv<<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->part, p->T, S, tps);
+  k_performer_kv_mfma<<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->part, p->T, S, tps);
   UVC_CHECK_LAUNCH();
   k_part_reduce<<<dim3(ceil_div(PKV, 256), p->B), 256, 0, st>>>(p->part, p->kptv, S);
   UVC_CHECK_LAUNCH();
-  if (p->att_is_f32 || p->dtype == UVC_F32) k_performer_q<float><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->kptv, (float*)p->att, p->T, ntile);
-  else k_performer_q<bf16_t><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->kptv, (bf16_t*)p->att, p->T, ntile);
+  if (p->att_is_f32 || p->dtype == UVC_F32) k_performer_q_mfma<float><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->kptv, (float*)p->att, p->T, ntile);
+  else k_performer_q_mfma<bf16_t><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->kptv, (bf16_t*)p->att, p->T, ntile);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }
@@ -669,13 +786,13 @@ extern "C" int uvc_performer_bwd(const uvc_performer_args* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int ntile = (p->T + PT - 1) / PT, S = splits_of(p->B, p->T), tps = PTPS;
   const bool f32 = p->g_is_f32 || p->dtype == UVC_F32;
-  if (f32) k_performer_bwd_q<float><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->kptv, (const float*)p->datt, (float*)p->dkqv, p->part, p->T, S, tps);
-  else k_performer_bwd_q<bf16_t><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->kptv, (const bf16_t*)p->datt, (bf16_t*)p->dkqv, p->part, p->T, S, tps);
+  if (f32) k_performer_bwd_q_mfma<float><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->kptv, (const float*)p->datt, (float*)p->dkqv, p->part, p->T, S, tps);
+  else k_performer_bwd_q_mfma<bf16_t><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->kptv, (const bf16_t*)p->datt, (bf16_t*)p->dkqv, p->part, p->T, S, tps);
   UVC_CHECK_LAUNCH();
   k_part_reduce<<<dim3(ceil_div(PKV, 256), p->B), 256, 0, st>>>(p->part, p->dkptv, S);
   UVC_CHECK_LAUNCH();
-  if (f32) k_performer_bwd_k<float><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->dkptv, (const float*)p->dskip, (float*)p->dkqv, p->T, ntile);
-  else k_performer_bwd_k<bf16_t><<<p->B * ntile, 256, 0, st>>>(p->kqv, p->w, p->dkptv, (const bf16_t*)p->dskip, (bf16_t*)p->dkqv, p->T, ntile);
+  if (f32) k_performer_bwd_k_mfma<float><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->dkptv, (const float*)p->dskip, (float*)p->dkqv, p->T, S, tps);
+  else k_performer_bwd_k_mfma<bf16_t><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->dkptv, (const bf16_t*)p->dskip, (bf16_t*)p->dkqv, p->T, S, tps);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

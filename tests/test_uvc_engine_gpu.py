@@ -165,7 +165,7 @@ def test_warmup_returns_early():
     g_cpu = torch.tensor([-1.0, 1.0]).expand(2, 2).contiguous().clone()
     cur_o = OU.uvc_update(st, hp, W1c, W3c, 1e-3, g_cpu, None, e1, None, 1, 1)
     assert abs(float(cur) - cur_o) < 1e-5
-    assert torch.equal(mm._flat, before)           # no primal/dual update in warm-up
+    assert torch.equal(mm._flat[:-4], before[:-4])   # no primal/dual update in warm-up (the last four floats are the step's report: resource ...)
     assert torch.equal(model.blocks[0].attn.proj.weight.data.cpu(), W1c[0])   # but prox ran (:42)
 
 

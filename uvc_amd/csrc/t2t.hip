@@ -38,31 +38,62 @@ __device__ __forceinline__ LaneTaps<NV> lane_taps(const UG& g, int lane) {
   }
   return t;
 }
-template <int NV, bool CF>
-__device__ __forceinline__ void gather_row(const UG& g, const LaneTaps<NV>& tp, int b, int ho, int wo, bool valid, int lane, float* lrow, float (&v)[NV]) {
-  const int h0 = ho * g.s - g.p, w0 = wo * g.s - g.p;
+// U rows per wave at a time, every load of the U rows issued before the first use (r4): a wave that gathers one row per trip pays a memory round trip per
+// row (3 loads in flight on the generic path; on the token-major path the runtime tap loop wrote each tap to LDS as it arrived: nine round trips).  In the
+// T2T-ViT-14 step: LayerNorm backward of stage 2 273 -> 199 us, the forwards 139 -> 126 and 65 -> 60 us; the image split (scattered 28-byte pieces per
+// lane group) stays 2.5x off its bytes.  Token-major sources have k*k <= 9 taps (C = 64, dim <= 576).
+struct TapTable { int ki[9], kj[9]; };
+__device__ __forceinline__ TapTable tap_table(const UG& g) {
+  TapTable t;
+  int ki = 0, kj = 0;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { t.ki[j] = ki; t.kj[j] = kj; if (++kj == g.k) { kj = 0; ++ki; } }
+  return t;
+}
+struct RowId { int b, ho, wo, row; bool valid; };
+__device__ __forceinline__ RowId row_id(const UG& g, int row) {
+  RowId r;
+  r.row = row; r.valid = row < g.rows;
+  const int rr = r.valid ? row : 0;
+  const int bh = rr / g.Wo;
+  r.wo = rr - bh * g.Wo; r.b = bh / g.Ho; r.ho = bh - r.b * g.Ho;
+  return r;
+}
+template <int NV, bool CF, int U>
+__device__ __forceinline__ void gather_rows(const UG& g, const LaneTaps<NV>& tp, const TapTable& tt, const RowId (&id)[U], int lane, float (*lrow)[NV * 64], float (&v)[U][NV]) {
   if (CF) {
-    const float* sb = g.src + (int64_t)b * g.sb + lane;
-    int ki = 0, kj = 0;
-    for (int j = 0; j < g.kk; ++j) {
-      const int hi = h0 + ki, wi = w0 + kj;
-      float x = 0.f;
-      if (valid && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) x = sb[(int64_t)hi * g.sh + (int64_t)wi * g.sw];
-      lrow[lane * g.kk + j] = x;
-      if (++kj == g.k) { kj = 0; ++ki; }
+    float x[U][9];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int h0 = id[u].ho * g.s - g.p, w0 = id[u].wo * g.s - g.p;
+      const float* sb = g.src + (int64_t)id[u].b * g.sb + lane;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int hi = h0 + tt.ki[j], wi = w0 + tt.kj[j];
+        x[u][j] = (id[u].valid && j < g.kk && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? sb[(int64_t)hi * g.sh + (int64_t)wi * g.sw] : 0.f;
+      }
     }
-    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = (lane + 64 * j < g.dim) ? lrow[lane + 64 * j] : 0.f;
-    __syncthreads();
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+        if (j < g.kk) lrow[u][lane * g.kk + j] = x[u][j];
+    __builtin_amdgcn_wave_barrier();                 // the rows are the wave's own; DS operations of one wave execute in order
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[u][j] = (lane + 64 * j < g.dim) ? lrow[u][lane + 64 * j] : 0.f;
+    __builtin_amdgcn_wave_barrier();
   } else {
-    const float* sb = g.src + (int64_t)b * g.sb + (int64_t)h0 * g.sh + (int64_t)w0 * g.sw;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int hi = h0 + tp.ki[j], wi = w0 + tp.kj[j];
-      float x = 0.f;
-      if (valid && tp.off[j] >= 0 && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) x = sb[tp.off[j]];
-      v[j] = x;
+    for (int u = 0; u < U; ++u) {
+      const int h0 = id[u].ho * g.s - g.p, w0 = id[u].wo * g.s - g.p;
+      const float* sb = g.src + (int64_t)id[u].b * g.sb + (int64_t)h0 * g.sh + (int64_t)w0 * g.sw;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int hi = h0 + tp.ki[j], wi = w0 + tp.kj[j];
+        v[u][j] = (id[u].valid && tp.off[j] >= 0 && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? sb[tp.off[j]] : 0.f;
+      }
     }
   }
 }
@@ -95,10 +126,12 @@ __device__ __forceinline__ void store_row(float* lrow, const float (&v)[NV], TO*
 
 template <typename TO, int NV, bool CF>
 __global__ __launch_bounds__(256) void k_unfold_ln(UG g) {
-  __shared__ __attribute__((aligned(16))) float lds[4][NV * 64];
+  constexpr int U = NV <= 3 ? 4 : 2;                  // rows per wave and trip
+  __shared__ __attribute__((aligned(16))) float lds[4][U][NV * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   LaneTaps<NV> tp;
   if (!CF) tp = lane_taps<NV>(g, lane);
+  const TapTable tt = tap_table(g);
   float gam[NV], bet[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -106,28 +139,28 @@ __global__ __launch_bounds__(256) void k_unfold_ln(UG g) {
     gam[j] = (g.gamma && e < g.dim) ? g.gamma[e] : 0.f;
     bet[j] = (g.gamma && e < g.dim) ? g.beta[e] : 0.f;
   }
-  for (int bh = blockIdx.x; bh < g.B * g.Ho; bh += gridDim.x) {
-    const int b = bh / g.Ho, ho = bh - b * g.Ho;
-    for (int wo0 = 0; wo0 < g.Wo; wo0 += 4) {
-      const int wo = wo0 + wv;
-      const bool valid = wo < g.Wo;
-      const int row = bh * g.Wo + wo;
-      float v[NV];
-      gather_row<NV, CF>(g, tp, b, ho, wo, valid, lane, lds[wv], v);
+  for (int row0 = blockIdx.x * 4 * U; row0 < g.rows; row0 += gridDim.x * 4 * U) {
+    RowId id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) id[u] = row_id(g, row0 + 4 * u + wv);
+    float v[U][NV];
+    gather_rows<NV, CF, U>(g, tp, tt, id, lane, lds[wv], v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
       if (g.gamma) {
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) s += v[j];
+        for (int j = 0; j < NV; ++j) s += v[u][j];
         const float mean = wave_sum(s) / (float)g.dim;
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { const float d = (lane + 64 * j < g.dim) ? v[j] - mean : 0.f; q += d * d; }
+        for (int j = 0; j < NV; ++j) { const float d = (lane + 64 * j < g.dim) ? v[u][j] - mean : 0.f; q += d * d; }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.dim + g.eps);
-        if (valid && lane == 0) { g.mean[row] = mean; g.rstd[row] = rstd; }
+        if (id[u].valid && lane == 0) { g.mean[id[u].row] = mean; g.rstd[id[u].row] = rstd; }
 #pragma unroll
-        for (int j = 0; j < NV; ++j) v[j] = (lane + 64 * j < g.dim) ? (v[j] - mean) * rstd * gam[j] + bet[j] : 0.f;
+        for (int j = 0; j < NV; ++j) v[u][j] = (lane + 64 * j < g.dim) ? (v[u][j] - mean) * rstd * gam[j] + bet[j] : 0.f;
       }
-      store_row<TO, NV>(lds[wv], v, (TO*)g.out + (int64_t)(valid ? row : 0) * g.ldo, g.ldo, lane, valid);
+      store_row<TO, NV>(lds[wv][u], v[u], (TO*)g.out + (int64_t)(id[u].valid ? id[u].row : 0) * g.ldo, g.ldo, lane, id[u].valid);
     }
   }
 }
@@ -136,7 +169,8 @@ __global__ __launch_bounds__(256) void k_unfold_ln(UG g) {
 // per-workgroup partial sums of dgamma / dbeta in `partial` ([gridDim.x][2*dim]).
 template <typename TDY, int NV, bool CF>
 __global__ __launch_bounds__(256) void k_unfold_ln_bwd(UG g) {
-  __shared__ __attribute__((aligned(16))) float lds[4][NV * 64];
+  constexpr int U = NV <= 3 ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) float lds[4][U][NV * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float dgm[NV], dbt[NV], gam[NV];
 #pragma unroll
@@ -144,37 +178,44 @@ __global__ __launch_bounds__(256) void k_unfold_ln_bwd(UG g) {
   const float inv = 1.0f / (float)g.dim;
   LaneTaps<NV> tp;
   if (!CF) tp = lane_taps<NV>(g, lane);
-  for (int bh = blockIdx.x; bh < g.B * g.Ho; bh += gridDim.x) {
-    const int b = bh / g.Ho, ho = bh - b * g.Ho;
-    for (int wo0 = 0; wo0 < g.Wo; wo0 += 4) {
-      const int wo = wo0 + wv;
-      const bool valid = wo < g.Wo;
-      const int row = bh * g.Wo + wo;
-      float v[NV];
-      gather_row<NV, CF>(g, tp, b, ho, wo, valid, lane, lds[wv], v);
-      const float mean = valid ? g.mean[row] : 0.f, rstd = valid ? g.rstd[row] : 0.f;
-      const TDY* dyr = (const TDY*)g.dy + (int64_t)(valid ? row : 0) * g.ldo;
+  const TapTable tt = tap_table(g);
+  for (int row0 = blockIdx.x * 4 * U; row0 < g.rows; row0 += gridDim.x * 4 * U) {
+    RowId id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) id[u] = row_id(g, row0 + 4 * u + wv);
+    float v[U][NV], dyv[U][NV], mean[U], rstd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                     // the gradient rows and the row statistics travel with the gathers
+      const TDY* dyr = (const TDY*)g.dy + (int64_t)(id[u].valid ? id[u].row : 0) * g.ldo;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) dyv[u][j] = (id[u].valid && lane + 64 * j < g.dim) ? ElemIO<TDY>::load(dyr + lane + 64 * j) : 0.f;
+      mean[u] = id[u].valid ? g.mean[id[u].row] : 0.f;
+      rstd[u] = id[u].valid ? g.rstd[id[u].row] : 0.f;
+    }
+    gather_rows<NV, CF, U>(g, tp, tt, id, lane, lds[wv], v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
       float gy[NV], s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int e = lane + 64 * j;
-        const float dy = (valid && e < g.dim) ? ElemIO<TDY>::load(dyr + e) : 0.f;
-        v[j] = (e < g.dim) ? (v[j] - mean) * rstd : 0.f;          // xhat
-        dgm[j] += dy * v[j];
+        const float dy = dyv[u][j];
+        v[u][j] = (e < g.dim) ? (v[u][j] - mean[u]) * rstd[u] : 0.f;          // xhat
+        dgm[j] += dy * v[u][j];
         dbt[j] += dy;
         gy[j] = dy * gam[j];
         s1 += gy[j];
-        s2 += gy[j] * v[j];
+        s2 += gy[j] * v[u][j];
       }
       if (g.dxu) {
         s1 = wave_sum(s1) * inv;
         s2 = wave_sum(s2) * inv;
-        if (valid) {
-          float* o = g.dxu + (int64_t)row * g.dim;
+        if (id[u].valid) {
+          float* o = g.dxu + (int64_t)id[u].row * g.dim;
 #pragma unroll
           for (int j = 0; j < NV; ++j) {
             const int e = lane + 64 * j;
-            if (e < g.dim) o[e] = rstd * (gy[j] - s1 - v[j] * s2);
+            if (e < g.dim) o[e] = rstd[u] * (gy[j] - s1 - v[u][j] * s2);
           }
         }
       }
@@ -185,14 +226,14 @@ __global__ __launch_bounds__(256) void k_unfold_ln_bwd(UG g) {
   for (int pass = 0; pass < 2; ++pass) {
     if (wv > 0) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) lds[wv][lane + 64 * j] = pass == 0 ? dgm[j] : dbt[j];
+      for (int j = 0; j < NV; ++j) lds[wv][0][lane + 64 * j] = pass == 0 ? dgm[j] : dbt[j];
     }
     __syncthreads();
     if (wv == 0) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int e = lane + 64 * j;
-        const float t = (pass == 0 ? dgm[j] : dbt[j]) + lds[1][e] + lds[2][e] + lds[3][e];
+        const float t = (pass == 0 ? dgm[j] : dbt[j]) + lds[1][0][e] + lds[2][0][e] + lds[3][0][e];
         if (e < g.dim) g.partial[(int64_t)blockIdx.x * 2 * g.dim + pass * g.dim + e] = t;
       }
     }
@@ -715,7 +756,7 @@ extern "C" int uvc_unfold_ln_fwd(const uvc_unfold_args* a, void* stream) {
   if (!a->out || (a->gamma && (!a->beta || !a->mean || !a->rstd))) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold_ln_fwd: null pointer");
   if (g.ldo % 8) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold_ln_fwd: ldo must be a multiple of 8 (16-byte row stores)");
   hipStream_t st = (hipStream_t)stream;
-  int grid = g.B * g.Ho;
+  int grid = (g.rows + 7) / 8;                         // (8 or 16 rows per workgroup and trip)
   if (grid > 16384) grid = 16384;
   const bool f32 = a->out_is_f32 || a->dtype == UVC_F32;
   const int nv = (g.dim + 63) / 64;
@@ -732,8 +773,7 @@ extern "C" int uvc_unfold_ln_bwd(const uvc_unfold_args* a, void* stream) {
   if (int e = fill_geom(a, g)) return e;
   if (!a->gamma || !a->mean || !a->rstd || !a->dy || !a->partial || !a->dgamma || !a->dbeta) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold_ln_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  int grid = g.B * g.Ho;
-  if (grid > bwd_grid(g.rows)) grid = bwd_grid(g.rows);
+  int grid = bwd_grid(g.rows);
   const bool f32 = a->dy_is_f32 || a->dtype == UVC_F32;
   const int nv = (g.dim + 63) / 64;
 #define UB_LAUNCH(NVV, CFF) do { if (f32) k_unfold_ln_bwd<float, NVV, CFF><<<grid, 256, 0, st>>>(g); else k_unfold_ln_bwd<bf16_t, NVV, CFF><<<grid, 256, 0, st>>>(g); } while (0)

@@ -29,9 +29,12 @@ typedef struct uvc_unfold_args {
   void* out; float* mean; float* rstd;  /* mean / rstd [B*L] (LayerNorm only) */
   /* backward (uvc_unfold_ln_bwd): dY [B*L, ldo] is the gradient wrt `out` */
   const void* dy; int32_t dy_is_f32;
-  float* dxu;                            /* [B*L, dim] float32 gradient wrt the unfolded row, or NULL when the source needs none */
+  float* dxu;                            /* [B*L, dim] float32 gradient wrt the unfolded row, or NULL when the source needs none.  Column order: natural
+                                          * (c*k*k + ki*k + kj), or tap-major ((ki*k + kj)*C + c) when dxu_tap_major (last field) is set */
   float* partial;                        /* scratch [uvc_unfold_bwd_blocks() * 2 * dim] */
   float* dgamma; float* dbeta; float beta_acc;   /* written as beta_acc*old + sum */
+  int32_t dxu_tap_major;                 /* token-major sources (sc == 1, C == 64) only: dxu leaves as [B*L][k*k][C], which uvc_fold_tokens(tap_major = 1) reads as
+                                          * whole 256-byte channel rows (one wave per pixel, the channel on the lane) */
 } uvc_unfold_args;
 int uvc_unfold_ln_fwd(const uvc_unfold_args* args, void* stream);
 int uvc_unfold_ln_bwd(const uvc_unfold_args* args, void* stream);
@@ -39,9 +42,10 @@ int uvc_unfold_bwd_blocks(int32_t rows);
 
 /* Fold = adjoint of the soft split onto a token-major map: dst[b, h*W + w, c] = sum over the windows (ho, wo) and taps
  * (ki, kj) that cover (h, w) of src[b*L + ho*Wo + wo, c*k*k + ki*k + kj].  A gather (deterministic, no atomics).
- * src is float32 or T (`src_is_f32`), rows `lds` apart; dst [B, H*W, C] is float32 or T (`dst_is_f32`; sums in float32). */
+ * src is float32 or T (`src_is_f32`), rows `lds` apart; dst [B, H*W, C] is float32 or T (`dst_is_f32`; sums in float32).
+ * tap_major: the columns of src are ordered (ki*k + kj)*C + c (uvc_unfold_args.dxu_tap_major) instead of c*k*k + ki*k + kj. */
 int uvc_fold_tokens(const void* src, int32_t src_is_f32, int32_t dtype, int32_t lds, void* dst, int32_t dst_is_f32, int32_t B, int32_t C, int32_t H,
-                    int32_t W, int32_t k, int32_t s, int32_t p, void* stream);
+                    int32_t W, int32_t k, int32_t s, int32_t p, int32_t tap_major, void* stream);
 
 /* Performer linear attention (token_performer.py:31-62) for emb = 64, m = 32 random features.
  * kqv [B*T, 192] float32 = Linear(norm1(x)) split as k | q | v (:46); w [32, 64] float32 (the fixed random features).

@@ -109,6 +109,14 @@ def test_unfold_ln_bwd_and_fold(case, dtype):
         ops.fold_tokens(dxu, dst, B, C, H, W, k, s, p, dtype)
         ref = xr.grad.permute(0, 2, 3, 1).reshape(B, H * W, C)
         np.testing.assert_allclose(dst.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-5)
+        if C == 64:                                                  # tap-major dxu ([rows][k*k][C]) is the same numbers re-ordered, and folds to the same map
+            dxt = torch.empty(rows, dim, device="cuda")
+            ops.unfold_ln_bwd(srcd, strides, B, C, H, W, k, s, p, dyp, dtype, gamma=g_, mean=mean, rstd=rstd, partial=partial, dgamma=dgamma, dbeta=dbeta, dxu=dxt,
+                              dxu_tap_major=True)
+            assert torch.equal(dxt.view(rows, k * k, C), dxu.view(rows, C, k * k).transpose(1, 2))
+            dst2 = torch.empty(B, H * W, C, device="cuda")
+            ops.fold_tokens(dxt, dst2, B, C, H, W, k, s, p, dtype, tap_major=True)
+            assert torch.equal(dst2, dst)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])

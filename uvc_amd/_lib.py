@@ -105,7 +105,7 @@ class uvc_unfold_args(C.Structure):          # include/uvc_t2t.h
                [(n, C.c_int32) for n in ("B", "C", "H", "W", "k", "s", "p", "ldo", "out_is_f32", "dtype")] + \
                [("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("out", C.c_void_p), ("mean", C.c_void_p),
                 ("rstd", C.c_void_p), ("dy", C.c_void_p), ("dy_is_f32", C.c_int32), ("dxu", C.c_void_p), ("partial", C.c_void_p),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("beta_acc", C.c_float)]
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("beta_acc", C.c_float), ("dxu_tap_major", C.c_int32)]
 
 
 class uvc_performer_args(C.Structure):
@@ -179,7 +179,7 @@ _SIGNATURES = {
     "uvc_unfold_ln_fwd": [C.POINTER(uvc_unfold_args), VP],
     "uvc_unfold_ln_bwd": [C.POINTER(uvc_unfold_args), VP],
     "uvc_unfold_bwd_blocks": [I32],
-    "uvc_fold_tokens": [VP, I32, I32, I32, VP, I32, I32, I32, I32, I32, I32, I32, I32, VP],
+    "uvc_fold_tokens": [VP, I32, I32, I32, VP, I32, I32, I32, I32, I32, I32, I32, I32, I32, VP],
     "uvc_performer_splits": [I32, I32],
     "uvc_performer_fwd": [C.POINTER(uvc_performer_args), VP],
     "uvc_performer_bwd": [C.POINTER(uvc_performer_args), VP],

@@ -16,7 +16,7 @@ struct UG {                       // unfold geometry + pointers, passed by value
   int B, C, H, W, k, s, p, Ho, Wo, L, kk, dim, ldo, rows, c_fast;
   const float* gamma; const float* beta; float eps;
   void* out; float* mean; float* rstd;
-  const void* dy; float* dxu; float* partial;
+  const void* dy; float* dxu; float* partial; int dxu_tm;
 };
 
 // One wave gathers one unfolded row into registers in natural feature order e = lane + 64*j (e = c*kk + ki*k + kj).
@@ -210,8 +210,16 @@ __global__ __launch_bounds__(256) void k_unfold_ln_bwd(UG g) {
       if (g.dxu) {
         s1 = wave_sum(s1) * inv;
         s2 = wave_sum(s2) * inv;
-        if (id[u].valid) {
-          float* o = g.dxu + (int64_t)id[u].row * g.dim;
+        float* o = g.dxu + (int64_t)(id[u].valid ? id[u].row : 0) * g.dim;
+        if (CF && g.dxu_tm) {                         // tap-major: [k*k][64 channels], the channel on the lane (the fold reads whole channel rows)
+#pragma unroll
+          for (int j = 0; j < NV; ++j) lds[wv][u][lane + 64 * j] = rstd[u] * (gy[j] - s1 - v[u][j] * s2);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+            if (t < g.kk && id[u].valid) o[t * 64 + lane] = lds[wv][u][lane * g.kk + t];
+          __builtin_amdgcn_wave_barrier();
+        } else if (id[u].valid) {
 #pragma unroll
           for (int j = 0; j < NV; ++j) {
             const int e = lane + 64 * j;
@@ -285,6 +293,53 @@ __global__ void k_fold(const TS* src, int lds, TD* dst, int B, int C, int H, int
   ElemIO<TD>::store(dst + idx, acc);
 }
 
+// Tap-major source ([rows][k*k][64 channels], uvc_unfold_args.dxu_tap_major): a wave takes PPW consecutive output pixels, the channel on the lane -- every
+// tap is one 256-byte row and the pixel arithmetic is wave-uniform (scalar unit).  KK / SS / PP > 0: the taps are compile-time, so the loads of all PPW pixels are
+// issued before the first sum (a wave with one pixel's 1-4 loads in flight was latency-bound: 222 us for 282 MB at stage 2 of T2T-ViT-14; the element-per-thread
+// kernel above 199 us in either column order).
+template <typename TS, typename TD, int KK, int SS, int PP, int PPW>
+__global__ __launch_bounds__(256) void k_fold_tm(const TS* src, int lds, TD* dst, int B, int H, int W, int k_, int s_, int p_, int Ho, int Wo) {
+  const int k = KK > 0 ? KK : k_, s = KK > 0 ? SS : s_, p = KK > 0 ? PP : p_;
+  const int lane = threadIdx.x & 63;
+  const int pix0 = ((int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * PPW;
+  const int npix = B * H * W;
+  float acc[PPW];
+#pragma unroll
+  for (int u = 0; u < PPW; ++u) {
+    acc[u] = 0.f;
+    const int pix = pix0 + u;
+    if (pix >= npix) continue;
+    const int b = pix / (H * W), hw = pix - b * H * W, h = hw / W, w = hw - h * W;
+    const TS* sb = src + (int64_t)b * Ho * Wo * lds + lane;
+    if (KK > 0) {
+#pragma unroll
+      for (int ki = 0; ki < (KK > 0 ? KK : 1); ++ki) {
+        const int hh = h + p - ki, ho = hh / s;
+        if (hh < 0 || hh % s || ho >= Ho) continue;
+#pragma unroll
+        for (int kj = 0; kj < (KK > 0 ? KK : 1); ++kj) {
+          const int ww = w + p - kj, wo = ww / s;
+          if (ww < 0 || ww % s || wo >= Wo) continue;
+          acc[u] += ElemIO<TS>::load(sb + (int64_t)(ho * Wo + wo) * lds + (ki * k + kj) * 64);
+        }
+      }
+    } else {
+      for (int ki = 0; ki < k; ++ki) {
+        const int hh = h + p - ki, ho = hh / s;
+        if (hh < 0 || hh % s || ho >= Ho) continue;
+        for (int kj = 0; kj < k; ++kj) {
+          const int ww = w + p - kj, wo = ww / s;
+          if (ww < 0 || ww % s || wo >= Wo) continue;
+          acc[u] += ElemIO<TS>::load(sb + (int64_t)(ho * Wo + wo) * lds + (ki * k + kj) * 64);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PPW; ++u)
+    if (pix0 + u < npix) ElemIO<TD>::store(dst + (int64_t)(pix0 + u) * 64 + lane, acc[u]);
+}
+
 int fill_geom(const uvc_unfold_args* a, UG& g) {
   if (!a || !a->src) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold: null pointer");
   if (a->B <= 0 || a->C <= 0 || a->k <= 0 || a->s <= 0 || a->p < 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold: geometry");
@@ -294,7 +349,8 @@ int fill_geom(const uvc_unfold_args* a, UG& g) {
   g.L = g.Ho * g.Wo; g.kk = a->k * a->k; g.dim = a->C * g.kk; g.ldo = a->ldo; g.rows = a->B * g.L;
   g.c_fast = (a->sc == 1 && a->C == 64) ? 1 : 0;
   g.gamma = a->gamma; g.beta = a->beta; g.eps = a->eps; g.out = a->out; g.mean = a->mean; g.rstd = a->rstd;
-  g.dy = a->dy; g.dxu = a->dxu; g.partial = a->partial;
+  g.dy = a->dy; g.dxu = a->dxu; g.partial = a->partial; g.dxu_tm = a->dxu_tap_major;
+  if (g.dxu_tm && !g.c_fast) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_unfold: dxu_tap_major needs a token-major source (sc == 1, C == 64)");
   if (g.Ho <= 0 || g.Wo <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_unfold: empty output");
   if (g.dim > 576 || g.ldo < g.dim || g.ldo > ((g.dim + 63) / 64) * 64) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_unfold: need C*k*k <= 576 and dim <= ldo <= roundup(dim, 64)");
   return UVC_OK;
@@ -787,7 +843,7 @@ extern "C" int uvc_unfold_ln_bwd(const uvc_unfold_args* a, void* stream) {
 }
 
 extern "C" int uvc_fold_tokens(const void* src, int32_t src_is_f32, int32_t dtype, int32_t lds, void* dst, int32_t dst_is_f32, int32_t B, int32_t C, int32_t H,
-                               int32_t W, int32_t k, int32_t s, int32_t p, void* stream) {
+                               int32_t W, int32_t k, int32_t s, int32_t p, int32_t tap_major, void* stream) {
   if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || s <= 0 || p < 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_fold_tokens: arguments");
   const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
   if (Ho <= 0 || Wo <= 0 || lds < C * k * k) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_fold_tokens: geometry");
@@ -795,7 +851,19 @@ extern "C" int uvc_fold_tokens(const void* src, int32_t src_is_f32, int32_t dtyp
   const int grid = (int)((total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
   const bool sf = src_is_f32 || dtype == UVC_F32, df = dst_is_f32 || dtype == UVC_F32;
-  if (sf && df) k_fold<float, float><<<grid, 256, 0, st>>>((const float*)src, lds, (float*)dst, B, C, H, W, k, s, p, Ho, Wo);
+  if (tap_major) {
+    if (C != 64) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_fold_tokens: tap_major needs C == 64");
+    constexpr int PPW = 8;
+    const int gp = (B * H * W + 4 * PPW - 1) / (4 * PPW);
+#define FOLD_TM(TS_, TD_) do { \
+      if (k == 3 && s == 2 && p == 1) k_fold_tm<TS_, TD_, 3, 2, 1, PPW><<<gp, 256, 0, st>>>((const TS_*)src, lds, (TD_*)dst, B, H, W, k, s, p, Ho, Wo); \
+      else k_fold_tm<TS_, TD_, 0, 0, 0, PPW><<<gp, 256, 0, st>>>((const TS_*)src, lds, (TD_*)dst, B, H, W, k, s, p, Ho, Wo); } while (0)
+    if (sf && df) FOLD_TM(float, float);
+    else if (sf) FOLD_TM(float, bf16_t);
+    else if (df) FOLD_TM(bf16_t, float);
+    else FOLD_TM(bf16_t, bf16_t);
+#undef FOLD_TM
+  } else if (sf && df) k_fold<float, float><<<grid, 256, 0, st>>>((const float*)src, lds, (float*)dst, B, C, H, W, k, s, p, Ho, Wo);
   else if (sf) k_fold<float, bf16_t><<<grid, 256, 0, st>>>((const float*)src, lds, (bf16_t*)dst, B, C, H, W, k, s, p, Ho, Wo);
   else if (df) k_fold<bf16_t, float><<<grid, 256, 0, st>>>((const bf16_t*)src, lds, (float*)dst, B, C, H, W, k, s, p, Ho, Wo);
   else k_fold<bf16_t, bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, lds, (bf16_t*)dst, B, C, H, W, k, s, p, Ho, Wo);

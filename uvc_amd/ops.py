@@ -364,20 +364,23 @@ def unfold_bwd_blocks(rows) -> int:
     return int(L.lib().uvc_unfold_bwd_blocks(rows))
 
 
-def unfold_ln_bwd(src, strides, B, Cc, H, W, k, s, p, dy, dtype, *, gamma, mean, rstd, partial, dgamma, dbeta, dxu=None, beta_acc=0.0, eps=1e-5):
+def unfold_ln_bwd(src, strides, B, Cc, H, W, k, s, p, dy, dtype, *, gamma, mean, rstd, partial, dgamma, dbeta, dxu=None, beta_acc=0.0, eps=1e-5,
+                  dxu_tap_major=False):
+    """dxu_tap_major (token-major sources with 64 channels): dxu leaves as [rows][k*k][C] for fold_tokens(..., tap_major=True)."""
     _chk(src, dy, gamma, mean, rstd, partial, dgamma, dbeta, dxu)
     a = _unfold_args(src, strides, B, Cc, H, W, k, s, p, dy.shape[1], dtype)
     a.gamma, a.mean, a.rstd, a.eps = L.ptr(gamma), L.ptr(mean), L.ptr(rstd), eps
     a.dy, a.dy_is_f32, a.dxu, a.partial = L.ptr(dy), _is_f32(dy), L.ptr(dxu), L.ptr(partial)
     a.dgamma, a.dbeta, a.beta_acc = L.ptr(dgamma), L.ptr(dbeta), beta_acc
+    a.dxu_tap_major = int(bool(dxu_tap_major))
     L.check(L.lib().uvc_unfold_ln_bwd(C.byref(a), L.cur_stream()), "uvc_unfold_ln_bwd")
 
 
-def fold_tokens(src, dst, B, Cc, H, W, k, s, p, dtype, lds=None):
-    """dst[B, H*W, C] (float32 or T) = adjoint of the soft split applied to src [B*L, lds]."""
+def fold_tokens(src, dst, B, Cc, H, W, k, s, p, dtype, lds=None, tap_major=False):
+    """dst[B, H*W, C] (float32 or T) = adjoint of the soft split applied to src [B*L, lds] (columns c*k*k + tap, or tap*C + c with tap_major)."""
     _chk(src, dst)
     L.check(L.lib().uvc_fold_tokens(L.ptr(src), _is_f32(src), dtype, lds if lds is not None else src.shape[1], L.ptr(dst), _is_f32(dst), B, Cc, H, W,
-                                    k, s, p, L.cur_stream()), "uvc_fold_tokens")
+                                    k, s, p, int(bool(tap_major)), L.cur_stream()), "uvc_fold_tokens")
 
 
 def performer_splits(B, T) -> int:

@@ -408,7 +408,7 @@ class T2T_ViT(DistilledVisionTransformer):
         ops.gemm_nt(b["dkqv"], sh[name + ".kqv"][1], b["dxn"], dtype=dt)
         ops.unfold_ln_bwd(src, strides, B, C_, H, W, k, s, p, b["dxn"], dt, gamma=fp(f["norm1_w"], f["dim"]), mean=b["mean1"], rstd=b["rstd1"],
                           partial=b["ln1_partial"], dgamma=fg(f["norm1_w"], f["dim"]), dbeta=fg(f["norm1_b"], f["dim"]), dxu=b["dxu"] if need_dx else None,
-                          beta_acc=beta, eps=LN_EPS)
+                          beta_acc=beta, eps=LN_EPS, dxu_tap_major=need_dx)     # [rows][9 taps][64]: whole channel rows for the fold below
 
     def _front_end_backward(self, st):
         fs = st["front"]
@@ -427,7 +427,7 @@ class T2T_ViT(DistilledVisionTransformer):
         ops.fold_tokens(bufs["dxu3"], b2["dout"], B, 64, s2, s2, 3, 2, 1, dt)
         tok = lambda side: (side * side * 64, 1, side * 64, 64)
         self._performer_backward("attention2", b1["out"], tok(s1), B, 64, s1, s1, 3, 2, 1, b2, bufs, True)
-        ops.fold_tokens(b2["dxu"], b1["dout"], B, 64, s1, s1, 3, 2, 1, dt)
+        ops.fold_tokens(b2["dxu"], b1["dout"], B, 64, s1, s1, 3, 2, 1, dt, tap_major=True)
         self._performer_backward("attention1", x, (3 * S * S, S * S, S, 1), B, 3, S, S, 7, 4, 2, b1, bufs, False)
 
     def mark_weights_changed(self):

@@ -36,3 +36,21 @@ for tm in (False, True):
     f1()
     print("tap_major=%d  unfold_ln_bwd %7.1f us   fold %7.1f us   (dxu %.0f MB float32 written and read, dy %.0f MB, tokens %.0f + %.0f MB)" %
           (tm, timeit(f1, 20), timeit(f2, 20), rows * dim * 4 / 1e6, rows * dim * 2 / 1e6, src.numel() * 4 / 1e6, dst.numel() * 2 / 1e6))
+
+# the image split (stage 0): 224 x 224 x 3 -> 3136 tokens of 147 (+13 K padding) features
+B, C, H, W, k, s, p = 128, 3, 224, 224, 7, 4, 2
+img = torch.randn(B, C, H, W, device=dev, generator=g)
+strides = (C * H * W, H * W, W, 1)
+Ho, Wo = ops.unfold_out_hw(H, W, k, s, p)
+rows, dim, ldo = B * Ho * Wo, C * k * k, 160
+gamma, beta = torch.ones(dim, device=dev), torch.zeros(dim, device=dev)
+out = torch.empty(rows, ldo, device=dev, dtype=bf)
+mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+f0 = lambda: ops.unfold_ln_fwd(img, strides, B, C, H, W, k, s, p, out, ops.UVC_BF16, gamma=gamma, beta=beta, mean=mean, rstd=rstd)  # noqa: E731
+f0()
+dy = torch.randn(rows, ldo, device=dev, generator=g).to(bf)
+partial = torch.empty(ops.unfold_bwd_blocks(rows) * 2 * dim, device=dev)
+dgamma, dbeta = torch.empty(dim, device=dev), torch.empty(dim, device=dev)
+f1 = lambda: ops.unfold_ln_bwd(img, strides, B, C, H, W, k, s, p, dy, ops.UVC_BF16, gamma=gamma, mean=mean, rstd=rstd, partial=partial, dgamma=dgamma, dbeta=dbeta)  # noqa: E731
+print("image split: forward %7.1f us (%.0f MB)   LayerNorm backward %7.1f us (%.0f MB)" %
+      (timeit(f0, 20), (img.numel() * 4 + out.numel() * 2) / 1e6, timeit(f1, 20), (img.numel() * 4 + dy.numel() * 2) / 1e6))

@@ -5,7 +5,8 @@
 #   (b) fc1 stores ONE tensor instead of GELU(a) and GELU'(a) -> variant "onegelu": the training fc1 writes GELU(a) only, the backward reads the stale
 #       GELU' buffer: same kernels, same reads, one 155-MB write per layer less -- what a one-tensor scheme would gain BEFORE paying for its recomputation
 # Both variants compute wrong numbers on purpose; they are timing probes built from sed-edited COPIES of vit_engine.hip (the product source carries no switch).
-#   here:            tools/bound_probes.sh build   -> tools/perturb/libuvc_hip_{noteacherqkv,onegelu}.so
+#   (c) the weight-gradient partials reduced for free        -> variant "notnreduce": k_tn_reduce never launched
+#   here:            tools/bound_probes.sh build   -> tools/perturb/libuvc_hip_{noteacherqkv,onegelu,notnreduce}.so
 #   on the GPU box:  tools/bound_probes.sh run     -> gpurun_out/bound_probes.txt  (alternating same-box A/B through tools/exp_ab.sh)
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -15,6 +16,13 @@ if [ "${1:-}" = build ]; then
   mkdir -p /tmp/perturb "$R/tools/perturb"
   sed 's|^    TRY(nt(c, b.h1, 0, wmat(c, q\[2\], c.soff.blk_w\[l\]\[0\]), b.qkv, 0, d.M, 3 \* d.D, d.D,|    if (io->training) TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D,|' "$R/uvc_amd/csrc/vit_engine.hip" > /tmp/perturb/vit_noteacherqkv.hip
   sed 's|TRY(nt(c, h2, 0, w1, ga, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_GRAD, b1, nullptr, nullptr, nullptr, nullptr, gu));|TRY(nt(c, h2, 0, w1, gu, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_OUT, b1));|' "$R/uvc_amd/csrc/vit_engine.hip" > /tmp/perturb/vit_onegelu.hip
+  # (c) VERDICT r3 next #6: what ANY scheme that removes the weight-gradient partial reduction could gain -- the k_tn_reduce launches skipped altogether
+  #     (the gradients stay unreduced: wrong numbers, same GEMMs)
+  sed 's|^    k_tn_reduce<4><<<ceil_div(tot / 4, 256), 256, 0, st>>>|    if (false) k_tn_reduce<4><<<ceil_div(tot / 4, 256), 256, 0, st>>>|; s|^    k_tn_reduce<1><<<ceil_div(tot, 256), 256, 0, st>>>|    if (false) k_tn_reduce<1><<<ceil_div(tot, 256), 256, 0, st>>>|' "$R/uvc_amd/csrc/gemm.hip" > /tmp/perturb/gemm_notnreduce.hip
+  cmp -s /tmp/perturb/gemm_notnreduce.hip "$R/uvc_amd/csrc/gemm.hip" && { echo "variant notnreduce did not apply"; exit 1; }
+  sed -i 's|#include "common.h"|#include "'"$R"'/uvc_amd/csrc/common.h"|; s|#include "../../include/|#include "'"$R"'/include/|' /tmp/perturb/gemm_notnreduce.hip
+  /opt/rocm/bin/hipcc $FLAGS -c /tmp/perturb/gemm_notnreduce.hip -o /tmp/perturb/gemm_notnreduce.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/tools/perturb/libuvc_hip_notnreduce.so" $(ls "$R"/uvc_amd/csrc/build/*.o | grep -v '/gemm.o$') /tmp/perturb/gemm_notnreduce.o || exit 1
   for v in noteacherqkv onegelu; do
     cmp -s /tmp/perturb/vit_$v.hip "$R/uvc_amd/csrc/vit_engine.hip" && { echo "variant $v did not apply"; exit 1; }
     sed -i 's|#include "common.h"|#include "'"$R"'/uvc_amd/csrc/common.h"|; s|#include "../../include/|#include "'"$R"'/include/|' /tmp/perturb/vit_$v.hip
@@ -30,6 +38,6 @@ mkdir -p "$R/gpurun_out"
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$R}
 {
   echo "# same-box alternating A/B, DeiT-Tiny batch 512, 60 steps each: <variant> <img/s> <ms per step> <sum of stand-alone kernel ms>"
-  for v in noteacherqkv onegelu; do echo "## $v"; bash "$R/tools/exp_ab.sh" $v; done
+  for v in ${PROBES:-noteacherqkv onegelu notnreduce}; do echo "## $v"; bash "$R/tools/exp_ab.sh" $v; done
 } > "$OUT" 2>&1
 cat "$OUT"

@@ -396,7 +396,7 @@ constexpr int WS_BM = 64;
 // KT = 12 (K = 384: DeiT-Small / T2T-ViT widths) runs as 6 waves x 32 columns: the wave's W slice is 96 VGPRs again, the two A images
 // (64 rows x 800 B) and the transpose buffers take 116 KB of dynamic LDS, one workgroup per CU.
 template <typename TA, typename TC, int EPI, int KT, int WS_NW, int NJ = 4>
-__global__ __launch_bounds__(64 * WS_NW, (NJ == 4 || KT > 6) ? 2 : 4) void k_gemm_ws(NtArgs g, int ngroups, int nslots) {
+__global__ __launch_bounds__(64 * WS_NW, (KT > 6 && WS_NW > 6) ? 1 : (NJ == 4 || KT > 6) ? 2 : 4) void k_gemm_ws(NtArgs g, int ngroups, int nslots) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   constexpr int ROWB = KT * 64 + 32;             // bytes per staged A row (KT*32 bf16 + pad; words = 8 or 40 mod 64, see NT_ROWB)
@@ -611,10 +611,12 @@ static bool ws384_ok(const NtArgs& a, int epi, int vn, bool a_f32) {
   if (epi == UVC_EPI_NONE || epi == UVC_EPI_DGELU) return false;
   return !a_f32 && a.K == 384 && a.N % 192 == 0 && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % vn == 0 && a.ldr % vn == 0 && a.ldaux % vn == 0 && a.M >= 4096;
 }
-template <typename TC>
+// NW = 8 (r4): N a multiple of 256 (fc1, dfc2: N = 1536) runs eight waves x 32 columns -- two waves on every SIMD (six left two SIMDs with one), six
+// column groups instead of eight per A tile
+template <typename TC, int NW = 6>
 static int launch_ws384(const NtArgs& a, int epi, hipStream_t st) {
-  constexpr int KT = 12, NW = 6, NJ = 2;
-  const int ngroups = a.N / 192;
+  constexpr int KT = 12, NJ = 2;
+  const int ngroups = a.N / (32 * NW);
   const int ntiles = ceil_div(a.M, WS_BM);
   int nslots = (256 / ngroups) & ~7;                       // one workgroup per CU
   if (nslots < 8) nslots = 8;
@@ -1048,8 +1050,10 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
       return p->c_is_f32 ? launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, false, 7, false>(a, st) : launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, false, 7, true>(a, st);
   }
   const bool ws = !generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
-  if (!generic && ws384_ok(a, e, p->c_is_f32 ? 4 : 8, p->a_is_f32 != 0))
+  if (!generic && ws384_ok(a, e, p->c_is_f32 ? 4 : 8, p->a_is_f32 != 0)) {
+    if (!p->c_is_f32 && a.N % 256 == 0 && p->force_generic != 5) return launch_ws384<bf16_t, 8>(a, e, st);    // (force_generic == 5: six waves, A/B)
     return p->c_is_f32 ? launch_ws384<float>(a, e, st) : launch_ws384<bf16_t>(a, e, st);
+  }
   if (!generic && wsn_ok(a, e, p->a_is_f32 != 0))
     return p->c_is_f32 ? launch_wsn<float>(a, e, st) : launch_wsn<bf16_t>(a, e, st);
   // (force_generic == 2 asks for kernels WITHOUT an LDS-DMA ring: the 256 x 256 kernel is one; == 3 takes it at any size)

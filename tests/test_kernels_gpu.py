@@ -1074,3 +1074,42 @@ def test_gemm_nt_lnbwd_row_tile_d384_equals_the_unfused_pair(K, with_add2, x_bf1
     torch.testing.assert_close(db, db2, rtol=1e-4, atol=1e-2 + 1e-5 * M)
     if with_add2:
         torch.testing.assert_close(dots, dots2, rtol=1e-4, atol=0.5)
+
+
+@pytest.mark.parametrize("M,K", [(4096 + 37, 1536), (25216, 1152), (4096, 768), (50432, 1536), (50432, 384), (4096 + 129, 384)])
+@pytest.mark.parametrize("gate", [False, True])
+def test_gemm_nt_row384_forward_with_layernorm_is_bit_identical_to_the_unfused_pair(M, K, gate):
+    """uvc_gemm_nt with ln_out at N = 384 (k_gemm_row384_lnbwd<.., 1>: fc2 + bias + residual [+ gate mix] of DeiT-Small / T2T-ViT writing the next
+    block's norm1, attn.proj + bias + residual writing norm2, from the same launch): C, the LayerNorm rows and the statistics equal the generic kernel + the stand-alone LayerNorm pass BIT FOR BIT
+    (so whether a batch takes the fused form cannot show in its results) -- ragged M (a partial last row tile), an odd and an even number of k-steps,
+    more tiles than workgroups; inference form (no statistics wanted) included; twice in a row."""
+    from uvc_amd import ops
+    N = 384
+    A = (rnd(M, K, seed=411) * 0.5).bfloat16()
+    W = rnd(N, K, seed=412, scale=0.04).bfloat16()
+    bias = rnd(N, seed=413) * 0.1
+    R, R2 = rnd(M, N, seed=414).bfloat16(), rnd(M, N, seed=415).bfloat16()
+    gm, bt = 1 + 0.1 * rnd(N, seed=416), 0.1 * rnd(N, seed=417)
+    gate_t = torch.tensor([0.3, 0.7], device=dev())
+    epi = ops.EPI_BIAS_RESID_GATE if gate else ops.EPI_BIAS_RESID
+    kw = dict(dtype=BF16, epilogue=epi, bias=bias, R=R)
+    if gate:
+        kw.update(R2=R2, gate=gate_t)
+    from uvc_amd import _lib as L
+    assert L.lib().uvc_gemm_nt_ln_supported(M, N, K, BF16, epi) == 1
+    C0 = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(A, W, C0, force_generic=1, **kw)
+    h0 = torch.empty_like(C0)
+    m0, r0 = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.layernorm_fwd(C0, gm, bt, h0, m0, r0, M, N, BF16)
+    for trial in range(2):
+        C1 = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+        h1 = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+        m1, r1 = torch.full((M,), float("nan"), device=dev()), torch.full((M,), float("nan"), device=dev())
+        ops.gemm_nt(A, W, C1, ln_gamma=gm, ln_beta=bt, ln_out=h1, ln_mean=m1, ln_rstd=r1, **kw)
+        assert torch.equal(C1, C0), (trial, "C")
+        assert torch.equal(h1, h0), (trial, "LayerNorm rows")
+        assert torch.equal(m1, m0) and torch.equal(r1, r0), (trial, "statistics")
+    h2 = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(A, W, torch.empty_like(C0), ln_gamma=gm, ln_beta=bt, ln_out=h2, **kw)          # no statistics (no-grad forward)
+    assert torch.equal(h2, h0)

@@ -996,8 +996,12 @@ bool nt256_takes(const NtArgs& a, bool a_f32, bool any_size);
 int launch_nt8p_f32(const NtArgs& a, int epi, int ri, hipStream_t st);
 int launch_nt8p_bf16(const NtArgs& a, int epi, int ri, hipStream_t st);
 bool nt8p_takes(const NtArgs& a, bool a_f32);
+bool row384_fwd_ok(const NtArgs& a, int epi);
+int launch_row384_fwd(const NtArgs& a, int epi, hipStream_t st);
 
 extern "C" int uvc_gemm_nt_ln_supported(int32_t M, int32_t N, int32_t K, int32_t dtype, int32_t epilogue) {
+  // N = 384 (r4): k_gemm_row384_lnbwd<.., 1>, bf16 C / R only; its rows are bit-identical to the unfused pair, so the row threshold does not show in results
+  if (dtype == UVC_BF16 && N == 384) return M >= 4096 && K % 64 == 0 && K >= 384 && (epilogue == UVC_EPI_BIAS_RESID || epilogue == UVC_EPI_BIAS_RESID_GATE);
   if (dtype != UVC_BF16 || N != 192 || M < 16) return 0;      // any row count from 16 up: whether norm is fused must not depend on the batch
   return ((K == 768 || K == 512 || K == 256) && (epilogue == UVC_EPI_BIAS_RESID || epilogue == UVC_EPI_BIAS_RESID_GATE)) || (K == 192 && epilogue == UVC_EPI_BIAS_RESID);
 }
@@ -1029,6 +1033,11 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   if (p->ln_out) {
     if (!p->ln_gamma || !p->ln_beta || (p->ln_mean != nullptr) != (p->ln_rstd != nullptr))
       return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: ln_out needs ln_gamma, ln_beta (and ln_mean, ln_rstd together)");
+    if (p->N == 384) {
+      if (!uvc_gemm_nt_ln_supported(p->M, p->N, p->K, p->dtype, e) || generic || p->a_is_f32 || p->c_is_f32 || p->alpha != 1.0f || p->alpha_ptr || !row384_fwd_ok(a, e))
+        return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: ln_out is not available for this problem (uvc_gemm_nt_ln_supported; N = 384: bf16 C and R only)");
+      return launch_row384_fwd(a, e, st);
+    }
     if (!uvc_gemm_nt_ln_supported(p->M, p->N, p->K, p->dtype, e) || generic || p->a_is_f32 || p->alpha != 1.0f || p->alpha_ptr ||
         a.ldb != a.K || !wsn16_dma_ok(a) || ((uintptr_t)p->ln_out & 7) != 0)
       return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: ln_out is not available for this problem (uvc_gemm_nt_ln_supported)");
@@ -1779,6 +1788,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
 }
 
 int launch_row384_lnbwd(const LnbArgs& a, int x_lowp, hipStream_t st);
+
 extern "C" int uvc_gemm_lnbwd_supported(int32_t M, int32_t D, int32_t K, int32_t dtype) {
   if (dtype != UVC_BF16 || M < 4096) return 0;
   if (D == 192) return K == 768 || K == 576;
@@ -2032,9 +2042,21 @@ constexpr int R3_LDS = 2 * R3_STAGE + 8 * (2 * R3_BN + 2) * 4;   // stages (the 
 static_assert(R3_BM * R3_RS <= 2 * R3_STAGE, "the result tile fits the stages");
 
 struct R3Frags { u32x4 a[4]; u32x4 b[6]; };
+// MODE 1 (r4): the FORWARD counterpart on the same main loop -- fc2 / attn.proj (K -> 384) + bias + residual (+ gate mix) with the LayerNorm of the
+// output rows as a second output (uvc_gemm_nt with ln_out at N = 384: the next block's norm1 / this block's norm2, two stand-alone passes per block
+// before).  Behind the k-loop the float32 tile goes to LDS one 64-row half at a time (rows of 1568 bytes), and the eight waves run the epilogue of
+// nt_epilogue_rows and then k_ln_fwd_v<bf16, bf16, 6>'s arithmetic over whole rows with that kernel's lane map (16 lanes x 24 columns, four rows
+// at a time): C, the LayerNorm rows and the statistics are BIT-IDENTICAL to k_gemm_nt + k_ln_fwd_v, so whether a batch takes the fused form does
+// not show in its results (tests/test_kernels_gpu.py; the engine's batch-independence tests).
+struct R3Fwd {
+  const float* bias; const void* R; const void* R2; const float* dptr; void* C;
+  const float* ln_gamma; const float* ln_beta; void* ln_out; float* ln_mean; float* ln_rstd; float ln_eps; int gate;
+};
+constexpr int R3_FS = R3_BN * 4 + 32;                        // float32 half-tile row: 392 words = 8 mod 64 (conflict-free 16-byte writes by (row, 4-column group))
+static_assert(64 * R3_FS <= 2 * R3_STAGE, "a float32 half tile fits the stages");
 
-template <bool XLOW>
-__global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int tiles_m) {
+template <bool XLOW, int MODE = 0>
+__global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int tiles_m, R3Fwd f) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   constexpr int D = R3_BN, NV4 = 3, LPR = 32;
@@ -2110,7 +2132,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
   f32x4 gam[NV4], dgam[NV4], dbet[NV4];
 #pragma unroll
   for (int i = 0; i < NV4; ++i) {
-    gam[i] = *reinterpret_cast<const f32x4*>(g.gamma + (sub + LPR * i) * 4);
+    gam[i] = MODE == 0 ? *reinterpret_cast<const f32x4*>(g.gamma + (sub + LPR * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     dgam[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbet[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float a1 = g.a1 ? *g.a1 : 1.f, a2 = g.a2 ? *g.a2 : 1.f;
@@ -2179,6 +2201,89 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
     wait_lgkm<0>();
     wait_vm<0>();
     __syncthreads();                                              // every wave is done with the stages and nothing is in flight into them
+    if constexpr (MODE == 1) {
+      const int sub16 = lane & 15, rg4 = lane >> 4;
+      const float invD384 = 1.0f / (float)D;
+      const float d0 = f.gate ? f.dptr[0] : 0.f, d1 = f.gate ? f.dptr[1] : 1.f;
+      const bf16_t* Rp = reinterpret_cast<const bf16_t*>(f.R);
+      const bf16_t* R2p = reinterpret_cast<const bf16_t*>(f.R2);
+      for (int half = 0; half < 2; ++half) {
+        if (wm == half) {                                          // this M group's 64 rows, float32, row-major
+          const unsigned base = s0 + (unsigned)((lane & 15) * R3_FS + (wn * 96 + (lane >> 4) * 4) * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+              asm volatile("ds_write_b128 %0, %1" ::"v"(base + (unsigned)(i * 16 * R3_FS + j * 64)), "v"(acc[i][j]) : "memory");
+        }
+        wait_lgkm<0>();
+        __syncthreads();
+        // rows w * 8 .. + 7 of the half: two sets of four rows (16 lanes a row); both sets' residual rows requested before the first is used
+        u32x2 rr[2][6], rr2[2][6];
+        int rows_[2]; bool ok_[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          rows_[it] = bm * R3_BM + half * 64 + w * 8 + it * 4 + rg4;
+          ok_[it] = rows_[it] < g.M;
+          const size_t off = (size_t)(ok_[it] ? rows_[it] : 0) * D;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            rr[it][i] = ok_[it] ? *reinterpret_cast<const u32x2*>(Rp + off + (sub16 + 16 * i) * 4) : u32x2{0u, 0u};
+            rr2[it][i] = (ok_[it] && f.gate) ? *reinterpret_cast<const u32x2*>(R2p + off + (sub16 + 16 * i) * 4) : u32x2{0u, 0u};
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const unsigned la = s0 + (unsigned)((w * 8 + it * 4 + rg4) * R3_FS + sub16 * 16);
+          f32x4 v[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) v[i] = __builtin_bit_cast(f32x4, ds_read128_asm(la, i * 256));
+          wait_lgkm<0>();
+          asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+          float sm = 0.f;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(f.bias + (sub16 + 16 * i) * 4);
+            const f32x4 rv = Raw4L<bf16_t>::cvt(rr[it][i]), r2v = Raw4L<bf16_t>::cvt(rr2[it][i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = epi_scale_bias(v[i][e], 1.0f, bv[e]);
+              t += rv[e];
+              if (f.gate) t = epi_gate_mix(t, r2v[e], d0, d1);
+              v[i][e] = t;
+            }
+            u32x2 q; q[0] = pack_bf16x2(v[i][0], v[i][1]); q[1] = pack_bf16x2(v[i][2], v[i][3]);
+            if (ok_[it]) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(f.C) + (size_t)rows_[it] * D + (sub16 + 16 * i) * 4) = q;
+            v[i] = Raw4L<bf16_t>::cvt(q);                          // the LayerNorm is taken of the stored (rounded) row, as the stand-alone pass does
+            sm += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+          }
+          sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
+          const float mean = sm * invD384;
+          float qq = 0.f;
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dd = v[i][e] - mean; qq += dd * dd; }
+          qq += __shfl_xor(qq, 1, 64); qq += __shfl_xor(qq, 2, 64); qq += __shfl_xor(qq, 4, 64); qq += __shfl_xor(qq, 8, 64);
+          const float rstd = rsqrtf(qq * invD384 + f.ln_eps);
+          if (ok_[it]) {
+            bf16_t* y = reinterpret_cast<bf16_t*>(f.ln_out) + (size_t)rows_[it] * D;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              const f32x4 gm = *reinterpret_cast<const f32x4*>(f.ln_gamma + (sub16 + 16 * i) * 4), bt = *reinterpret_cast<const f32x4*>(f.ln_beta + (sub16 + 16 * i) * 4);
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+              u32x2 q; q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]);
+              *reinterpret_cast<u32x2*>(y + (sub16 + 16 * i) * 4) = q;
+            }
+            if (sub16 == 0 && f.ln_mean) { f.ln_mean[rows_[it]] = mean; f.ln_rstd[rows_[it]] = rstd; }
+          }
+        }
+        __syncthreads();                                           // the half is consumed: the other half / the next tile's requests may overwrite it
+      }
+      continue;
+    }
     // ---- the tile, rounded to bf16 (what k_gemm_nt stores), row-major in LDS: lane (li, gq) of acc[i][j] = row i * 16 + li, columns j * 16 + 4 gq ..
     {
       const unsigned base = s0 + (unsigned)((wm * 64 + (lane & 15)) * R3_RS + (wn * 96 + (lane >> 4) * 4) * 2);
@@ -2274,6 +2379,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
 #undef R8_MMA6
 #undef R8_REQ
 #undef R8_END
+  if constexpr (MODE == 1) return;
   // ---- this workgroup's partial row [2 D + 2]: the two row groups of a wave, then the eight waves in a fixed order
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem + 2 * R3_STAGE);
@@ -2301,8 +2407,28 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
 int launch_row384_lnbwd(const LnbArgs& a, int x_lowp, hipStream_t st) {
   const int tiles_m = ceil_div(a.M, R3_BM);
   const int grid = uvc_gemm_lnbwd_nblocks(a.M);           // 256 partial rows (M >= 4096): workgroups past the tiles write zeros
-  if (x_lowp) { UVC_MAX_LDS(R3_LDS, k_gemm_row384_lnbwd<true>); k_gemm_row384_lnbwd<true><<<grid, 512, R3_LDS, st>>>(a, tiles_m); }
-  else { UVC_MAX_LDS(R3_LDS, k_gemm_row384_lnbwd<false>); k_gemm_row384_lnbwd<false><<<grid, 512, R3_LDS, st>>>(a, tiles_m); }
+  R3Fwd f = {};
+  if (x_lowp) { UVC_MAX_LDS(R3_LDS, k_gemm_row384_lnbwd<true>); k_gemm_row384_lnbwd<true><<<grid, 512, R3_LDS, st>>>(a, tiles_m, f); }
+  else { UVC_MAX_LDS(R3_LDS, k_gemm_row384_lnbwd<false>); k_gemm_row384_lnbwd<false><<<grid, 512, R3_LDS, st>>>(a, tiles_m, f); }
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+// uvc_gemm_nt with ln_out at N = 384 (bf16 operands, residual rows and outputs; K a multiple of 64, >= 128)
+bool row384_fwd_ok(const NtArgs& a, int epi) {
+  return a.N == R3_BN && a.K % 64 == 0 && a.K >= 128 && a.lda == a.K && a.ldb == a.K && a.ldc == R3_BN && a.ldr == R3_BN &&
+         (epi == UVC_EPI_BIAS_RESID || epi == UVC_EPI_BIAS_RESID_GATE) && (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.R | (uintptr_t)a.ln_out) & 15) == 0 &&
+         (size_t)(a.M + 128) * a.K * 2 < (1ull << 31);
+}
+int launch_row384_fwd(const NtArgs& a, int epi, hipStream_t st) {
+  LnbArgs b = {};
+  b.A = a.A; b.W = a.B; b.M = a.M; b.K = a.K;
+  R3Fwd f;
+  f.bias = a.bias; f.R = a.R; f.R2 = a.R2; f.dptr = a.dptr; f.C = a.C; f.ln_gamma = a.ln_gamma; f.ln_beta = a.ln_beta; f.ln_out = a.ln_out;
+  f.ln_mean = a.ln_mean; f.ln_rstd = a.ln_rstd; f.ln_eps = a.ln_eps; f.gate = epi == UVC_EPI_BIAS_RESID_GATE ? 1 : 0;
+  const int tiles_m = ceil_div(a.M, R3_BM);
+  const int grid = tiles_m < 256 ? tiles_m : 256;
+  UVC_MAX_LDS(R3_LDS, k_gemm_row384_lnbwd<true, 1>);
+  k_gemm_row384_lnbwd<true, 1><<<grid, 512, R3_LDS, st>>>(b, tiles_m, f);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

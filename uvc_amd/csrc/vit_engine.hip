@@ -496,7 +496,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     // norm2 as a second output of attn.proj + residual (the MLP kernel, where it runs, normalises its rows itself)
     // (not on the compact token rows of a `tail` block: B * ntok may be below the kernel's 16 rows, and whether a norm is fused must
     // not depend on the batch -- the two forms round differently in the last bit)
-    const bool ln2_in_proj = !tail && !mlp_one_kernel && io->fuse_next_ln != 0 && uvc_gemm_nt_ln_supported(rows, d.D, d.D, d.dtype, UVC_EPI_BIAS_RESID);
+    const bool ln2_in_proj = !tail && !mlp_one_kernel && io->fuse_next_ln != 0 && uvc_gemm_nt_ln_supported(rows, d.D, d.D, d.dtype, UVC_EPI_BIAS_RESID) && (d.D != 384 || d.rlow);   // (D = 384: bf16 residual rows only)
     {
       const NextLn n2 = {P + q[6], P + q[7], h2, io->training ? mean2 : nullptr, io->training ? rstd2 : nullptr};
       TRY(nt(c, tail ? t.oc : b.o, 0, wmat(c, q[4], c.soff.blk_w[l][1]), x1, rf, rows, d.D, d.D, UVC_EPI_BIAS_RESID, P + q[5], xres, nullptr, nullptr, nullptr, nullptr,
@@ -536,7 +536,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     {
       const int ln = tail ? -1 : next_running(l);
       const int epi = io->gate_d ? UVC_EPI_BIAS_RESID_GATE : UVC_EPI_BIAS_RESID;
-      if (ln >= 0 && io->fuse_next_ln != 0 && uvc_gemm_nt_ln_supported(rows, d.D, Fe, d.dtype, epi)) {
+      if (ln >= 0 && io->fuse_next_ln != 0 && uvc_gemm_nt_ln_supported(rows, d.D, Fe, d.dtype, epi) && (d.D != 384 || d.rlow)) {
         nl.gamma = P + o.blk[ln][0]; nl.beta = P + o.blk[ln][1]; nl.h = w.blk[ln].h1;
         nl.mean = io->training ? w.blk[ln].mean1 : nullptr; nl.rstd = io->training ? w.blk[ln].rstd1 : nullptr;
         pnl = &nl;

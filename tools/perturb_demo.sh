@@ -1,6 +1,6 @@
 #!/bin/bash
 # Shows once that tests/test_streaming_batch_gpu.py (r3) and tests/test_wide_models_gpu.py (r4) go red when a production kernel is wrong.
-#   here (build container):  tools/perturb_demo.sh build     -> tools/perturb/libuvc_hip_{ws,lnbwd}.so (git-ignored; they travel with gpurun)
+#   here (build container):  tools/perturb_demo.sh build     -> tools/perturb/libuvc_hip_{ws,lnbwd,wide,row384,tn8p,row384fwd}.so (git-ignored; they travel with gpurun)
 #   on the GPU box:          tools/perturb_demo.sh run       -> gpurun_out/perturb_demo.txt
 # The perturbed libraries are built from sed-edited COPIES of gemm.hip under /tmp: the product source carries no test switch.
 set -u
@@ -26,7 +26,9 @@ j = s.index("*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];"
 s = s[:j] + "*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j] * 1.03f;" + s[j + len("*reinterpret_cast<f32x4*>(P + (size_t)n1 * g.N2 + n2) = acc[i][j];"):]
 open(sys.argv[2], "w").write(s)
 PY
-  for v in ws lnbwd wide row384 tn8p; do
+  # 6. (r4) k_gemm_row384_lnbwd<.., 1> (D = 384: fc2 / attn.proj + residual + the next LayerNorm in one launch): the GEMM result x 1.02 before bias / residual
+  sed 's|float t = epi_scale_bias(v\[i\]\[e\], 1.0f, bv\[e\]);|float t = epi_scale_bias(v[i][e] * 1.02f, 1.0f, bv[e]);|' "$R/uvc_amd/csrc/gemm.hip" > /tmp/perturb/gemm_row384fwd.hip
+  for v in ws lnbwd wide row384 tn8p row384fwd; do
     cmp -s /tmp/perturb/gemm_$v.hip "$R/uvc_amd/csrc/gemm.hip" && { echo "perturbation $v did not apply"; exit 1; }
     sed -i 's|#include "common.h"|#include "'"$R"'/uvc_amd/csrc/common.h"|; s|#include "../../include/uvc_kernels.h"|#include "'"$R"'/include/uvc_kernels.h"|' /tmp/perturb/gemm_$v.hip
     /opt/rocm/bin/hipcc $FLAGS -c /tmp/perturb/gemm_$v.hip -o /tmp/perturb/gemm_$v.o || exit 1
@@ -47,9 +49,9 @@ cp "$R/uvc_amd/libuvc_hip.so" /tmp/libuvc_hip_good.so
     (cd "$R" && python -m pytest tests/test_streaming_batch_gpu.py -q -x -k "matches_oracle_at_streaming_batch and not fp32" 2>&1 | grep -E "AssertionError|passed|failed|assert " | cut -c1-600 | head -8)
   done
   echo; echo "# tests/test_wide_models_gpu.py::test_wide_model_step_matches_oracle_on_production_kernels (DeiT-Small batch 24, DeiT-Base batch 12 with the wide tiles forced)"
-  for v in wide row384 tn8p; do
+  for v in wide row384 tn8p row384fwd; do
     cp "$R/tools/perturb/libuvc_hip_$v.so" "$R/uvc_amd/libuvc_hip.so"
-    echo; echo "## perturbed: $v (wide NT tiles x 1.02 | k_gemm_row384_lnbwd dx x 1.02 | k_gemm_tn8p partial tiles x 1.03 (a leaf kernel: below the 2.5 % per-tensor bound a scaling is inside the bf16 noise the bound admits)) -- expected: FAILED"
+    echo; echo "## perturbed: $v (wide NT tiles x 1.02 | k_gemm_row384_lnbwd dx x 1.02 | k_gemm_row384_lnbwd<.., 1> (forward + LayerNorm) GEMM result x 1.02 | k_gemm_tn8p partial tiles x 1.03 (a leaf kernel: below the 2.5 % per-tensor bound a scaling is inside the bf16 noise the bound admits)) -- expected: FAILED"
     (cd "$R" && python -m pytest tests/test_wide_models_gpu.py -q -k "matches_oracle_on_production_kernels" 2>&1 | grep -E "AssertionError|passed|failed|assert " | cut -c1-600 | head -8)
   done
   cp /tmp/libuvc_hip_good.so "$R/uvc_amd/libuvc_hip.so"

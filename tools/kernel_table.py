@@ -71,7 +71,9 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     # DeiT-Tiny width (uvc_vit_io.fuse_next_ln): norm1 of blocks 1 .. L-1 is written by the kernel that produces their input rows
     # (fc2 + residual + gate mix of the student, the fused MLP of the teacher) and the student's norm2 by attn.proj + residual, so only
     # block 0's norm1 is a pass of its own (the final norms and the last block's token-row norm2 run on B rows: not listed)
-    fuse_ln = tiny
+    # D = 384 (r4, M >= 4096): the same through k_gemm_row384_lnbwd<.., 1> -- fc2 and attn.proj of the student AND of the teacher write the next LayerNorm
+    fuse_ln = tiny or (D == 384 and M >= 4096)
+    row384 = fuse_ln and not tiny
     n_ln1 = 1 if fuse_ln else L
     add("ln_fwd", "k_ln_fwd_v", (1 + T) * n_ln1 + (0 if fuse_ln else Lf), ru + u, 0, lambda: ops.layernorm_fwd(xr, gam, bet, y, m_, r_, M, D, dt), wfrac=u / (ru + u))
     qkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
@@ -90,17 +92,17 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     o32 = torch.empty(M, D, device=dev, dtype=rdt)      # output rows of the residual stream
     # student at DeiT-Tiny width: norm2 leaves with attn.proj's rows (the teacher's fused MLP normalises its rows itself)
     if fuse_ln:
-        add("proj+resid+norm2", "k_gemm_wsn16_dma<3, 6", Lf, 2 * u + 2 * ru, 2.0 * M * D * D,
+        add("proj+resid+norm2", "k_gemm_row384_lnbwd<true, 1>" if row384 else "k_gemm_wsn16_dma<3, 6", Lf * (1 + T if row384 else 1), 2 * u + 2 * ru, 2.0 * M * D * D,
             lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=xr, ln_gamma=gam, ln_beta=bet, ln_out=y, ln_mean=m_, ln_rstd=r_),
             wfrac=(ru + u) / (2 * u + 2 * ru))
-    if not fuse_ln or T:
+    if not fuse_ln or (T and tiny):
         add("proj+resid", "k_gemm_wsn16_dma<3, 6, false" if tiny else "k_gemm", (T if fuse_ln else 1 + T) * Lf, u + 2 * ru, 2.0 * M * D * D,
             lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=xr), wfrac=ru / (u + 2 * ru))
     aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
     add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
         lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu))
     if fuse_ln:
-        add("fc2+resid+gate+norm1", "k_gemm_wsn16_dma<4", Lf, 5 * u + 3 * ru, 2.0 * M * D * F,
+        add("fc2+resid+gate+norm1", "k_gemm_row384_lnbwd<true, 1>" if row384 else "k_gemm_wsn16_dma<4", Lf, 5 * u + 3 * ru, 2.0 * M * D * F,
             lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=xr, R2=gr_, gate=gate,
                                 ln_gamma=gam, ln_beta=bet, ln_out=y, ln_mean=m_, ln_rstd=r_), wfrac=(ru + u) / (5 * u + 3 * ru))
     else:
@@ -110,8 +112,12 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
         # wider models: the teacher's MLP is two GEMMs (the fused kernel exists for D = 192 only): fc1 + GELU (one output), fc2 + residual
         add("teacher fc1+gelu", "k_gemm", Lf, 5 * u, 2.0 * M * D * F,
             lambda: ops.gemm_nt(xb, W1, uu, dtype=dt, epilogue=ops.EPI_BIAS_GELU_OUT, bias=bF), wfrac=0.8)
-        add("teacher fc2+resid", "k_gemm", Lf, 4 * u + 2 * ru, 2.0 * M * D * F,
-            lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=xr), wfrac=ru / (4 * u + 2 * ru))
+        if row384:
+            add("teacher fc2+resid+norm1", "k_gemm_row384_lnbwd<true, 1>", Lf, 5 * u + 2 * ru, 2.0 * M * D * F,
+                lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=xr, ln_gamma=gam, ln_beta=bet, ln_out=y), wfrac=(ru + u) / (5 * u + 2 * ru))
+        else:
+            add("teacher fc2+resid", "k_gemm", Lf, 4 * u + 2 * ru, 2.0 * M * D * F,
+                lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=xr), wfrac=ru / (4 * u + 2 * ru))
     if tiny and with_teacher:
         add("teacher mlp_fused+norm1", "k_mlp_fused", Lf, u + 2 * ru, 4.0 * M * D * F,
             lambda: ops.mlp_fused_fwd(xr, gam, bet, W1, bF, W2, bD, o32, next_gamma=gam, next_beta=bet, next_h=y), wfrac=(ru + u) / (u + 2 * ru))

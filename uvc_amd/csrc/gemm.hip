@@ -611,12 +611,12 @@ static bool ws384_ok(const NtArgs& a, int epi, int vn, bool a_f32) {
   if (epi == UVC_EPI_NONE || epi == UVC_EPI_DGELU) return false;
   return !a_f32 && a.K == 384 && a.N % 192 == 0 && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % vn == 0 && a.ldr % vn == 0 && a.ldaux % vn == 0 && a.M >= 4096;
 }
-// NW = 8 (r4): N a multiple of 256 (fc1, dfc2: N = 1536) runs eight waves x 32 columns -- two waves on every SIMD (six left two SIMDs with one), six
-// column groups instead of eight per A tile
+// NW = 8 (r4): N a multiple of 128 from 512 up runs eight waves x 32 columns -- two waves on every SIMD (six left two SIMDs with one), six column groups
+// instead of eight per A tile at N = 1536; N = 1152 (qkv; T2T-ViT's MLP) is 4.5 groups, the last with four idle waves: still 6-15 % faster than six waves
 template <typename TC, int NW = 6>
 static int launch_ws384(const NtArgs& a, int epi, hipStream_t st) {
   constexpr int KT = 12, NJ = 2;
-  const int ngroups = a.N / (32 * NW);
+  const int ngroups = ceil_div(a.N, 32 * NW);               // (a last group with idle waves: N = 1152 on eight waves is 4.5 groups)
   const int ntiles = ceil_div(a.M, WS_BM);
   int nslots = (256 / ngroups) & ~7;                       // one workgroup per CU
   if (nslots < 8) nslots = 8;
@@ -1060,7 +1060,7 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   }
   const bool ws = !generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
   if (!generic && ws384_ok(a, e, p->c_is_f32 ? 4 : 8, p->a_is_f32 != 0)) {
-    if (!p->c_is_f32 && a.N % 256 == 0 && p->force_generic != 5) return launch_ws384<bf16_t, 8>(a, e, st);    // (force_generic == 5: six waves, A/B)
+    if (!p->c_is_f32 && a.N % 128 == 0 && a.N >= 512 && p->force_generic != 5) return launch_ws384<bf16_t, 8>(a, e, st);    // (force_generic == 5: six waves, A/B)
     return p->c_is_f32 ? launch_ws384<float>(a, e, st) : launch_ws384<bf16_t>(a, e, st);
   }
   if (!generic && wsn_ok(a, e, p->a_is_f32 != 0))

@@ -608,7 +608,8 @@ static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
 // Measured at M = 50 k rows against the generic tiled kernel: qkv 102 -> 72 us, fc1 (+GELU, GELU') 178 -> 148, proj 47 -> 43, fc2 dgrad x GELU'
 // 133 -> 128; the plain and the recomputing-dGELU epilogues were slower (26 -> 28, 149 -> 162) and stay on the generic kernel.
 static bool ws384_ok(const NtArgs& a, int epi, int vn, bool a_f32) {
-  if (epi == UVC_EPI_NONE || epi == UVC_EPI_DGELU) return false;
+  if (epi == UVC_EPI_DGELU) return false;
+  if (epi == UVC_EPI_NONE && !(vn == 8 && a.N % 128 == 0 && a.N >= 512)) return false;      // (plain epilogue: the eight-wave form only -- T2T-ViT's bias-free qkv)
   return !a_f32 && a.K == 384 && a.N % 192 == 0 && a.ldb == a.K && a.lda % 8 == 0 && a.ldc % vn == 0 && a.ldr % vn == 0 && a.ldaux % vn == 0 && a.M >= 4096;
 }
 // NW = 8 (r4): N a multiple of 128 from 512 up runs eight waves x 32 columns -- two waves on every SIMD (six left two SIMDs with one), six column groups
@@ -627,7 +628,7 @@ static int launch_ws384(const NtArgs& a, int epi, hipStream_t st) {
     UVC_MAX_LDS(sh, k_gemm_ws<bf16_t, TC, E, KT, NW, NJ>); \
     k_gemm_ws<bf16_t, TC, E, KT, NW, NJ><<<grid, 64 * NW, sh, st>>>(a, ngroups, nslots); } break;
   switch (epi) {
-    WS_CASE(UVC_EPI_BIAS) WS_CASE(UVC_EPI_BIAS_GELU) WS_CASE(UVC_EPI_BIAS_RESID)
+    WS_CASE(UVC_EPI_NONE) WS_CASE(UVC_EPI_BIAS) WS_CASE(UVC_EPI_BIAS_GELU) WS_CASE(UVC_EPI_BIAS_RESID)
     WS_CASE(UVC_EPI_BIAS_RESID_GATE) WS_CASE(UVC_EPI_BIAS_GELU_OUT) WS_CASE(UVC_EPI_BIAS_GELU_GRAD) WS_CASE(UVC_EPI_MUL_AUX)
     default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: unknown epilogue");
   }

@@ -2209,17 +2209,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
       const bf16_t* Rp = reinterpret_cast<const bf16_t*>(f.R);
       const bf16_t* R2p = reinterpret_cast<const bf16_t*>(f.R2);
       for (int half = 0; half < 2; ++half) {
-        if (wm == half) {                                          // this M group's 64 rows, float32, row-major
-          const unsigned base = s0 + (unsigned)((lane & 15) * R3_FS + (wn * 96 + (lane >> 4) * 4) * 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-              asm volatile("ds_write_b128 %0, %1" ::"v"(base + (unsigned)(i * 16 * R3_FS + j * 64)), "v"(acc[i][j]) : "memory");
-        }
-        wait_lgkm<0>();
-        __syncthreads();
-        // rows w * 8 .. + 7 of the half: two sets of four rows (16 lanes a row); both sets' residual rows requested before the first is used
+        // rows w * 8 .. + 7 of the half: two sets of four rows (16 lanes a row); both sets' residual rows are requested here, in front of the
+        // staging writes and the barrier, so that their HBM round trip runs beside them
         u32x2 rr[2][6], rr2[2][6];
         int rows_[2]; bool ok_[2];
 #pragma unroll
@@ -2233,6 +2224,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
             rr2[it][i] = (ok_[it] && f.gate) ? *reinterpret_cast<const u32x2*>(R2p + off + (sub16 + 16 * i) * 4) : u32x2{0u, 0u};
           }
         }
+        if (wm == half) {                                          // this M group's 64 rows, float32, row-major
+          const unsigned base = s0 + (unsigned)((lane & 15) * R3_FS + (wn * 96 + (lane >> 4) * 4) * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+              asm volatile("ds_write_b128 %0, %1" ::"v"(base + (unsigned)(i * 16 * R3_FS + j * 64)), "v"(acc[i][j]) : "memory");
+        }
+        wait_lgkm<0>();
+        __syncthreads();
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const unsigned la = s0 + (unsigned)((w * 8 + it * 4 + rg4) * R3_FS + sub16 * 16);

@@ -3423,6 +3423,11 @@ static int tn_splits(int M, int N1, int N2, int cfg) {
   int splits = cfg == 0 ? ceil_div(target, tiles) : target / tiles;       // big tiles: one workgroup per CU (LDS), so at most 256 of them -- one more is a second round
   const int max_splits = ceil_div(M, TN_BM);
   if (splits > max_splits) splits = max_splits;
+  // (r4) not more splits than rows justify: a split writes and the reduce re-reads a whole float32 tile, and below ~1 k rows per split that traffic is what the
+  // kernel moves (dW_proj of DeiT-Tiny: 128 splits of 788 rows; T2T-ViT-14 at 25 k rows: partial bytes = operand bytes).  Measured in the step, same box:
+  // >= 1024 rows: DeiT-Tiny 12.19 -> 12.06 ms (1536: 12.5), DeiT-Small / Base unchanged; the 192 x 192 tiles at M < 32 k (T2T-ViT-14) >= 2048 rows: 13.22 -> 12.88 ms
+  const int rmin = (cfg == 3 && M < 32768) ? 2048 : 1024;
+  if (cfg != 0 && M >= 2 * rmin && splits > M / rmin) splits = M / rmin;
   return splits < 1 ? 1 : splits;
 }
 

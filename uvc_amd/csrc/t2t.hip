@@ -1,7 +1,8 @@
 // T2T-ViT tokens-to-token front end (include/uvc_t2t.h): soft split fused with the stage's LayerNorm, its adjoint (fold),
 // and the Performer's linear attention, forward and backward.  Follows UVC/T2TViT/models/t2t_vit.py:84-105 and
 // token_performer.py:31-62 of the reference.  HBM-bound token streams (3136 / 784 / 196 tokens per image, 64-wide):
-// one pass over each stream, float32 arithmetic on the VALU, LDS tiles of 64 tokens, deterministic two-level sums.
+// one pass over each stream, float32 arithmetic (the Performer's inner products on v_mfma_f32_16x16x4_f32 since round 4), tiles of 64 tokens,
+// deterministic two-level sums.
 #include "common.h"
 #include "../../include/uvc_kernels.h"
 #include "../../include/uvc_t2t.h"

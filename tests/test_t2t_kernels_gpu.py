@@ -27,6 +27,7 @@ CASES = [  # (name, B, C, H, W, k, s, p, token_major)
     ("image_ragged", 3, 3, 36, 36, 7, 4, 2, False),
     ("tokens", 2, 64, 16, 16, 3, 2, 1, True),
     ("tokens_odd", 1, 64, 7, 7, 3, 2, 1, True),
+    ("tokens_k2", 2, 64, 10, 10, 2, 2, 0, True),          # four taps, no padding: the run-time tap paths of the gather and of the tap-major fold
 ]
 
 

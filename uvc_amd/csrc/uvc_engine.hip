@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ sc1, con
                                               const float* __restrict__ sc3, uvc_dims d,
                                               int32_t* __restrict__ rank1, int32_t* __restrict__ rankh,
                                               int32_t* __restrict__ rank3) {
-  extern __shared__ float sh[];
+  extern __shared__ __attribute__((aligned(16))) float sh[];
   const int l = blockIdx.y;
   // W3 columns
   for (int i = threadIdx.x; i < d.F; i += blockDim.x) sh[i] = sc3[l * d.F + i];
@@ -109,7 +109,15 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ sc1, con
     if (i < d.F) {
       const float v = sh[i];
       int rk = 0;
-      for (int j = 0; j < d.F; ++j) {
+      int j = 0;
+      for (; j + 4 <= d.F; j += 4) {                  // four scores per (broadcast) LDS read
+        const float4 u = *reinterpret_cast<const float4*>(sh + j);
+        rk += (u.x < v) || (u.x == v && j < i);
+        rk += (u.y < v) || (u.y == v && j + 1 < i);
+        rk += (u.z < v) || (u.z == v && j + 2 < i);
+        rk += (u.w < v) || (u.w == v && j + 3 < i);
+      }
+      for (; j < d.F; ++j) {
         const float u = sh[j];
         rk += (u < v) || (u == v && j < i);
       }

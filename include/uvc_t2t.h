@@ -69,6 +69,33 @@ int uvc_performer_splits(int32_t B, int32_t T);
 int uvc_performer_fwd(const uvc_performer_args* args, void* stream);
 int uvc_performer_bwd(const uvc_performer_args* args, void* stream);
 
+/* One Token_performer stage of the tokens-to-token module (T2TViT/models/t2t_vit.py:84-105, token_performer.py:45-69), forward and
+ * backward, sequenced in C: soft split + norm1 -> kqv Linear -> linear attention -> v + proj -> norm2 -> MLP (GELU) + residual, and the
+ * reverse with every weight / bias / LayerNorm gradient.  The same launches, in the same order and with the same arguments, as the calls
+ * to uvc_unfold_ln_*, uvc_gemm_nt / _tn, uvc_performer_*, uvc_layernorm_* they replace (results bit-identical): a stage is one call
+ * across the boundary instead of 7 (forward) / 11 (backward).  T = element type of `dtype`; "f32" buffers are float32 in both modes. */
+typedef struct uvc_t2t_stage {
+  /* geometry of the soft split that feeds the stage */
+  const float* src; int64_t sb, sc, sh, sw;
+  int32_t B, C, H, W, k, s, p;
+  int32_t T, dim, dimp, dtype, training;      /* T = tokens per image after the split, dim = C*k*k, dimp = dim padded to the GEMM's K granularity */
+  float eps, beta;                            /* LayerNorm eps; beta = 1: gradients accumulate into the g_* buffers, 0: overwrite */
+  int32_t need_dx, reserved;                  /* backward: leave d(unfolded row) in dxu (tap-major, see uvc_unfold_args.dxu_tap_major) */
+  /* parameters (float32) and their gradients */
+  const float *norm1_w, *norm1_b, *kqv_b, *w, *proj_b, *norm2_w, *norm2_b, *fc1_b, *fc2_b;
+  float *g_norm1_w, *g_norm1_b, *g_kqv_w, *g_kqv_b, *g_proj_w, *g_proj_b, *g_norm2_w, *g_norm2_b, *g_fc1_w, *g_fc1_b, *g_fc2_w, *g_fc2_b;
+  /* T-typed weight copies W [out, in] and W^T [in, out] */
+  const void *kqv_w, *kqv_wt, *proj_w, *proj_wt, *fc1_w, *fc1_wt, *fc2_w, *fc2_wt;
+  /* forward buffers: xn [M, dimp] T, kqv [M, 192] f32, att [M, 64] T, x1 [M, 64] f32, h, u, gp [M, 64] T (gp: training only), out [M, 64] f32 */
+  void* xn; float* mean1; float* rstd1; float* kqv; float* part; float* kptv; void* att; float* x1; void* h; float* mean2; float* rstd2;
+  void* u; void* gp; float* out;
+  /* backward: dout [M, 64] T (input), da, dh, dx1, datt [M, 64] T, dkqv [M, 192] T, dkptv [B, 65, 32] f32, dxn [M, dimp] T, scratch */
+  const void* dout; void* da; void* dh; void* dx1; void* datt; void* dkqv; float* dkptv; void* dxn;
+  float* ln2_partial; float* ln1_partial; float* dxu; void* tn_ws; int64_t tn_ws_bytes;
+} uvc_t2t_stage;
+int uvc_t2t_stage_forward(const uvc_t2t_stage* st, void* stream);
+int uvc_t2t_stage_backward(const uvc_t2t_stage* st, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

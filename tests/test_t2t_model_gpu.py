@@ -181,3 +181,31 @@ def test_t2t_14_full_size_training_gradients_match_oracle():
         assert got is not None, k
         worst[k] = float((got.cpu() - gr).abs().max()) / (float(gr.abs().max()) + 1e-12)
     assert max(worst.values()) < 8e-2, worst
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_front_end_stage_in_c_equals_the_python_sequence(precision):
+    """uvc_t2t_stage_forward / _backward (one C call per Token_performer stage) issue the launches the Python sequence issues: logits, the token
+    embedding and every gradient are bit-identical; twice in a row with gradient accumulation on the second pass (beta = 1)."""
+    res = []
+    for in_c in (True, False):
+        r, cfg, sd, m, x, g = build("t2t_micro", precision, enable_block_gating=1, use_gumbel=0, enable_warmup=False)
+        m.front_in_c = in_c
+        m.train()
+        outs = []
+        for rep in range(2):
+            m.grad_accumulate = rep == 1
+            (out, _), _ = m(x.cuda())
+            dl = torch.randn(out.shape, generator=torch.Generator().manual_seed(5 + rep)) * 0.1
+            out.backward(dl.cuda())
+            outs.append(out.detach().clone())
+        torch.cuda.synchronize()
+        res.append((outs, m._flat_grad.clone(), m._ws_view(x.shape[0], True, "pe").clone()))
+        m.eval()
+        with torch.no_grad():
+            res[-1] = res[-1] + (m(x.cuda())[0].clone(),)
+    (o_c, g_c, pe_c, ev_c), (o_p, g_p, pe_p, ev_p) = res
+    assert all(torch.equal(a, b) for a, b in zip(o_c, o_p))
+    assert torch.equal(pe_c, pe_p) and torch.equal(ev_c, ev_p)
+    assert torch.equal(g_c, g_p)
+    assert float(g_c.abs().sum()) > 0

@@ -108,6 +108,19 @@ class uvc_unfold_args(C.Structure):          # include/uvc_t2t.h
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("beta_acc", C.c_float), ("dxu_tap_major", C.c_int32)]
 
 
+class uvc_t2t_stage(C.Structure):            # include/uvc_t2t.h
+    _fields_ = [("src", C.c_void_p)] + [(n, C.c_int64) for n in ("sb", "sc", "sh", "sw")] + \
+               [(n, C.c_int32) for n in ("B", "C", "H", "W", "k", "s", "p", "T", "dim", "dimp", "dtype", "training")] + \
+               [("eps", C.c_float), ("beta", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("norm1_w", "norm1_b", "kqv_b", "w", "proj_b", "norm2_w", "norm2_b", "fc1_b", "fc2_b",
+                                          "g_norm1_w", "g_norm1_b", "g_kqv_w", "g_kqv_b", "g_proj_w", "g_proj_b", "g_norm2_w", "g_norm2_b", "g_fc1_w", "g_fc1_b",
+                                          "g_fc2_w", "g_fc2_b",
+                                          "kqv_w", "kqv_wt", "proj_w", "proj_wt", "fc1_w", "fc1_wt", "fc2_w", "fc2_wt",
+                                          "xn", "mean1", "rstd1", "kqv", "part", "kptv", "att", "x1", "h", "mean2", "rstd2", "u", "gp", "out",
+                                          "dout", "da", "dh", "dx1", "datt", "dkqv", "dkptv", "dxn", "ln2_partial", "ln1_partial", "dxu", "tn_ws")] + \
+               [("tn_ws_bytes", C.c_int64)]
+
+
 class uvc_performer_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("kqv", "w", "part", "kptv", "att")] + [("att_is_f32", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("datt", "dskip", "dkqv", "dkptv")] + \
@@ -183,6 +196,8 @@ _SIGNATURES = {
     "uvc_performer_splits": [I32, I32],
     "uvc_performer_fwd": [C.POINTER(uvc_performer_args), VP],
     "uvc_performer_bwd": [C.POINTER(uvc_performer_args), VP],
+    "uvc_t2t_stage_forward": [C.POINTER(uvc_t2t_stage), VP],
+    "uvc_t2t_stage_backward": [C.POINTER(uvc_t2t_stage), VP],
 }
 
 

@@ -6,6 +6,7 @@
 #include "common.h"
 #include "../../include/uvc_kernels.h"
 #include "../../include/uvc_t2t.h"
+#include <string.h>
 
 namespace {
 
@@ -904,4 +905,99 @@ extern "C" int uvc_performer_bwd(const uvc_performer_args* p, void* stream) {
   else k_performer_bwd_k_mfma<bf16_t><<<p->B * S, 256, 0, st>>>(p->kqv, p->w, p->dkptv, (const bf16_t*)p->dskip, (bf16_t*)p->dkqv, p->T, S, tps);
   UVC_CHECK_LAUNCH();
   return UVC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One Token_performer stage sequenced in C (include/uvc_t2t.h: uvc_t2t_stage)
+// ------------------------------------------------------------------------------------------------
+namespace {
+#define ST_TRY(x) do { if (int e_ = (x)) return e_; } while (0)
+int st_nt(const uvc_t2t_stage* s, const void* A, const void* B, void* C, int c_f32, int N, int K, int epi, const float* bias, const void* R, int r_f32, int ldr,
+          const void* aux, void* C2, void* stream) {
+  uvc_gemm_nt_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.R = R; a.aux = aux;
+  a.alpha = 1.0f; a.M = s->B * s->T; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N; a.ldr = ldr ? ldr : N; a.ldaux = N;
+  a.dtype = s->dtype; a.a_is_f32 = s->dtype == UVC_F32; a.c_is_f32 = c_f32 || s->dtype == UVC_F32; a.epilogue = epi; a.r_is_f32 = R ? (r_f32 || s->dtype == UVC_F32) : 0;
+  return uvc_gemm_nt(&a, stream);
+}
+int st_tn(const uvc_t2t_stage* s, const void* A, const void* B, float* C, float* colsum, int N1, int N2, void* stream) {
+  uvc_gemm_tn_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.B = B; a.C = C; a.workspace = s->tn_ws; a.workspace_bytes = s->tn_ws_bytes; a.colsum_out = colsum; a.alpha = 1.0f; a.beta = s->beta;
+  a.M = s->B * s->T; a.N1 = N1; a.N2 = N2; a.lda = N1; a.ldb = N2; a.ldc = N2; a.dtype = s->dtype; a.a_is_f32 = s->dtype == UVC_F32;
+  return uvc_gemm_tn(&a, stream);
+}
+void st_unfold(const uvc_t2t_stage* s, uvc_unfold_args& a) {
+  memset(&a, 0, sizeof(a));
+  a.src = s->src; a.sb = s->sb; a.sc = s->sc; a.sh = s->sh; a.sw = s->sw;
+  a.B = s->B; a.C = s->C; a.H = s->H; a.W = s->W; a.k = s->k; a.s = s->s; a.p = s->p; a.ldo = s->dimp; a.dtype = s->dtype;
+  a.gamma = s->norm1_w; a.mean = s->mean1; a.rstd = s->rstd1; a.eps = s->eps;
+}
+}  // namespace
+
+extern "C" int uvc_t2t_stage_forward(const uvc_t2t_stage* s, void* stream) {
+  if (!s || !s->src || !s->xn || !s->kqv || !s->att || !s->x1 || !s->h || !s->u || !s->out) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_t2t_stage_forward: null pointer");
+  if (s->training && !s->gp) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_t2t_stage_forward: training needs gp");
+  const int f32 = s->dtype == UVC_F32;
+  {
+    uvc_unfold_args a;
+    st_unfold(s, a);
+    a.beta = s->norm1_b; a.out = s->xn; a.out_is_f32 = f32;
+    ST_TRY(uvc_unfold_ln_fwd(&a, stream));
+  }
+  ST_TRY(st_nt(s, s->xn, s->kqv_w, s->kqv, 1, 192, s->dimp, UVC_EPI_BIAS, s->kqv_b, nullptr, 0, 0, nullptr, nullptr, stream));
+  {
+    uvc_performer_args a;
+    memset(&a, 0, sizeof(a));
+    a.kqv = s->kqv; a.w = s->w; a.part = s->part; a.kptv = s->kptv; a.att = s->att; a.att_is_f32 = f32; a.B = s->B; a.T = s->T; a.dtype = s->dtype;
+    ST_TRY(uvc_performer_fwd(&a, stream));
+  }
+  // y = v + proj(att): v is columns 128 .. 191 of kqv (token_performer.py:52)
+  ST_TRY(st_nt(s, s->att, s->proj_w, s->x1, 1, 64, 64, UVC_EPI_BIAS_RESID, s->proj_b, s->kqv + 128, 1, 192, nullptr, nullptr, stream));
+  {
+    uvc_ln_args a;
+    memset(&a, 0, sizeof(a));
+    a.x = s->x1; a.gamma = s->norm2_w; a.beta = s->norm2_b; a.y = s->h; a.mean = s->mean2; a.rstd = s->rstd2; a.eps = s->eps;
+    a.rows = s->B * s->T; a.D = 64; a.rows_per_group = 1; a.group_stride = 64; a.dtype = s->dtype; a.y_is_f32 = f32;
+    ST_TRY(uvc_layernorm_fwd(&a, stream));
+  }
+  if (s->training) ST_TRY(st_nt(s, s->h, s->fc1_w, s->gp, 0, 64, 64, UVC_EPI_BIAS_GELU_GRAD, s->fc1_b, nullptr, 0, 0, nullptr, s->u, stream));   // C = GELU'(a), C2 = GELU(a)
+  else ST_TRY(st_nt(s, s->h, s->fc1_w, s->u, 0, 64, 64, UVC_EPI_BIAS_GELU_OUT, s->fc1_b, nullptr, 0, 0, nullptr, nullptr, stream));
+  return st_nt(s, s->u, s->fc2_w, s->out, 1, 64, 64, UVC_EPI_BIAS_RESID, s->fc2_b, s->x1, 1, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int uvc_t2t_stage_backward(const uvc_t2t_stage* s, void* stream) {
+  if (!s || !s->src || !s->dout || !s->da || !s->dh || !s->dx1 || !s->datt || !s->dkqv || !s->dkptv || !s->dxn || !s->tn_ws || !s->ln1_partial || !s->ln2_partial || !s->gp)
+    return uvc_set_error_msg(UVC_ERR_ARG, "uvc_t2t_stage_backward: null pointer");
+  if (s->need_dx && !s->dxu) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_t2t_stage_backward: need_dx without dxu");
+  const int f32 = s->dtype == UVC_F32;
+  ST_TRY(st_tn(s, s->dout, s->u, s->g_fc2_w, s->g_fc2_b, 64, 64, stream));
+  ST_TRY(st_nt(s, s->dout, s->fc2_wt, s->da, 0, 64, 64, UVC_EPI_MUL_AUX, nullptr, nullptr, 0, 0, s->gp, nullptr, stream));
+  ST_TRY(st_tn(s, s->da, s->h, s->g_fc1_w, s->g_fc1_b, 64, 64, stream));
+  ST_TRY(st_nt(s, s->da, s->fc1_wt, s->dh, 0, 64, 64, UVC_EPI_NONE, nullptr, nullptr, 0, 0, nullptr, nullptr, stream));
+  {
+    uvc_ln_args a;
+    memset(&a, 0, sizeof(a));
+    a.x = s->x1; a.gamma = s->norm2_w; a.mean = s->mean2; a.rstd = s->rstd2; a.dy = s->dh; a.dx = s->dx1; a.add1 = s->dout;
+    a.partial = s->ln2_partial; a.dgamma = s->g_norm2_w; a.dbeta = s->g_norm2_b; a.eps = s->eps; a.beta_acc = s->beta;
+    a.rows = s->B * s->T; a.D = 64; a.rows_per_group = 1; a.group_stride = 64; a.dtype = s->dtype; a.dy_is_f32 = f32; a.g_lowp = !f32;
+    ST_TRY(uvc_layernorm_bwd(&a, stream));
+  }
+  ST_TRY(st_tn(s, s->dx1, s->att, s->g_proj_w, s->g_proj_b, 64, 64, stream));
+  ST_TRY(st_nt(s, s->dx1, s->proj_wt, s->datt, 0, 64, 64, UVC_EPI_NONE, nullptr, nullptr, 0, 0, nullptr, nullptr, stream));
+  {
+    uvc_performer_args a;
+    memset(&a, 0, sizeof(a));
+    a.kqv = s->kqv; a.w = s->w; a.part = s->part; a.kptv = s->kptv; a.datt = s->datt; a.dskip = s->dx1; a.dkqv = s->dkqv; a.dkptv = s->dkptv; a.g_is_f32 = f32;
+    a.B = s->B; a.T = s->T; a.dtype = s->dtype;
+    ST_TRY(uvc_performer_bwd(&a, stream));
+  }
+  ST_TRY(st_tn(s, s->dkqv, s->xn, s->g_kqv_w, s->g_kqv_b, 192, s->dimp, stream));
+  ST_TRY(st_nt(s, s->dkqv, s->kqv_wt, s->dxn, 0, s->dimp, 192, UVC_EPI_NONE, nullptr, nullptr, 0, 0, nullptr, nullptr, stream));
+  uvc_unfold_args a;
+  st_unfold(s, a);
+  a.dy = s->dxn; a.dy_is_f32 = f32; a.partial = s->ln1_partial; a.dgamma = s->g_norm1_w; a.dbeta = s->g_norm1_b; a.beta_acc = s->beta;
+  a.dxu = s->need_dx ? s->dxu : nullptr; a.dxu_tap_major = s->need_dx ? 1 : 0;
+  return uvc_unfold_ln_bwd(&a, stream);
 }

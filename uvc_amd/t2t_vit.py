@@ -124,6 +124,7 @@ class T2T_ViT(DistilledVisionTransformer):
         self.eps = eps
         self.enable_warmup = enable_warmup
         self.frozen_weights = False
+        self.front_in_c = True                # a Token_performer stage is one C call (uvc_t2t_stage_forward / _backward); False: the same launches from Python (A/B, tests)
         self.two_stream_backward = True
         self._wgrad_stream = None
         self.grad_accumulate = False
@@ -350,8 +351,50 @@ class T2T_ViT(DistilledVisionTransformer):
         self._front_bufs[key] = bufs
         return bufs
 
-    def _performer_forward(self, name, src, strides, B, C_, H, W, k, s, p, b, training):
+    def _stage_struct(self, name, src, strides, B, C_, H, W, k, s, p, b, bufs, training, need_dx):
+        """uvc_t2t_stage of one Token_performer stage (the whole stage is ONE call across the boundary, include/uvc_t2t.h): pointers into the flat
+        parameter / gradient buffers, the weight shadows and the stage's buffers -- all of them live as long as `b` does."""
+        key = "_stage_struct"
+        st = b.get(key)
+        f, sh = self._front[name], self._front_weights()
+        fp, fg = self._fp, self._fg
+        if st is None:
+            st = L.uvc_t2t_stage()
+            st.B, st.C, st.H, st.W, st.k, st.s, st.p = B, C_, H, W, k, s, p
+            st.T, st.dim, st.dimp, st.dtype, st.training, st.eps = b["T"], f["dim"], f["dimp"], self._dt(), int(training), LN_EPS
+            for n_, t_ in (("norm1_w", fp(f["norm1_w"], f["dim"])), ("norm1_b", fp(f["norm1_b"], f["dim"])), ("kqv_b", fp(f["kqv_b"], 192)), ("w", fp(f["w"], 32, 64)),
+                           ("proj_b", fp(f["proj_b"], 64)), ("norm2_w", fp(f["norm2_w"], 64)), ("norm2_b", fp(f["norm2_b"], 64)), ("fc1_b", fp(f["fc1_b"], 64)),
+                           ("fc2_b", fp(f["fc2_b"], 64))):
+                setattr(st, n_, L.ptr(t_))
+            for key_ in ("kqv", "proj", "fc1", "fc2"):
+                w_, wt_ = sh[name + "." + key_]
+                setattr(st, key_ + "_w", L.ptr(w_))
+                setattr(st, key_ + "_wt", L.ptr(wt_))
+            for n_ in ("xn", "mean1", "rstd1", "kqv", "part", "kptv", "att", "x1", "h", "mean2", "rstd2", "u", "out"):
+                setattr(st, n_, L.ptr(b[n_]))
+            if training:
+                for n_, t_ in (("g_norm1_w", fg(f["norm1_w"], f["dim"])), ("g_norm1_b", fg(f["norm1_b"], f["dim"])), ("g_kqv_w", fg(f["kqv_w"], 192, f["dimp"])),
+                               ("g_kqv_b", fg(f["kqv_b"], 192)), ("g_proj_w", fg(f["proj_w"], 64, 64)), ("g_proj_b", fg(f["proj_b"], 64)), ("g_norm2_w", fg(f["norm2_w"], 64)),
+                               ("g_norm2_b", fg(f["norm2_b"], 64)), ("g_fc1_w", fg(f["fc1_w"], 64, 64)), ("g_fc1_b", fg(f["fc1_b"], 64)), ("g_fc2_w", fg(f["fc2_w"], 64, 64)),
+                               ("g_fc2_b", fg(f["fc2_b"], 64))):
+                    setattr(st, n_, L.ptr(t_))
+                for n_ in ("gp", "dout", "da", "dh", "dx1", "datt", "dkqv", "dkptv", "dxn", "ln2_partial", "ln1_partial"):
+                    setattr(st, n_, L.ptr(b[n_]))
+                st.dxu = L.ptr(b["dxu"]) if b["dxu"] is not None else None
+                st.tn_ws, st.tn_ws_bytes = L.ptr(bufs["tn_ws"]), bufs["tn_ws"].numel()
+            b[key] = st
+        st.src = L.ptr(src)                      # the image of this batch / the previous stage's output
+        st.sb, st.sc, st.sh, st.sw = strides
+        st.beta = 1.0 if self.grad_accumulate else 0.0
+        st.need_dx = int(bool(need_dx))
+        return st
+
+    def _performer_forward(self, name, src, strides, B, C_, H, W, k, s, p, b, training, bufs=None):
         """One Token_performer stage (token_performer.py:45-69) on the soft split of `src`; result in b['out'] [B*T, 64]."""
+        if self.front_in_c:
+            st = self._stage_struct(name, src, strides, B, C_, H, W, k, s, p, b, bufs, training, False)
+            L.check(L.lib().uvc_t2t_stage_forward(C.byref(st), L.cur_stream()), "uvc_t2t_stage_forward")
+            return
         f, dt, sh = self._front[name], self._dt(), self._front_weights()
         M, T = b["M"], b["T"]
         fp = self._fp
@@ -378,9 +421,9 @@ class T2T_ViT(DistilledVisionTransformer):
         s1, s2, s3 = bufs["side"]
         dt = self._dt()
         b1, b2 = bufs["attention1"], bufs["attention2"]
-        self._performer_forward("attention1", x, (3 * S * S, S * S, S, 1), B, 3, S, S, 7, 4, 2, b1, training)
+        self._performer_forward("attention1", x, (3 * S * S, S * S, S, 1), B, 3, S, S, 7, 4, 2, b1, training, bufs)
         tok = lambda side: (side * side * 64, 1, side * 64, 64)          # token-major [B, side*side, 64] read as [B, 64, side, side]
-        self._performer_forward("attention2", b1["out"], tok(s1), B, 64, s1, s1, 3, 2, 1, b2, training)
+        self._performer_forward("attention2", b1["out"], tok(s1), B, 64, s1, s1, 3, 2, 1, b2, training, bufs)
         ops.unfold_ln_fwd(b2["out"], tok(s2), B, 64, s2, s2, 3, 2, 1, bufs["tok_u"], dt)
         pe = self._ws_view(B, training, "pe")
         ops.gemm_nt(bufs["tok_u"], self._front_weights()["project"][0], pe, dtype=dt, epilogue=ops.EPI_BIAS, bias=self._fp(self._front["project_b"], self.embed_dim))
@@ -389,6 +432,10 @@ class T2T_ViT(DistilledVisionTransformer):
 
     def _performer_backward(self, name, src, strides, B, C_, H, W, k, s, p, b, bufs, need_dx):
         """Backward of one stage from b['dout'] [B*T, 64]; leaves d(unfolded input) in b['dxu'] when the source needs it."""
+        if self.front_in_c:
+            st = self._stage_struct(name, src, strides, B, C_, H, W, k, s, p, b, bufs, True, need_dx)
+            L.check(L.lib().uvc_t2t_stage_backward(C.byref(st), L.cur_stream()), "uvc_t2t_stage_backward")
+            return
         f, dt, sh = self._front[name], self._dt(), self._front_weights()
         M, T = b["M"], b["T"]
         fp, fg = self._fp, self._fg

@@ -7,6 +7,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from uvc_amd import _lib  # noqa: E402
+if os.environ.get("UVC_LIB"):
+    _lib.LIB_PATH = os.environ["UVC_LIB"]
 from uvc_amd import ops  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -97,6 +97,32 @@ __device__ __forceinline__ float sum_rows4(float v) {
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// Sum over aligned groups of W lanes (16, 32 or 64), in every lane: the butterfly  v += shfl_xor(v, 1); v += shfl_xor(v, 2); ... v += shfl_xor(v, W / 2)
+// with the SAME additions (same bits) and no LDS crossbar: quad swaps by DPP, then the mirrored half row / row -- after the steps before them every lane of a
+// quad / of a half row holds the same partial sum, so the mirrored partner carries exactly what the xor-4 / xor-8 partner would -- then the row swaps.
+// (__shfl_xor compiles to ds_bpermute_b32: a dependent chain of 4-6 LDS round trips per reduction; the soft-split kernels spent 40 % of their time there.)
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int W> __device__ __forceinline__ float xor_tree_sum(float v) {
+  static_assert(W == 16 || W == 32 || W == 64, "group width");
+  v = dpp_add<0xB1>(v);            // quad_perm [1, 0, 3, 2]   = xor 1
+  v = dpp_add<0x4E>(v);            // quad_perm [2, 3, 0, 1]   = xor 2
+  v = dpp_add<0x141>(v);           // row_half_mirror          = xor 4 (on quad-uniform values)
+  v = dpp_add<0x140>(v);           // row_mirror               = xor 8 (on half-row-uniform values)
+  if (W >= 32) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  if (W == 64) {
+    const unsigned c = __float_as_uint(v);
+    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+    v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+  }
+  return v;
+}
+
 __device__ __forceinline__ float max_rows4(float v) {           // max over lanes l, l^16, l^32, l^48, in every lane
   const unsigned u = __float_as_uint(v);
   const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);

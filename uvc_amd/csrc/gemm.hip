@@ -2259,14 +2259,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
             v[i] = Raw4L<bf16_t>::cvt(q);                          // the LayerNorm is taken of the stored (rounded) row, as the stand-alone pass does
             sm += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
           }
-          sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
+          sm = xor_tree_sum<16>(sm);                   // (k_ln_fwd_v's sum16)
           const float mean = sm * invD384;
           float qq = 0.f;
 #pragma unroll
           for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float dd = v[i][e] - mean; qq += dd * dd; }
-          qq += __shfl_xor(qq, 1, 64); qq += __shfl_xor(qq, 2, 64); qq += __shfl_xor(qq, 4, 64); qq += __shfl_xor(qq, 8, 64);
+          qq = xor_tree_sum<16>(qq);
           const float rstd = rsqrtf(qq * invD384 + f.ln_eps);
           if (ok_[it]) {
             bf16_t* y = reinterpret_cast<bf16_t*>(f.ln_out) + (size_t)rows_[it] * D;
@@ -2342,10 +2342,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_row384_lnbwd(LnbArgs g, int til
             c1 += gy[i][e];
             c2 += gy[i][e] * xh;
           }
-#pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) c1 += __shfl_xor(c1, o, 64);
-#pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) c2 += __shfl_xor(c2, o, 64);
+        c1 = xor_tree_sum<LPR>(c1);                    // (k_ln_bwd_v's sum_lpr: the same additions)
+        c2 = xor_tree_sum<LPR>(c2);
         c1 *= invD; c2 *= invD;
         if (R.ok) {
           bf16_t* dx = reinterpret_cast<bf16_t*>(g.dx) + (size_t)R.r * D;

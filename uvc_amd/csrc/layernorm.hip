@@ -174,10 +174,7 @@ template <> struct Raw4<bf16_t> {
     return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
   }
 };
-__device__ __forceinline__ float sum16(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-  return v;
-}
+__device__ __forceinline__ float sum16(float v) { return xor_tree_sum<16>(v); }       // (same bits as the xor-shuffle butterfly 1, 2, 4, 8: common.h)
 
 constexpr int LNV_FWD_ROWS = 64;     // rows per block (16 per wave, 4 at a time)
 // TX: element type of x (float32, or bf16 = the bf16 residual stream of the throughput mode; statistics stay float32)
@@ -240,11 +237,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd_v(uvc_ln_args a) {
 // TG: element type of the gradient stream (dx, add1, add2): float32, or bf16 when uvc_ln_args.g_lowp is set.
 // LPR lanes share a row (D = 4 * LPR * NV4): 16 for D <= 192, 32 for 384, 64 for 768, so that NV4 stays <= 3 and the two
 // row register sets fit (with 16 lanes per row D = 384 took all 256 VGPRs and D = 768 spilled ~750 registers to scratch).
-template <int LPR> __device__ __forceinline__ float sum_lpr(float v) {
-#pragma unroll
-  for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+template <int LPR> __device__ __forceinline__ float sum_lpr(float v) { return xor_tree_sum<LPR>(v); }     // (the butterfly 1, 2, ..., LPR / 2)
 template <typename TX, typename TDY, typename TG, int NV4, int LPR>
 __global__ __launch_bounds__(256) void k_ln_bwd_v(uvc_ln_args a, int rpb) {
   constexpr int DD = 4 * LPR * NV4, RPW = 64 / LPR;        // row length; rows a wave handles at a time

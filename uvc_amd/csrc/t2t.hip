@@ -27,20 +27,9 @@ struct UG {                       // unfold geometry + pointers, passed by value
 // Integer divisions stay out of the row loop (with runtime k / kk / L they were ~2000 VALU cycles per row, more than the loads):
 // workgroups walk (image, output row) pairs and their waves the output columns, the taps of the token-major path advance
 // incrementally, and the generic path decomposes its features once per lane (LaneTaps).
-// Sum over the 64 lanes, in every lane, without the LDS crossbar: four DPP steps inside the 16-lane rows (quad swaps, then the mirrored half / row, whose partner
-// lanes hold the same partial sums as the xor-4 / xor-8 partners would), then the two row-swap instructions (sum_rows4).  wave_sum's six dependent ds_bpermute
-// round trips were 40 % of the image split's time (twice per row; with the LayerNorm arithmetic removed 149 -> 87 us): image split forward 139 -> 125 us, stage 2 forward
-// 87 -> 67 us (same box).
-template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v = dpp_add<0xB1>(v);            // quad_perm [1, 0, 3, 2]
-  v = dpp_add<0x4E>(v);            // quad_perm [2, 3, 0, 1]
-  v = dpp_add<0x141>(v);           // row_half_mirror
-  v = dpp_add<0x140>(v);           // row_mirror
-  return sum_rows4(v);
-}
+// wave sums of the forward kernels by DPP + row swaps (common.h: xor_tree_sum) instead of wave_sum's six dependent ds_bpermute round trips: with the LayerNorm
+// arithmetic removed the image split went 149 -> 87 us; image split forward 139 -> 125 us, stage 2 forward 87 -> 67 us (same box)
+__device__ __forceinline__ float wave_sum_dpp(float v) { return xor_tree_sum<64>(v); }
 template <int NV> struct LaneTaps { int off[NV], ki[NV], kj[NV]; };
 template <int NV>
 __device__ __forceinline__ LaneTaps<NV> lane_taps(const UG& g, int lane) {

@@ -415,8 +415,7 @@ __device__ __forceinline__ void prm_t(const float (&wf)[2][16], const float (&xf
     c1 = mfma4(wf[1][s], xf[s], c1);
     xx += xf[s] * xf[s];
   }
-  xx += __shfl_xor(xx, 16, 64);
-  xx += __shfl_xor(xx, 32, 64);
+  xx = sum_rows4(xx);
 #pragma unroll
   for (int r = 0; r < 4; ++r) { p[0][r] = expf(c0[r] - 0.5f * xx) / SQRT_M; p[1][r] = expf(c1[r] - 0.5f * xx) / SQRT_M; }
 }
@@ -528,8 +527,7 @@ __global__ __launch_bounds__(256) void k_performer_q_mfma(const float* kqv, cons
   for (int r = 0; r < 4; ++r) den += p[0][r] * ksum0[r];
 #pragma unroll
   for (int r = 0; r < 4; ++r) den += p[1][r] * ksum1[r];
-  den += __shfl_xor(den, 16, 64);
-  den += __shfl_xor(den, 32, 64);
+  den = sum_rows4(den);
   den += 1e-8f;
 #pragma unroll
   for (int et = 0; et < 4; ++et) {
@@ -608,8 +606,7 @@ __device__ __forceinline__ void prm_bwd_t(const float (&wT)[4][8], const float (
   for (int r = 0; r < 4; ++r) gs += gq[0][r];
 #pragma unroll
   for (int r = 0; r < 4; ++r) gs += gq[1][r];
-  gs += __shfl_xor(gs, 16, 64);
-  gs += __shfl_xor(gs, 32, 64);
+  gs = sum_rows4(gs);
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
@@ -668,8 +665,7 @@ __global__ __launch_bounds__(256) void k_performer_bwd_q_mfma(const float* kqv, 
     for (int r = 0; r < 4; ++r) den += p[0][r] * ksum0[r];
 #pragma unroll
     for (int r = 0; r < 4; ++r) den += p[1][r] * ksum1[r];
-    den += __shfl_xor(den, 16, 64);
-    den += __shfl_xor(den, 32, 64);
+    den = sum_rows4(den);
     den += 1e-8f;
     float dot = 0.f;                                   // sum_n dy num
 #pragma unroll
@@ -682,8 +678,7 @@ __global__ __launch_bounds__(256) void k_performer_bwd_q_mfma(const float* kqv, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) { dot += dy[et][r] * c[r]; dy[et][r] = dy[et][r] / den; }       // dy becomes dnum
     }
-    dot += __shfl_xor(dot, 16, 64);
-    dot += __shfl_xor(dot, 32, 64);
+    dot = sum_rows4(dot);
     const float dden = -dot / (den * den);
     __syncthreads();                                   // the column reads of the tile before are done
 #pragma unroll

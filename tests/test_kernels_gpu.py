@@ -217,6 +217,52 @@ def test_attention_fwd_bwd(dtype, B, N, H):
     torch.testing.assert_close(dqkv.double(), x.grad, **tb)
 
 
+@pytest.mark.parametrize("B,N,H,grid", [(2, 197, 3, 0), (7, 197, 3, 4), (3, 198, 2, 2), (5, 193, 1, 2), (2, 200, 2, 1)])
+def test_attention_backward_one_pass(B, N, H, grid):
+    """The one-pass persistent backward (uvc_attn_args.variant 2: k_attn_bwd_one, r5) against float64 and against the dq + dk/dv pair
+    (variant 1); several heads per workgroup (grid < B * H, uneven head counts per workgroup), both ends of its N range; bit-identical
+    repeat; variant 0 picks it at these shapes."""
+    from uvc_amd import ops
+    D = H * 64
+    qkv = to_t(rnd(B, N, 3 * D, seed=31), BF16)
+    dout = to_t(rnd(B, N, D, seed=32), BF16)
+    o = torch.empty(B, N, D, device=dev(), dtype=torch.bfloat16)
+    lse = torch.empty(B, H, N, device=dev())
+    ops.attention_fwd(qkv, o, lse, B, N, H, BF16)
+    x = qkv.double().requires_grad_(True)
+    q, k, v = x.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * 64 ** -0.5
+    ref = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, N, D)
+    ref.backward(dout.double())
+    outs = []
+    for variant, gr in ((1, 0), (2, grid), (2, grid), (0, 0)):
+        dqkv = torch.full((B, N, 3 * D), float("nan"), device=dev(), dtype=torch.bfloat16)
+        delta = torch.full((B, H, N), float("nan"), device=dev())
+        ops.attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, BF16, variant=variant, grid=gr)
+        torch.testing.assert_close(dqkv.double(), x.grad, rtol=5e-2, atol=6e-2)
+        torch.testing.assert_close(delta.double(), (dout.double() * o.double()).view(B, N, H, 64).sum(-1).permute(0, 2, 1), rtol=1e-3, atol=1e-3)
+        outs.append(dqkv)
+    assert torch.equal(outs[1], outs[2])                       # repeat: same bits
+    assert torch.equal(outs[1], outs[3])                       # variant 0 is the one-pass kernel here (any grid: same bits)
+    # closer to the pair than the bf16 tolerance against float64: the two differ by the rounding of P / dS only
+    e_pair = (outs[0].double() - x.grad).abs().max().item()
+    e_one = (outs[1].double() - x.grad).abs().max().item()
+    assert e_one <= 1.5 * e_pair + 1e-3, (e_one, e_pair)
+    err = lambda t: ((t.double() - x.grad).norm() / x.grad.norm()).item()
+    assert err(outs[1]) <= 1.1 * err(outs[0]) + 1e-4, (err(outs[1]), err(outs[0]))
+
+
+def test_attention_backward_one_pass_refuses_other_shapes():
+    from uvc_amd import ops
+    from uvc_amd._lib import UvcHipError
+    B, N, H = 1, 64, 1
+    qkv = to_t(rnd(B, N, 3 * 64, seed=33), BF16)
+    o = torch.zeros(B, N, 64, device=dev(), dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, N, device=dev())
+    with pytest.raises(UvcHipError):
+        ops.attention_bwd(qkv, o, lse, o.clone(), torch.empty_like(qkv), torch.empty_like(lse), B, N, H, BF16, variant=2)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_attention_backward_head_keep(dtype):
     """uvc_attention_bwd with head_keep: heads marked 0 get dq = dk = dv = 0 without being computed -- what the full computation gives

@@ -56,7 +56,8 @@ class uvc_gemm_tn_args(C.Structure):
 
 class uvc_attn_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("qkv", "o", "lse", "dout", "dqkv", "delta")] + \
-               [(n, C.c_int32) for n in ("B", "N", "H", "head_dim", "dtype")] + [("scale", C.c_float), ("head_keep", C.c_void_p)]
+               [(n, C.c_int32) for n in ("B", "N", "H", "head_dim", "dtype")] + [("scale", C.c_float), ("head_keep", C.c_void_p),
+                                                                                ("variant", C.c_int32), ("grid", C.c_int32)]
 
 
 class uvc_attn_tok_args(C.Structure):

@@ -507,6 +507,277 @@ __global__ __launch_bounds__(512) void k_attn_bwd_dkv(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward as ONE persistent kernel (bf16, round 5): every operand of a head crosses the memory system once (q, k, v, dO, O in, dq, dk, dv
+// out = the 8 u of the roofline accounting), S and dP are computed once per (query tile, key tile) and feed all three products
+// (5 matmuls where the dq + dk/dv pair above runs 7, one exp2 per score instead of two).
+//
+// One workgroup per CU walks (image, head) pairs.  NT compute waves + 3 helper waves:
+//   * compute wave w owns KEY tile w (K fragments from the LDS image, V fragments straight from global memory, dK^T / dV^T accumulators) and
+//     QUERY tile w (dQ^T accumulators).  Step s = 0 .. NT-1 pairs its keys with query tile t = (w + s) % NT:
+//         S = Q_t K_w^T, dP = dO_t V_w^T (lane (key, g) holds queries 4g .. 4g+3), P = exp2(S c2 - lse), dS = P (dP - delta) scale,
+//         dV_w^T += dO_t^T P, dK_w^T += Q_t^T dS (the 16 queries on the k dimension), dS -> this wave's 512-byte exchange tile [key][query];
+//     then it reads the tile wave (w - s) % NT left for query tile w back TRANSPOSED (ds_read_b64_tr_b16) and adds K_p^T dS^T to dQ_w^T.
+//     Every query tile receives its NT contributions in step order: deterministic, no atomics.  The hand-over is point to point -- a
+//     produced / consumed counter pair per tile in LDS (DS operations of a wave execute in order, so the counter write follows the tile
+//     write) -- NOT a workgroup barrier: the r4 form of this kernel spent 30 of its 146 us in 14 barriers per head, all 16 waves in the
+//     same phase at the same time.  One barrier per HEAD is left.
+//   * the helper waves bring the NEXT head's Q, dO, K images into the other half of the LDS by LDS-DMA (global_load_lds_dwordx4, no
+//     registers, no ds_write) while the compute waves run the steps of the current one, and take delta = rowsum(dO * O) and lse * log2(e)
+//     for it: the r4 form ran [stage 100 KB | steps | store 75 KB] back to back, 78 + 68 us.  The compute waves' code contains no DMA, so
+//     hipcc does not drain vmcnt in front of their LDS reads.
+// LDS (NT = 13, N <= 200): 2 x 3 images of 200 rows x 128 bytes (unpadded: chunk c of row r sits at c ^ swz(r), conflict-free for the
+// b128 row fragments and the b64 transposing reads alike; the DMA writes lane-linearly, so the swizzle is on its SOURCE address) = 153 600,
+// exchange tiles 6 656, lse / delta 2 x 1 664, counters 128: 163 712 of 163 840 bytes.  Tile NT-1 reads 8 rows past its image: whatever
+// lies there is finite bf16 (the LDS is zeroed at the start, then only images and dS tiles are written) and meets P = dS = 0: padded
+// queries have lse = +inf, padded keys are masked in the last key tile's wave.
+namespace one {
+// timing probes (tools/attn_probes.sh builds the variants; wrong numbers on purpose; the library is built with 0):
+//   1 = no steps (images in, results out)   2 = steps without the counter waits   3 = no images (the helpers fetch nothing)   4 = no result stores
+#ifndef UVC_ATTN_PROBE
+#define UVC_ATTN_PROBE 0
+#endif
+constexpr int ROW = 128;
+__device__ __forceinline__ int swz(int r) { return ((r >> 1) & 3) << 1; }
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mma16(const s16x4v& a, const s16x4v& b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ s16x4v trd(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4v))(p)); }
+__device__ __forceinline__ s16x4v pack4(const f32x4& v) {
+  u32x2 r; r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]);
+  return __builtin_bit_cast(s16x4v, r);
+}
+// Produced / consumed counters in LDS, accessed by DS instructions written out by hand: through a generic pointer hipcc emits FLAT loads /
+// stores (vmcnt, and no ordering against the wave's DS operations); DS operations of one wave execute in order, which is what makes
+// "tile write, then counter write" / "counter read, then tile read" a hand-over.  (An asm DS operation the compiler does not count only
+// makes its own s_waitcnt lgkmcnt(n) wait for more, never less: the counter retires in order.)
+__device__ __forceinline__ int lds_poll(unsigned addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+// (bounded: a protocol error must show as wrong numbers in a test, not as a hung GPU -- 2^18 polls are ~20 ms, a hand-over takes < 1 us)
+__device__ __forceinline__ void spin_ge(unsigned addr, int v) {
+  if (UVC_ATTN_PROBE == 2) return;
+  for (int n = 0; lds_poll(addr) < v && n < (1 << 18); ++n) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void post(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+template <int NT, int R> struct Lay {
+  static constexpr int IMG = R * ROW, BUF = 3 * IMG;
+  static constexpr int OFF_X = 2 * BUF;                         // exchange tiles [NT][512]
+  static constexpr int OFF_LD = OFF_X + NT * 512;               // [2 buffers][lse2, delta][NT * 16] float
+  static constexpr int OFF_FL = OFF_LD + 2 * 2 * NT * 16 * 4;   // produced[16], consumed[16]
+  static constexpr int TOTAL = OFF_FL + 128;
+  static_assert(TOTAL <= 163840 && TOTAL % 16 == 0 && R % 8 == 0 && R <= NT * 16 && R + 8 >= NT * 16, "layout");
+};
+constexpr int NH = 3;                                           // helper waves
+
+template <int NT, int R>
+__global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  typedef Lay<NT, R> L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and the compiler knows it: tile indices and counters in SGPRs
+  const int nbh = a.B * a.H;
+  const size_t ldq = (size_t)3 * a.H * HD, ldo = (size_t)a.H * HD;
+  {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid * 16; i < L::TOTAL; i += (NT + NH) * 64 * 16) *reinterpret_cast<u32x4*>(smem + i) = z;
+  }
+  __syncthreads();
+  const unsigned fP = (unsigned)(size_t)(LDS_PTR(char))smem + L::OFF_FL, fC = fP + 64;      // LDS byte addresses of produced[16], consumed[16]
+  float* sLD = reinterpret_cast<float*>(smem + L::OFF_LD);
+  if ((int)blockIdx.x >= nbh) return;
+
+  if (w >= NT) {
+    // ------------------------------------------------------------------------------ helper waves: the next head's images, lse, delta
+    constexpr int NP = R / 8;                                   // 1-KB pieces (8 rows) per image
+    constexpr int NPH = (NP + NH - 1) / NH;                     // ... per helper (the last one may be issued twice: no branch around a DMA)
+    constexpr int NLS = (NT * 16 + NH * 64 - 1) / (NH * 64);
+    const int j = w - NT;
+    const int rr = lane >> 3, gc = (lane & 7) ^ swz(rr);
+    auto fill = [&](int bh, int buf) {
+      const int b = bh / a.H, h = bh % a.H;
+      const char* qb = reinterpret_cast<const char*>(a.qkv) + ((size_t)b * a.N * ldq + h * HD) * 2;
+      const char* kb = qb + a.H * HD * 2;
+      const char* dob = reinterpret_cast<const char*>(a.dout) + ((size_t)b * a.N * ldo + h * HD) * 2;
+      const char* ob = reinterpret_cast<const char*>(a.o) + ((size_t)b * a.N * ldo + h * HD) * 2;
+      char* img = smem + buf * L::BUF;
+      u32x4 ov[NPH];
+      float ls[NLS];
+      // piece i of this helper is p = j + NH i: rows 8 p + rr.  Only the LAST one can run past the image (p > NP - 1: issued again as
+      // piece NP - 1, no branch around a DMA) or past the sequence (row > N - 1: that row's lanes fetch row N - 1 -- finite, never used);
+      // the others are one 32-bit lane offset against a wave-uniform base that advances by NH * 8 rows (SGPR arithmetic).
+      const unsigned lq = (unsigned)((8 * j + rr) * ldq * 2 + gc * 16), lo = (unsigned)((8 * j + rr) * ldo * 2 + gc * 16);
+      const int pl = min(j + NH * (NPH - 1), NP - 1), rl = min(8 * pl + rr, a.N - 1);
+      const unsigned lql = (unsigned)(rl * ldq * 2 + gc * 16), lol = (unsigned)(rl * ldo * 2 + gc * 16);
+#pragma unroll
+      for (int i = 0; i < NPH; ++i) {
+        const bool last = i == NPH - 1;
+        ov[i] = *reinterpret_cast<const u32x4*>(last ? ob + lol : ob + (size_t)i * NH * 8 * ldo * 2 + lo);
+      }
+#pragma unroll
+      for (int i = 0; i < NLS; ++i) {
+        const int r = (i * NH + j) * 64 + lane;
+        ls[i] = r < a.N ? a.lse[((size_t)b * a.H + h) * a.N + r] * 1.44269504088896340736f : INFINITY;
+      }
+#pragma unroll
+      for (int i = 0; i < NPH; ++i) {
+        const bool last = i == NPH - 1;
+        const int p = last ? pl : j + NH * i;
+        const size_t sq = (size_t)i * NH * 8 * ldq * 2, so = (size_t)i * NH * 8 * ldo * 2;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(last ? qb + lql : qb + sq + lq),
+                                         (void __attribute__((address_space(3)))*)(img + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(last ? dob + lol : dob + so + lo),
+                                         (void __attribute__((address_space(3)))*)(img + L::IMG + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(last ? kb + lql : kb + sq + lq),
+                                         (void __attribute__((address_space(3)))*)(img + 2 * L::IMG + p * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces have landed (its own dO rows are read next)
+      float* sLse = sLD + buf * 2 * NT * 16;
+      float* sDel = sLse + NT * 16;
+#pragma unroll
+      for (int i = 0; i < NPH; ++i) {
+        const int p = min(j + NH * i, NP - 1), row = 8 * p + rr;
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(img + L::IMG + p * 1024 + lane * 16);
+        float d = frag_dot<T>(x, __builtin_bit_cast(bf16x8, ov[i]));
+        d = dpp_add<0xB1>(d); d = dpp_add<0x4E>(d); d = dpp_add<0x141>(d);      // the 8 lanes of a row
+        if ((lane & 7) == 0) {
+          sDel[row] = row < a.N ? d : 0.f;
+          if (row < a.N && a.delta) a.delta[((size_t)b * a.H + h) * a.N + row] = d;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NLS; ++i) {
+        const int r = (i * NH + j) * 64 + lane;
+        if (r < NT * 16) sLse[r] = ls[i];
+      }
+    };
+    auto dead = [&](int bh) { return a.head_keep && a.head_keep[bh % a.H] == 0; };
+    int bh = blockIdx.x, it = 0;
+    if (!dead(bh) && UVC_ATTN_PROBE != 3) fill(bh, 0);
+    __syncthreads();
+    for (; bh < nbh; bh += gridDim.x, ++it) {
+      const int nxt = bh + (int)gridDim.x;
+      if (nxt < nbh && !dead(nxt) && UVC_ATTN_PROBE != 3) fill(nxt, (it + 1) & 1);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------- compute waves
+  const int key = w * 16 + li;
+  const float c2 = a.scale * 1.44269504088896340736f;
+  const bool last_keys = w * 16 + 16 > a.N;                     // (wave-uniform) this wave's key tile holds padded keys
+  const int offA = li * ROW + ((g ^ swz(li)) << 4);             // row fragment: row li of a tile, chunk g (k-step 1: ^ 64)
+  const int rT = 4 * g + (li >> 2);
+  const int offT = rT * ROW + ((swz(rT) | ((li & 3) >> 1)) << 4) + (li & 1) * 8;   // transposing read, columns 0 .. 15 (dt: ^ (dt << 5))
+  const int offXw = li * 32 + g * 8, offXr = rT * 32 + (li & 3) * 8;
+  char* sX = smem + L::OFF_X;
+  const unsigned voff = (unsigned)(key * ldq * 2 + g * 16);     // this lane's V fragment / result rows: one 32-bit offset against a wave-uniform base
+  auto load_v = [&](int bh, u32x4 (&v)[2]) {
+    const char* vb = reinterpret_cast<const char*>(a.qkv) + ((size_t)(bh / a.H) * a.N * ldq + (bh % a.H) * HD + 2 * a.H * HD) * 2;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) v[ks] = key < a.N ? *reinterpret_cast<const u32x4*>(vb + voff + ks * 64) : z;
+  };
+  u32x4 vnext[2];
+  int gstep = 0, it = 0, bh = blockIdx.x;
+  load_v(bh, vnext);
+  __syncthreads();
+  for (; bh < nbh; bh += gridDim.x, ++it) {
+    const int b = bh / a.H, h = bh % a.H;
+    const int nxt = bh + (int)gridDim.x;
+    char* dqb = reinterpret_cast<char*>(a.dqkv) + ((size_t)b * a.N * ldq + h * HD) * 2;
+    char* dkb = dqb + a.H * HD * 2;
+    char* dvb = dkb + a.H * HD * 2;
+    const unsigned soff = (unsigned)(key * ldq * 2 + g * 8);
+    if (a.head_keep && a.head_keep[h] == 0) {                   // pruned head (uvc_attn_args.head_keep): dq = dk = dv = 0 exactly
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      if (key < a.N) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          Store4<T>::st(reinterpret_cast<T*>(dqb + soff + d * 32), z);
+          Store4<T>::st(reinterpret_cast<T*>(dkb + soff + d * 32), z);
+          Store4<T>::st(reinterpret_cast<T*>(dvb + soff + d * 32), z);
+        }
+      }
+      if (nxt < nbh) load_v(nxt, vnext);
+      __syncthreads();
+      continue;
+    }
+    const char* sQ = smem + (it & 1) * L::BUF;
+    const char* sDO = sQ + L::IMG;
+    const char* sK = sDO + L::IMG;
+    const float* sLse = sLD + (it & 1) * 2 * NT * 16;
+    const float* sDel = sLse + NT * 16;
+    typename MM::Frag kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      vf[ks] = __builtin_bit_cast(typename MM::Frag, vnext[ks]);
+      kf[ks] = *reinterpret_cast<const typename MM::Frag*>(sK + w * 16 * ROW + (offA ^ (ks * 64)));
+    }
+    f32x4 dk[4], dv[4], dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; dq[dt] = dk[dt]; }
+    auto step = [&](int s) {
+      int t = w + s; if (t >= NT) t -= NT;                      // the query tile this wave's keys meet now
+      const char* qt = sQ + t * 16 * ROW;
+      const char* dt_ = sDO + t * 16 * ROW;
+      f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        c = MM::mma(*reinterpret_cast<const typename MM::Frag*>(qt + (offA ^ (ks * 64))), kf[ks], c);
+        dp = MM::mma(*reinterpret_cast<const typename MM::Frag*>(dt_ + (offA ^ (ks * 64))), vf[ks], dp);
+      }
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + t * 16 + g * 4);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + t * 16 + g * 4);
+      f32x4 pp, ds;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pr = __builtin_amdgcn_exp2f(c[e] * c2 - l4[e]);
+        pp[e] = pr;
+        ds[e] = pr * ((dp[e] - d4[e]) * a.scale);
+      }
+      if (last_keys && key >= a.N) { pp = f32x4{0.f, 0.f, 0.f, 0.f}; ds = pp; }      // padded keys: their K rows in LDS are not zeros
+      const s16x4v pf = pack4(pp), dsf = pack4(ds);
+      spin_ge(fC + w * 4, gstep);                                   // the tile of the step before has been read
+      *reinterpret_cast<s16x4v*>(sX + w * 512 + offXw) = dsf;   // [key][query]
+      post(fP + w * 4, gstep + 1);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        dv[d] = mma16(trd(dt_ + (offT ^ (d << 5))), pf, dv[d]);
+        dk[d] = mma16(trd(qt + (offT ^ (d << 5))), dsf, dk[d]);
+      }
+      int pw = w - s; if (pw < 0) pw += NT;                     // the wave whose keys met query tile w in this step
+      spin_ge(fP + pw * 4, gstep + 1);
+      const s16x4v dst = trd(sX + pw * 512 + offXr);
+      const char* kp = sK + pw * 16 * ROW;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dq[d] = mma16(trd(kp + (offT ^ (d << 5))), dst, dq[d]);
+      post(fC + pw * 4, gstep + 1);
+      ++gstep;
+    };
+    constexpr int SPLIT = NT >= 3 ? NT - 2 : 0;                 // the next head's V rows are requested under the last two steps
+#pragma unroll 1
+    for (int s = 0; s < (UVC_ATTN_PROBE == 1 ? 0 : SPLIT); ++s) step(s);
+    if (nxt < nbh) load_v(nxt, vnext);
+#pragma unroll 1
+    for (int s = SPLIT; s < (UVC_ATTN_PROBE == 1 ? 0 : NT); ++s) step(s);
+    if (key < a.N && UVC_ATTN_PROBE != 4) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        Store4<T>::st(reinterpret_cast<T*>(dkb + soff + d * 32), dk[d]);
+        Store4<T>::st(reinterpret_cast<T*>(dvb + soff + d * 32), dv[d]);
+        Store4<T>::st(reinterpret_cast<T*>(dqb + soff + d * 32), dq[d]);      // (query tile w: the same row index)
+      }
+    }
+    __syncthreads();                                            // every wave is done with this head's images; the next head's have landed
+  }
+}
+}  // namespace one
+
 template <typename T, int NT16> int launch(const AttnArgs& a, int which, hipStream_t st) {
   const int NP = NT16 * 16;
   size_t sh = (size_t)2 * NP * Geom<T>::ROWB;
@@ -556,6 +827,26 @@ int check(const uvc_attn_args* p, bool bwd) {
   return UVC_OK;
 }
 
+// the one-pass backward: bf16, 13 key / query tiles whose images fit 200 rows (DeiT's N = 197 / 198, T2T-ViT's 197)
+bool one_pass_supported(const uvc_attn_args* p) { return p->dtype == UVC_BF16 && p->N > 192 && p->N <= 200; }
+int launch_one_pass(const AttnArgs& a, int grid_arg, hipStream_t st) {
+  typedef one::Lay<13, 200> L;
+  static std::atomic<int> ncu_cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return uvc_set_error_msg(UVC_ERR_LAUNCH, "attention backward: hipGetDevice");
+  int ncu = dev < 64 ? ncu_cache[dev].load(std::memory_order_relaxed) : 0;
+  if (ncu == 0) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    if (dev < 64) ncu_cache[dev].store(ncu, std::memory_order_relaxed);
+  }
+  const int nbh = a.B * a.H;
+  const int grid = grid_arg > 0 ? (grid_arg < nbh ? grid_arg : nbh) : (nbh < ncu ? nbh : ncu);
+  UVC_MAX_LDS(L::TOTAL, one::k_attn_bwd_one<13, 200>);
+  one::k_attn_bwd_one<13, 200><<<grid, (13 + one::NH) * 64, L::TOTAL, st>>>(a);
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
+
 AttnArgs conv(const uvc_attn_args* p) {
   AttnArgs a;
   a.qkv = p->qkv; a.o = p->o; a.lse = p->lse; a.dout = p->dout; a.dqkv = p->dqkv; a.delta = p->delta;
@@ -576,9 +867,17 @@ extern "C" int uvc_attention_bwd(const uvc_attn_args* p, void* stream) {
   const AttnArgs a = conv(p);
   hipStream_t st = (hipStream_t)stream;
   if (p->dtype == UVC_F32) {
+    if (p->variant == 2) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "attention backward: the one-pass kernel is bf16 only");
     if (int e = dispatch<float>(a, 1, st)) return e;
     return dispatch<float>(a, 2, st);
   }
+  if (p->variant < 0 || p->variant > 2) return uvc_set_error_msg(UVC_ERR_ARG, "attention backward: bad variant");
+  if (p->variant == 2 && !one_pass_supported(p)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "attention backward: the one-pass kernel takes 193 <= N <= 200");
+#ifdef UVC_ATTN_BWD_PAIR_DEFAULT                       // A/B builds (tools/exp_ab.sh): variant 0 = the pair
+  if (p->variant == 2) return launch_one_pass(a, p->grid, st);
+#else
+  if (p->variant != 1 && one_pass_supported(p)) return launch_one_pass(a, p->grid, st);
+#endif
   if (int e = dispatch<bf16_t>(a, 1, st)) return e;
   return dispatch<bf16_t>(a, 2, st);
 }

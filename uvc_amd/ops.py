@@ -104,8 +104,9 @@ def attention_fwd(qkv, o, lse, B, N, H, dtype, head_keep=None):
     L.check(L.lib().uvc_attention_fwd(C.byref(a), L.cur_stream()), "uvc_attention_fwd")
 
 
-def attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype, head_keep=None):
+def attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype, head_keep=None, variant=0, grid=0):
     a = _attn_args(qkv, o, lse, B, N, H, dtype, dout, dqkv, delta)
+    a.variant, a.grid = int(variant), int(grid)
     if head_keep is not None:
         _chk(head_keep)
         a.head_keep = L.ptr(head_keep)

@@ -606,11 +606,12 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
       char* img = smem + buf * L::BUF;
       u32x4 ov[NPH];
       float ls[NLS];
-      // piece i of this helper is p = j + NH i: rows 8 p + rr.  Only the LAST one can run past the image (p > NP - 1: issued again as
-      // piece NP - 1, no branch around a DMA) or past the sequence (row > N - 1: that row's lanes fetch row N - 1 -- finite, never used);
+      // piece i of this helper is p = j + NH i: rows 8 p + rr.  Only the LAST one can run past the image (p > NP - 1: this helper's
+      // FIRST piece is fetched again instead -- no branch around a DMA, and no helper ever writes a piece another one reads results
+      // from) or past the sequence (row > N - 1: that row's lanes fetch row N - 1 -- finite, never used);
       // the others are one 32-bit lane offset against a wave-uniform base that advances by NH * 8 rows (SGPR arithmetic).
       const unsigned lq = (unsigned)((8 * j + rr) * ldq * 2 + gc * 16), lo = (unsigned)((8 * j + rr) * ldo * 2 + gc * 16);
-      const int pl = min(j + NH * (NPH - 1), NP - 1), rl = min(8 * pl + rr, a.N - 1);
+      const int pl = j + NH * (NPH - 1) < NP ? j + NH * (NPH - 1) : j, rl = min(8 * pl + rr, a.N - 1);
       const unsigned lql = (unsigned)(rl * ldq * 2 + gc * 16), lol = (unsigned)(rl * ldo * 2 + gc * 16);
 #pragma unroll
       for (int i = 0; i < NPH; ++i) {
@@ -639,7 +640,7 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
       float* sDel = sLse + NT * 16;
 #pragma unroll
       for (int i = 0; i < NPH; ++i) {
-        const int p = min(j + NH * i, NP - 1), row = 8 * p + rr;
+        const int p = (i == NPH - 1) ? pl : j + NH * i, row = 8 * p + rr;
         const bf16x8 x = *reinterpret_cast<const bf16x8*>(img + L::IMG + p * 1024 + lane * 16);
         float d = frag_dot<T>(x, __builtin_bit_cast(bf16x8, ov[i]));
         d = dpp_add<0xB1>(d); d = dpp_add<0x4E>(d); d = dpp_add<0x141>(d);      // the 8 lanes of a row
@@ -655,14 +656,40 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
       }
     };
     auto dead = [&](int bh) { return a.head_keep && a.head_keep[bh % a.H] == 0; };
-    int bh = blockIdx.x, it = 0;
+    // dq, dk, dv of a finished head lie in ITS image buffer (slots of Q, dO, K; same swizzle), left there by the compute waves between the
+    // head's two barriers: this helper's pieces leave as 1-KB instructions of 16 bytes per lane, 8 whole rows each -- the 8-byte-per-lane
+    // stores from the accumulator layout (16 rows x 32 bytes per instruction) cost the first form of this kernel 57 of its 117 us.
+    auto store_out = [&](int bh, int buf) {
+      const int b = bh / a.H, h = bh % a.H;
+      char* dqb = reinterpret_cast<char*>(a.dqkv) + ((size_t)b * a.N * ldq + h * HD) * 2;
+      const char* stg = smem + buf * L::BUF;
+      const bool zero = dead(bh);
+      const unsigned lq = (unsigned)((8 * j + rr) * ldq * 2 + gc * 16);
+#pragma unroll
+      for (int i = 0; i < NPH; ++i) {
+        const int p = j + NH * i;
+        if (p < NP && 8 * p + rr < a.N) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            u32x4 x = {0u, 0u, 0u, 0u};
+            if (!zero) x = *reinterpret_cast<const u32x4*>(stg + m * L::IMG + p * 1024 + lane * 16);
+            *reinterpret_cast<u32x4*>(dqb + (size_t)m * a.H * HD * 2 + (size_t)i * NH * 8 * ldq * 2 + lq) = x;
+          }
+        }
+      }
+    };
+    int bh = blockIdx.x, it = 0, prev = -1;
     if (!dead(bh) && UVC_ATTN_PROBE != 3) fill(bh, 0);
     __syncthreads();
     for (; bh < nbh; bh += gridDim.x, ++it) {
       const int nxt = bh + (int)gridDim.x;
+      if (prev >= 0 && UVC_ATTN_PROBE != 4) store_out(prev, (it + 1) & 1);      // head it - 1 ran on buffer (it - 1) & 1, which the next fill reuses
       if (nxt < nbh && !dead(nxt) && UVC_ATTN_PROBE != 3) fill(nxt, (it + 1) & 1);
-      __syncthreads();
+      __syncthreads();                                          // A: the steps of head it are done
+      __syncthreads();                                          // B: its results are staged
+      prev = bh;
     }
+    if (UVC_ATTN_PROBE != 4) store_out(prev, (it + 1) & 1);
     return;
   }
 
@@ -675,7 +702,7 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
   const int offT = rT * ROW + ((swz(rT) | ((li & 3) >> 1)) << 4) + (li & 1) * 8;   // transposing read, columns 0 .. 15 (dt: ^ (dt << 5))
   const int offXw = li * 32 + g * 8, offXr = rT * 32 + (li & 3) * 8;
   char* sX = smem + L::OFF_X;
-  const unsigned voff = (unsigned)(key * ldq * 2 + g * 16);     // this lane's V fragment / result rows: one 32-bit offset against a wave-uniform base
+  const unsigned voff = (unsigned)(key * ldq * 2 + g * 16);     // this lane's V fragment rows: one 32-bit offset against a wave-uniform base
   auto load_v = [&](int bh, u32x4 (&v)[2]) {
     const char* vb = reinterpret_cast<const char*>(a.qkv) + ((size_t)(bh / a.H) * a.N * ldq + (bh % a.H) * HD + 2 * a.H * HD) * 2;
     const u32x4 z = {0u, 0u, 0u, 0u};
@@ -689,21 +716,9 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
   for (; bh < nbh; bh += gridDim.x, ++it) {
     const int b = bh / a.H, h = bh % a.H;
     const int nxt = bh + (int)gridDim.x;
-    char* dqb = reinterpret_cast<char*>(a.dqkv) + ((size_t)b * a.N * ldq + h * HD) * 2;
-    char* dkb = dqb + a.H * HD * 2;
-    char* dvb = dkb + a.H * HD * 2;
-    const unsigned soff = (unsigned)(key * ldq * 2 + g * 8);
-    if (a.head_keep && a.head_keep[h] == 0) {                   // pruned head (uvc_attn_args.head_keep): dq = dk = dv = 0 exactly
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      if (key < a.N) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          Store4<T>::st(reinterpret_cast<T*>(dqb + soff + d * 32), z);
-          Store4<T>::st(reinterpret_cast<T*>(dkb + soff + d * 32), z);
-          Store4<T>::st(reinterpret_cast<T*>(dvb + soff + d * 32), z);
-        }
-      }
+    if (a.head_keep && a.head_keep[h] == 0) {                   // pruned head (uvc_attn_args.head_keep): the helpers write its zeros
       if (nxt < nbh) load_v(nxt, vnext);
+      __syncthreads();
       __syncthreads();
       continue;
     }
@@ -765,15 +780,18 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
     if (nxt < nbh) load_v(nxt, vnext);
 #pragma unroll 1
     for (int s = SPLIT; s < (UVC_ATTN_PROBE == 1 ? 0 : NT); ++s) step(s);
-    if (key < a.N && UVC_ATTN_PROBE != 4) {
+    __syncthreads();                                            // A: every wave is done with this head's images ...
+    if (key < a.N) {                                            // ... which now take the results (slot of Q: dq, of dO: dk, of K: dv), for the helpers
+      char* stg = smem + (it & 1) * L::BUF + key * ROW + (g & 1) * 8;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        Store4<T>::st(reinterpret_cast<T*>(dkb + soff + d * 32), dk[d]);
-        Store4<T>::st(reinterpret_cast<T*>(dvb + soff + d * 32), dv[d]);
-        Store4<T>::st(reinterpret_cast<T*>(dqb + soff + d * 32), dq[d]);      // (query tile w: the same row index)
+        const int co = ((d * 2 + (g >> 1)) ^ swz(li)) << 4;
+        *reinterpret_cast<s16x4v*>(stg + co) = pack4(dq[d]);    // (query tile w: the same row index)
+        *reinterpret_cast<s16x4v*>(stg + L::IMG + co) = pack4(dk[d]);
+        *reinterpret_cast<s16x4v*>(stg + 2 * L::IMG + co) = pack4(dv[d]);
       }
     }
-    __syncthreads();                                            // every wave is done with this head's images; the next head's have landed
+    __syncthreads();                                            // B: staged; the next head's images have landed
   }
 }
 }  // namespace one

@@ -12,7 +12,6 @@
 //   dQ  kernel: per query tile   S^T, dP^T = V dO^T, dS^T -> dQ^T = K^T dS^T     (K, V in LDS)
 //   dKV kernel: per key tile     S = Q K^T, dP = dO V^T, dS -> dV^T = dO^T P, dK^T = Q^T dS  (Q, dO in LDS)
 #include "common.h"
-#include <type_traits>
 #include "../../include/uvc_kernels.h"
 
 namespace {
@@ -535,21 +534,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_dkv(AttnArgs a) {
 namespace one {
 // timing probes (tools/attn_probes.sh builds the variants; wrong numbers on purpose; the library is built with 0):
 //   1 = no steps (images in, results out)   2 = steps without the counter waits   3 = no images (the helpers fetch nothing)   4 = no result stores
-//   5 = cycle stamps of workgroup 0's compute waves into the delta buffer (tools/attn_stamps.py reads them): [head][wave][slot 0..15][8] words,
-//       slots 0 .. NT-1 the steps (start, S/dP issued, exponentials done, tile handed on, end), slot 15 the head (start, steps done, barrier A, staged, barrier B)
 #ifndef UVC_ATTN_PROBE
 #define UVC_ATTN_PROBE 0
-#endif
-#if UVC_ATTN_PROBE == 5
-#define ATTN_STAMP(slot, k)                                                                                                            \
-  do {                                                                                                                                 \
-    if (blockIdx.x == 0 && it < 8) {                                                                                                   \
-      const unsigned tm__ = (unsigned)__builtin_amdgcn_s_memtime();                                                                    \
-      if (lane == 0) reinterpret_cast<unsigned*>(a.delta)[((it * 16 + w) * 16 + (slot)) * 8 + (k)] = tm__;                              \
-    }                                                                                                                                  \
-  } while (0)
-#else
-#define ATTN_STAMP(slot, k) do {} while (0)
 #endif
 constexpr int ROW = 128;
 __device__ __forceinline__ int swz(int r) { return ((r >> 1) & 3) << 1; }
@@ -560,25 +546,22 @@ __device__ __forceinline__ s16x4v pack4(const f32x4& v) {
   u32x2 r; r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]);
   return __builtin_bit_cast(s16x4v, r);
 }
-// The hand-over of a dS tile between two waves: produced / consumed counters in LDS next to the tiles.  Everything that touches a tile or a
-// counter is a DS instruction written out by hand (asm volatile: ordered among themselves, and WITHOUT a memory clobber -- the compiler
-// may move its reads of the images, which nothing writes during the steps, across them): through a generic pointer hipcc emits FLAT
-// loads / stores (vmcnt, and no ordering against the wave's DS operations).  DS operations of one wave execute in order, which makes
-// "tile write, then counter write" and "counter read, then tile read" a hand-over -- and lets the reader ask for the counter and the
-// tile TOGETHER: the tile is valid if the counter it came behind says so (it practically always does: the tile was written a step ago);
-// otherwise both are read again.  (An asm DS read the compiler does not count only makes its own s_waitcnt lgkmcnt(n) wait for more,
-// never less: the counter retires in order.)
-__device__ __forceinline__ void x_read(int& f, s16x4v& t, unsigned faddr, unsigned taddr) {
-  asm volatile("ds_read_b32 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(f), "=&v"(t) : "v"(faddr), "v"(taddr));
+// Produced / consumed counters in LDS, accessed by DS instructions written out by hand: through a generic pointer hipcc emits FLAT loads /
+// stores (vmcnt, and no ordering against the wave's DS operations); DS operations of one wave execute in order, which is what makes
+// "tile write, then counter write" / "counter read, then tile read" a hand-over.  (An asm DS operation the compiler does not count only
+// makes its own s_waitcnt lgkmcnt(n) wait for more, never less: the counter retires in order.)
+__device__ __forceinline__ int lds_poll(unsigned addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
 }
-__device__ __forceinline__ void x_wait(int& f, s16x4v& t) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f), "+v"(t)); }
-__device__ __forceinline__ void x_poll(int& f, unsigned faddr) { asm volatile("ds_read_b32 %0, %1" : "=&v"(f) : "v"(faddr)); }
-__device__ __forceinline__ void x_wait1(int& f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f)); }
-__device__ __forceinline__ void x_write(unsigned taddr, const s16x4v& v, unsigned faddr, int fv) {
-  asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(taddr), "v"(v), "v"(faddr), "v"(fv));
+// (bounded: a protocol error must show as wrong numbers in a test, not as a hung GPU -- 2^18 polls are ~20 ms, a hand-over takes < 1 us)
+__device__ __forceinline__ void spin_ge(unsigned addr, int v) {
+  if (UVC_ATTN_PROBE == 2) return;
+  for (int n = 0; lds_poll(addr) < v && n < (1 << 18); ++n) __builtin_amdgcn_s_sleep(1);
 }
-__device__ __forceinline__ void x_post(unsigned faddr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(faddr), "v"(v)); }
-constexpr int SPIN_MAX = 1 << 18;     // bounded spins: a protocol error must show as wrong numbers in a test, not as a hung GPU (2^18 polls ~ 20 ms)
+__device__ __forceinline__ void post(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+constexpr int SPIN_MAX = 1 << 18;
 template <int NT, int R> struct Lay {
   static constexpr int IMG = R * ROW, BUF = 3 * IMG;
   static constexpr int OFF_X = 2 * BUF;                         // exchange tiles [NT][512]
@@ -588,9 +571,16 @@ template <int NT, int R> struct Lay {
   static_assert(TOTAL <= 163840 && TOTAL % 16 == 0 && R % 8 == 0 && R <= NT * 16 && R + 8 >= NT * 16, "layout");
 };
 constexpr int NH = 3;                                           // helper waves
+// Heads are handed out DYNAMICALLY: workgroup b starts on head b and draws every further head from a device counter, one head ahead of its
+// steps (the images of the next head travel under the steps of the current one).  With a static stride a workgroup that reaches its CU late
+// -- the weight-gradient stream's one-workgroup-per-CU GEMMs run beside this kernel -- still owed all its heads at the end: the Tiny step
+// was 5 % SLOWER with this kernel than with the dq + dk/dv pair although the kernel alone is 20 us faster (profiles/r5e).  A launch owns one
+// of 64 counter pairs (the host rotates them; the last workgroup to leave resets the pair), so launches on different streams do not share one.
+struct Ticket { unsigned next, done; };
+__device__ Ticket g_ticket[64];
 
 template <int NT, int R>
-__global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
+__global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a, int slot) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   typedef Lay<NT, R> L;
@@ -605,6 +595,18 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
   }
   __syncthreads();
   const unsigned fP = (unsigned)(size_t)(LDS_PTR(char))smem + L::OFF_FL, fC = fP + 64;      // LDS byte addresses of produced[16], consumed[16]
+  const unsigned fN = fC + 14 * 4;                                // (two unused counters) the head after this one, + 1: slots [it & 1]
+  // the next head of this workgroup, published by the first helper wave at the START of a head, read by everybody else much later (polled: no
+  // barrier lies between); heads only grow, so a value above the current head is the new one
+  auto next_head = [&](int it, int cur) {
+    int v = 0;
+    for (int n = 0; n < SPIN_MAX; ++n) {
+      v = lds_poll(fN + ((it + 1) & 1) * 4) - 1;
+      if (v > cur) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return v;
+  };
   float* sLD = reinterpret_cast<float*>(smem + L::OFF_LD);
   if ((int)blockIdx.x >= nbh) return;
 
@@ -663,8 +665,8 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
         float d = frag_dot<T>(x, __builtin_bit_cast(bf16x8, ov[i]));
         d = dpp_add<0xB1>(d); d = dpp_add<0x4E>(d); d = dpp_add<0x141>(d);      // the 8 lanes of a row
         if ((lane & 7) == 0) {
-          sDel[row] = row < a.N ? d : 0.f;
-          if (row < a.N && a.delta && UVC_ATTN_PROBE != 5) a.delta[((size_t)b * a.H + h) * a.N + row] = d;
+          sDel[row] = row < a.N ? d * a.scale : 0.f;              // (scaled: ds = p (dp scale - delta scale))
+          if (row < a.N && a.delta) a.delta[((size_t)b * a.H + h) * a.N + row] = d;
         }
       }
 #pragma unroll
@@ -683,7 +685,8 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
       const char* stg = smem + buf * L::BUF;
       const bool zero = dead(bh);
       // the staged rows have their own swizzle (chunk c of row r at c ^ (r & 7), its 8-byte halves exchanged in rows 8 .. 15 of a tile): the 16
-      // rows x 8 bytes of one ds_write_b64 of the accumulator layout then cover all the banks once (under the images' swizzle: four times)
+      // rows x 8 bytes of one ds_write_b64 of the accumulator layout then cover all the banks once (under the images' swizzle four times:
+      // the staging alone was 3 - 4.7 k of a head's 36 k cycles, profiles/r5c)
       const unsigned lq = (unsigned)((8 * j + rr) * ldq * 2 + ((lane & 7) ^ rr) * 16);
 #pragma unroll
       for (int i = 0; i < NPH; ++i) {
@@ -702,22 +705,31 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
     int bh = blockIdx.x, it = 0, prev = -1;
     if (!dead(bh) && UVC_ATTN_PROBE != 3) fill(bh, 0);
     __syncthreads();
-    for (; bh < nbh; bh += gridDim.x, ++it) {
-      const int nxt = bh + (int)gridDim.x;
+    for (; bh < nbh; ++it) {
+      int nxt;
+      if (j == 0) {                                             // draw the next head and publish it
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(&g_ticket[slot].next, 1u);
+        nxt = (int)gridDim.x + __builtin_amdgcn_readfirstlane((int)t);
+        post(fN + ((it + 1) & 1) * 4, nxt + 1);
+      } else {
+        nxt = next_head(it, bh);
+      }
       if (prev >= 0 && UVC_ATTN_PROBE != 4) store_out(prev, (it + 1) & 1);      // head it - 1 ran on buffer (it - 1) & 1, which the next fill reuses
       if (nxt < nbh && !dead(nxt) && UVC_ATTN_PROBE != 3) fill(nxt, (it + 1) & 1);
       __syncthreads();                                          // A: the steps of head it are done
       __syncthreads();                                          // B: its results are staged
       prev = bh;
+      bh = nxt;
     }
     if (UVC_ATTN_PROBE != 4) store_out(prev, (it + 1) & 1);
+    if (j == 0 && lane == 0) {                                  // the last workgroup to leave (every draw of the launch has been made) resets the pair
+      if (atomicAdd(&g_ticket[slot].done, 1u) == gridDim.x - 1) { g_ticket[slot].next = 0; g_ticket[slot].done = 0; }
+    }
     return;
   }
 
   // -------------------------------------------------------------------------------- compute waves
-  if (UVC_ATTN_PROBE == 7 || UVC_ATTN_PROBE == 8) {              // probe: the younger waves lose the issue arbitration -- raise them
-    if (w >= 8) __builtin_amdgcn_s_setprio(2); else if (w >= 4) __builtin_amdgcn_s_setprio(1);
-  }
   const int key = w * 16 + li;
   const float c2 = a.scale * 1.44269504088896340736f;
   const bool last_keys = w * 16 + 16 > a.N;                     // (wave-uniform) this wave's key tile holds padded keys
@@ -737,13 +749,14 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
   int gstep = 0, it = 0, bh = blockIdx.x;
   load_v(bh, vnext);
   __syncthreads();
-  for (; bh < nbh; bh += gridDim.x, ++it) {
+  for (; bh < nbh; ++it) {
     const int b = bh / a.H, h = bh % a.H;
-    const int nxt = bh + (int)gridDim.x;
     if (a.head_keep && a.head_keep[h] == 0) {                   // pruned head (uvc_attn_args.head_keep): the helpers write its zeros
+      const int nxt = next_head(it, bh);
       if (nxt < nbh) load_v(nxt, vnext);
       __syncthreads();
       __syncthreads();
+      bh = nxt;
       continue;
     }
     const char* sQ = smem + (it & 1) * L::BUF;
@@ -751,207 +764,66 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
     const char* sK = sDO + L::IMG;
     const float* sLse = sLD + (it & 1) * 2 * NT * 16;
     const float* sDel = sLse + NT * 16;
-    typename MM::Frag vf[2];                                    // (this wave's K row fragments are read again every step: 8 registers)
+    typename MM::Frag kf[2], vf[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) vf[ks] = __builtin_bit_cast(typename MM::Frag, vnext[ks]);
-    const char* kw = sK + w * 16 * ROW;
+    for (int ks = 0; ks < 2; ++ks) {
+      vf[ks] = __builtin_bit_cast(typename MM::Frag, vnext[ks]);
+      kf[ks] = *reinterpret_cast<const typename MM::Frag*>(sK + w * 16 * ROW + (offA ^ (ks * 64)));
+    }
     f32x4 dk[4], dv[4], dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; dq[dt] = dk[dt]; }
-    // ---- the steps.  Step s pairs this wave's keys with query tile t(s) = (w + s) % NT and hands the dS tile on to that tile's owner; the
-    // tile wave p(s) = (w - s) % NT leaves for query tile w in step s is taken in at the TOP of step s + 1, in one batch of LDS reads with
-    // that step's Q / dO row fragments, lse, delta (counter and tile asked for together, see x_read): a step is two exposed LDS round
-    // trips (this batch; the consumed-counter poll before the tile is overwritten), where the first form of this kernel had seven.
-    // Steps run in pairs (A, B) so that everything past S / dP is a full-rate 16x16x32 MFMA: dV / dK take the 32 queries of t(A), t(B)
-    // together (P, dS of A wait in 4 registers), dQ the 32 keys of p(A), p(B) (A's tile waits in 2).  An odd NT ends on a single
-    // 16x16x16 step.
-    const unsigned ldsb = (unsigned)(size_t)(LDS_PTR(char))smem;
-    const unsigned xw_addr = ldsb + L::OFF_X + w * 512 + offXw;     // this wave's tile (write side), its produced counter
-    const unsigned xr_base = ldsb + L::OFF_X + offXr;               // a tile, read transposed: + 512 p
-    s16x4v pfA, dsfA, dstA;                                       // carried from step A of a pair to step B / to the consume after B
-    int tA = 0, pA = 0;
-    int fcons;                                                    // consumed counter of this wave's tile, polled ahead of its use
-    auto tile_of = [&](int sidx) { int t = w + sidx; if (t >= NT) t -= NT; return t; };
-    auto prod_of = [&](int sidx) { int p = w - sidx; if (p < 0) p += NT; return p; };
-    auto retake = [&](int pw, int need, int& f, s16x4v& dst) {     // (rare) the tile was not there yet
-      for (int n = 0; __builtin_amdgcn_readfirstlane(f) < need && n < SPIN_MAX; ++n) {
-        if (UVC_ATTN_PROBE != 6 && UVC_ATTN_PROBE != 8) __builtin_amdgcn_s_sleep(1);
-        x_read(f, dst, fP + pw * 4, xr_base + pw * 512);
-        x_wait(f, dst);
-      }
-    };
-    // MODE 0: first step of a pair; 1: second; 2: single (the last step of an odd NT).  CONS: what the tile taken in at the top belongs to:
-    // 0 = nothing to take (s = 0), 1 = first tile of a pair (keep), 2 = second tile of a pair (dQ += ... over 32 keys).
-    auto step = [&](auto mode_tag, auto cons_tag, int s) {
-      constexpr int MODE = decltype(mode_tag)::value, CONS = decltype(cons_tag)::value;
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
-      const int t = tile_of(s);
+    auto step = [&](int s) {
+      int t = w + s; if (t >= NT) t -= NT;                      // the query tile this wave's keys meet now
       const char* qt = sQ + t * 16 * ROW;
-      const char* dot = sDO + t * 16 * ROW;
-      ATTN_STAMP(s, 0);
-      // ---- batch 1: the hand-over of step s - 1 (counter and tile together) and this step's row operands.  The tile is acknowledged as
-      // early as this: its owner wants to overwrite it two phases from now, and the step is paced by the slowest wave otherwise
-      int f = 0; s16x4v dstB;
-      const int pB = prod_of(s - 1);
-      if (CONS == 1) x_read(f, dstA, fP + pB * 4, xr_base + pB * 512);
-      if (CONS == 2) x_read(f, dstB, fP + pB * 4, xr_base + pB * 512);
-      typename MM::Frag qf[2], dof[2], kf[2];
+      const char* dt_ = sDO + t * 16 * ROW;
+      f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        qf[ks] = *reinterpret_cast<const typename MM::Frag*>(qt + (offA ^ (ks * 64)));
-        kf[ks] = *reinterpret_cast<const typename MM::Frag*>(kw + (offA ^ (ks * 64)));
-        dof[ks] = *reinterpret_cast<const typename MM::Frag*>(dot + (offA ^ (ks * 64)));
+        c = MM::mma(*reinterpret_cast<const typename MM::Frag*>(qt + (offA ^ (ks * 64))), kf[ks], c);
+        dp = MM::mma(*reinterpret_cast<const typename MM::Frag*>(dt_ + (offA ^ (ks * 64))), vf[ks], dp);
       }
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + t * 16 + g * 4);
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + t * 16 + g * 4);
-      __builtin_amdgcn_sched_barrier(0);
-      if (CONS != 0) {
-        if (CONS == 1) x_wait(f, dstA); else x_wait(f, dstB);
-        if (__builtin_amdgcn_readfirstlane(f) < gstep && UVC_ATTN_PROBE != 2) { if (CONS == 1) retake(pB, gstep, f, dstA); else retake(pB, gstep, f, dstB); }
-        x_post(fC + pB * 4, gstep);                              // read: its owner may overwrite it
-      }
-      ATTN_STAMP(s, 5);
-      f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) { c = MM::mma(qf[ks], kf[ks], c); dp = MM::mma(dof[ks], vf[ks], dp); }
-      __builtin_amdgcn_sched_barrier(0);
-      ATTN_STAMP(s, 1);
-      // ---- batch 2, under the exponentials: the K^T operands of the dQ of the pair of tiles just completed, and the consumed counter of this
-      // wave's own tile
-      s16x4v ka[4], kb[4];
-      if (CONS == 2) {
-        const char* kpa = sK + pA * 16 * ROW;
-        const char* kpb = sK + pB * 16 * ROW;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { ka[d] = trd(kpa + (offT ^ (d << 5))); kb[d] = trd(kpb + (offT ^ (d << 5))); }
-      }
-      x_poll(fcons, fC + w * 4);
-      __builtin_amdgcn_sched_barrier(0);
       f32x4 pp, ds;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float pr = __builtin_amdgcn_exp2f(c[e] * c2 - l4[e]);
         pp[e] = pr;
-        ds[e] = pr * ((dp[e] - d4[e]) * a.scale);
+        ds[e] = pr * __builtin_fmaf(dp[e], a.scale, -d4[e]);      // d4 = delta * scale
       }
-      if (last_keys && key >= a.N) { pp = f32x4{0.f, 0.f, 0.f, 0.f}; ds = pp; }      // padded keys: their K rows in LDS are not zeros
+      if (last_keys) {                                           // padded keys: their K rows in LDS are not zeros (a branch: one wave of NT takes it)
+        asm volatile("" ::: "memory");
+        if (key >= a.N) { pp = f32x4{0.f, 0.f, 0.f, 0.f}; ds = pp; }
+      }
       const s16x4v pf = pack4(pp), dsf = pack4(ds);
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- this wave's own tile has been read (else: wait); then the new one goes out
-      x_wait1(fcons);
-      ATTN_STAMP(s, 2);
-      for (int n = 0; __builtin_amdgcn_readfirstlane(fcons) < gstep && n < SPIN_MAX && UVC_ATTN_PROBE != 2; ++n) {
-        if (UVC_ATTN_PROBE != 6 && UVC_ATTN_PROBE != 8) __builtin_amdgcn_s_sleep(1);
-        x_poll(fcons, fC + w * 4);
-        x_wait1(fcons);
+      spin_ge(fC + w * 4, gstep);                                   // the tile of the step before has been read
+      *reinterpret_cast<s16x4v*>(sX + w * 512 + offXw) = dsf;   // [key][query]
+      post(fP + w * 4, gstep + 1);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        dv[d] = mma16(trd(dt_ + (offT ^ (d << 5))), pf, dv[d]);
+        dk[d] = mma16(trd(qt + (offT ^ (d << 5))), dsf, dk[d]);
       }
-      ATTN_STAMP(s, 6);
-      x_write(xw_addr, dsf, fP + w * 4, gstep + 1);                // [key][query], then the produced counter
+      int pw = w - s; if (pw < 0) pw += NT;                     // the wave whose keys met query tile w in this step
+      spin_ge(fP + pw * 4, gstep + 1);
+      const s16x4v dst = trd(sX + pw * 512 + offXr);
+      const char* kp = sK + pw * 16 * ROW;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dq[d] = mma16(trd(kp + (offT ^ (d << 5))), dst, dq[d]);
+      post(fC + pw * 4, gstep + 1);
       ++gstep;
-      __builtin_amdgcn_sched_barrier(0);
-      ATTN_STAMP(s, 3);
-      // ---- batch 3 and the products: dV's transposed operands are asked for, dQ (of the pair of tiles just completed) runs, dK's operands
-      // are asked for, dV, dK run
-      s16x4v da[4], qa[4], dA[4], qA[4];
-      if (MODE != 0) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) da[d] = trd(dot + (offT ^ (d << 5)));
-      }
-      if (MODE == 1) {
-        const char* dotA = sDO + tA * 16 * ROW;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dA[d] = trd(dotA + (offT ^ (d << 5)));
-      }
-      if (CONS == 2) {
-        const bf16x8 bd = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dstA, dstB, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dq[d] = MM::mma(__builtin_bit_cast(bf16x8, __builtin_shufflevector(ka[d], kb[d], 0, 1, 2, 3, 4, 5, 6, 7)), bd, dq[d]);
-      }
-      if (CONS == 1) pA = pB;
-      __builtin_amdgcn_sched_barrier(0);
-      if (MODE != 0) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) qa[d] = trd(qt + (offT ^ (d << 5)));
-      }
-      if (MODE == 1) {
-        const char* qtA = sQ + tA * 16 * ROW;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) qA[d] = trd(qtA + (offT ^ (d << 5)));
-      }
-      if (MODE == 0) { pfA = pf; dsfA = dsf; tA = t; }
-      if (MODE == 1) {
-        const bf16x8 bp = __builtin_bit_cast(bf16x8, __builtin_shufflevector(pfA, pf, 0, 1, 2, 3, 4, 5, 6, 7));
-        const bf16x8 bs = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dsfA, dsf, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dv[d] = MM::mma(__builtin_bit_cast(bf16x8, __builtin_shufflevector(dA[d], da[d], 0, 1, 2, 3, 4, 5, 6, 7)), bp, dv[d]);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dk[d] = MM::mma(__builtin_bit_cast(bf16x8, __builtin_shufflevector(qA[d], qa[d], 0, 1, 2, 3, 4, 5, 6, 7)), bs, dk[d]);
-      }
-      if (MODE == 2) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dv[d] = mma16(da[d], pf, dv[d]);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dk[d] = mma16(qa[d], dsf, dk[d]);
-      }
-      ATTN_STAMP(s, 4);
     };
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2;
-    constexpr int NPAIR = NT / 2;
-    ATTN_STAMP(15, 0);
-    if (UVC_ATTN_PROBE != 1) {
-      if (NPAIR > 0) {
-        step(I0(), I0(), 0);
-        step(I1(), I1(), 1);
-      }
+    constexpr int SPLIT = NT >= 3 ? NT - 2 : 0;                 // the next head's V rows are requested under the last two steps
 #pragma unroll 1
-      for (int i = 1; i < NPAIR - 1; ++i) {
-        step(I0(), I2(), 2 * i);
-        step(I1(), I1(), 2 * i + 1);
-      }
-      if (NPAIR > 1) {
-        step(I0(), I2(), 2 * (NPAIR - 1));
-        step(I1(), I1(), 2 * (NPAIR - 1) + 1);
-      }
-      if (NT & 1) {
-        if (NPAIR > 0) step(I2(), I2(), NT - 1); else step(I2(), I0(), 0);
-      }
-      // ---- the tile of the last step
-      {
-        const int pB = prod_of(NT - 1);
-        int f; s16x4v dstB;
-        x_read(f, dstB, fP + pB * 4, xr_base + pB * 512);
-        s16x4v ka[4], kb[4];
-        const char* kpb = sK + pB * 16 * ROW;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) kb[d] = trd(kpb + (offT ^ (d << 5)));
-        if (!(NT & 1)) {
-          const char* kpa = sK + pA * 16 * ROW;
-#pragma unroll
-          for (int d = 0; d < 4; ++d) ka[d] = trd(kpa + (offT ^ (d << 5)));
-        }
-        x_wait(f, dstB);
-        if (__builtin_amdgcn_readfirstlane(f) < gstep) retake(pB, gstep, f, dstB);
-        x_post(fC + pB * 4, gstep);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          if (NT & 1) {
-            dq[d] = mma16(kb[d], dstB, dq[d]);
-          } else {
-            typedef short s16x8 __attribute__((ext_vector_type(8)));
-            dq[d] = MM::mma(__builtin_bit_cast(bf16x8, __builtin_shufflevector(ka[d], kb[d], 0, 1, 2, 3, 4, 5, 6, 7)),
-                            __builtin_bit_cast(bf16x8, __builtin_shufflevector(dstA, dstB, 0, 1, 2, 3, 4, 5, 6, 7)), dq[d]);
-          }
-        }
-      }
-    }
-    if (nxt < nbh) load_v(nxt, vnext);                            // the next head's V rows travel under the two barriers and the staging (8 registers the steps do not have)
-    ATTN_STAMP(15, 1);
+    for (int s = 0; s < (UVC_ATTN_PROBE == 1 ? 0 : SPLIT); ++s) step(s);
+    const int nxt = next_head(it, bh);                          // (published at the start of this head: no wait)
+    if (nxt < nbh) load_v(nxt, vnext);
+#pragma unroll 1
+    for (int s = SPLIT; s < (UVC_ATTN_PROBE == 1 ? 0 : NT); ++s) step(s);
     __syncthreads();                                            // A: every wave is done with this head's images ...
-    ATTN_STAMP(15, 2);
     if (key < a.N) {                                            // ... which now take the results (slot of Q: dq, of dO: dk, of K: dv), for the helpers
-      char* stg = smem + (it & 1) * L::BUF + key * ROW + (((g & 1) ^ (li >> 3)) << 3);      // (the staging swizzle: see store_out)
+      char* stg = smem + (it & 1) * L::BUF + key * ROW + (((g & 1) ^ (li >> 3)) << 3);
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int co = ((d * 2 + (g >> 1)) ^ (li & 7)) << 4;
@@ -960,9 +832,8 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a) {
         *reinterpret_cast<s16x4v*>(stg + 2 * L::IMG + co) = pack4(dv[d]);
       }
     }
-    ATTN_STAMP(15, 3);
     __syncthreads();                                            // B: staged; the next head's images have landed
-    ATTN_STAMP(15, 4);
+    bh = nxt;
   }
 }
 }  // namespace one
@@ -1029,9 +900,17 @@ int launch_one_pass(const AttnArgs& a, int grid_arg, hipStream_t st) {
     if (dev < 64) ncu_cache[dev].store(ncu, std::memory_order_relaxed);
   }
   const int nbh = a.B * a.H;
-  const int grid = grid_arg > 0 ? (grid_arg < nbh ? grid_arg : nbh) : (nbh < ncu ? nbh : ncu);
+  // A workgroup of this kernel takes a whole CU (160 KB of LDS, all 512 registers of every SIMD), and lives as long as the launch: at one
+  // workgroup per CU nothing of the weight-gradient stream runs beside it -- and this latency-bound kernel is the one place of the
+  // backward where an HBM-bound GEMM beside it costs nothing.  Measured in the step (profiles/r5f_gridexp*.txt, same box): DeiT-Tiny
+  // 12.70 ms with 256 workgroups, 12.62 with 232, 11.98 with 224 (the dq + dk/dv pair: 12.20), 12.02 with 200: one free CU in EVERY
+  // shader engine (256 CUs = 32 engines x 8) is what the other stream's dispatch needs -- with one engine full it stalls as if all were.
+  // DeiT-Small (H = 6) is 2 % faster with the whole chip, DeiT-Base indifferent: the narrow model alone leaves the CUs.
+  const int ncu_use = a.H <= 3 && ncu >= 64 ? ncu - ncu / 8 : ncu;
+  const int grid = grid_arg > 0 ? (grid_arg < nbh ? grid_arg : nbh) : (nbh < ncu_use ? nbh : ncu_use);
+  static std::atomic<unsigned> seq{0};
   UVC_MAX_LDS(L::TOTAL, one::k_attn_bwd_one<13, 200>);
-  one::k_attn_bwd_one<13, 200><<<grid, (13 + one::NH) * 64, L::TOTAL, st>>>(a);
+  one::k_attn_bwd_one<13, 200><<<grid, (13 + one::NH) * 64, L::TOTAL, st>>>(a, (int)(seq.fetch_add(1, std::memory_order_relaxed) & 63));
   UVC_CHECK_LAUNCH();
   return UVC_OK;
 }

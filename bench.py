@@ -64,7 +64,13 @@ def parse():
                         "gate logits frozen, lr = warmup_lr), reported for reference (SURVEY 8d)")
     p.add_argument("--compact_mlp", type=int, default=1, help="stage 2: skip pruned MLP hidden units (0 = dense masked computation)")
     p.add_argument("--serialize", type=int, default=0, help="diagnostic bit mask: 1 = weight gradients on the main stream, 2 = teacher forward on the main stream (3 = no overlap at all)")
-    p.add_argument("--cpu_steps", type=int, default=6)
+    p.add_argument("--cpu_steps", type=int, default=10, help="timed CPU-baseline steps at batch 8 after 3 warm-ups; the median is reported (BASELINE.md section 3)")
+    # the reference's own switches (run_uvc_train.sh:4-38, joint_train.py:684-879), so that BASELINE.json's configs 3 / 4 / 5 are benched AS STATED:
+    p.add_argument("--budget", type=float, default=0.5, help="FLOPs budget (config 3: 0.58)")
+    p.add_argument("--enable_deit", type=int, default=0, help="1: the distillation token and the second head (config 4: N = 198)")
+    p.add_argument("--enable_patch_gating", type=int, default=0, help="1: Gumbel top-k patch gating (config 5)")
+    p.add_argument("--patch_ratio", type=float, default=0.9)
+    p.add_argument("--enable_block_gating", type=int, default=1)
     p.add_argument("--full_tail", type=int, default=0, help="1: the last block computes all B*N rows like the reference (default: its token rows only; same outputs)")
     return p.parse_args()
 
@@ -187,7 +193,8 @@ def kernel_table(args):
     # are in the rocprofv3 tables under profiles/
     D, H, L, F = {"deit_tiny_patch16_224": (192, 3, 12, 768), "deit_small_patch16_224": (384, 6, 12, 1536), "deit_base_patch16_224": (768, 12, 12, 3072),
                   "t2t_vit_14": (384, 6, 14, 1152)}[args.model_type]
-    rows = KT.measure(KT.build(args.batch, D=D, H=H, L=L, F=F, tail=not args.full_tail, resid_f32=(args.precision == "bf16_f32resid") or None), iters=20)
+    rows = KT.measure(KT.build(args.batch, D=D, H=H, L=L, N=198 if args.enable_deit else 197, F=F, tail=not args.full_tail,
+                               resid_f32=(args.precision == "bf16_f32resid") or None), iters=20)
     rows.sort(key=lambda r: -r["us_per_step"])
     top = rows[0]
     ridge = PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS          # flop per byte where the two roofs meet (312)
@@ -242,29 +249,33 @@ def cpu_baseline(args):
     OS.U.uvc_update = timed
     points = []
     try:
-        for batch, max_steps, budget_s in ((8, args.cpu_steps, 25.0), (64, 2, 25.0)):
+        for batch, warm, max_steps, budget_s in ((8, 3, max(10, args.cpu_steps), 40.0), (64, 1, 3, 25.0)):
             r = SC.recipe("tiny8_pruned")
             r["batch"], r["steps"] = batch, 1
             r0, S = build_oracle_from_recipe(r)
             x_all, y_all = SC.make_inputs(r0)
             md, e1, e2 = split_draws(SC.recipe("tiny8_pruned"), gold, 0, S.cfg.depth)
             x, y = torch.from_numpy(x_all[0]), torch.from_numpy(y_all[0])
-            OS.stage1_step(S, x, y, list(md), e1, e2)          # warm-up
+            for _ in range(warm):
+                OS.stage1_step(S, x, y, list(md), e1, e2)      # warm-ups (3 at batch 8)
             acc["uvc"] = 0.0
             t0 = time.perf_counter()
-            n = 0
-            while n < max_steps and time.perf_counter() - t0 < budget_s:
+            per = []
+            while len(per) < max_steps and (time.perf_counter() - t0 < budget_s or len(per) < 3):
+                ts = time.perf_counter()
                 OS.stage1_step(S, x, y, list(md), e1, e2)
-                n += 1
-            dt = time.perf_counter() - t0
-            points.append({"batch": batch, "steps": n, "images_per_sec": round(batch * n / dt, 3), "s_per_step": round(dt / n, 3),
+                per.append(time.perf_counter() - ts)
+            n, dt = len(per), sum(per)
+            med = sorted(per)[n // 2]                            # the MEDIAN step is the value (the mean wandered 12.3 -> 10.9 img/s between rounds on identical code)
+            points.append({"batch": batch, "warmup_steps": warm, "steps": n, "images_per_sec": round(batch / med, 3), "s_per_step_median": round(med, 3),
+                           "s_per_step_mean": round(dt / n, 3), "s_per_step_min": round(min(per), 3), "s_per_step_max": round(max(per), 3),
                            "uvc_update_s_per_step": round(acc["uvc"] / n, 3), "model_part_s_per_step": round((dt - acc["uvc"]) / n, 3)})
     finally:
         OS.U.uvc_update = orig
     b8 = points[0]
     return {"value": b8["images_per_sec"], "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"oracle Stage-1 step (student fwd/bwd + teacher fwd + loss + clip + AdamW + uvc_optimizer), DeiT-Tiny, torch CPU fp32 {threads} threads: "
-                      f"batch 8 x {b8['steps']} steps (value), batch 64 x {points[1]['steps']} steps", "points": points}
+                      f"batch 8, 3 warm-ups + {b8['steps']} timed steps, median (value); batch 64, 1 + {points[1]['steps']} steps", "points": points}
 
 
 def main():
@@ -296,7 +307,9 @@ def main():
         tr.begin_epoch(a.warmup_epochs + 1)
     else:
         from uvc_amd.stage1 import Stage1Trainer, default_args
-        a = default_args(model_type=args.model_type, precision=args.precision, train_batch_size=args.batch, local_rank=local)
+        a = default_args(model_type=args.model_type, precision=args.precision, train_batch_size=args.batch, local_rank=local, budget=args.budget,
+                         enable_deit=args.enable_deit, enable_patch_gating=args.enable_patch_gating, patch_ratio=args.patch_ratio,
+                         enable_block_gating=args.enable_block_gating)
         tr = Stage1Trainer(a, device=f"cuda:{local}", distributed=world > 1)
         pruned_state(tr)
         tr.begin_epoch(a.warmup_epochs + 1 if args.phase == "train" else 1)      # UVC-train phase (post warm-up) is the metric, SURVEY.md §8d
@@ -346,7 +359,11 @@ def main():
         imgs = world * args.batch * args.steps / dt
         gf = executed_gflop_per_img(args.model_type, bool(args.full_tail))
         tiny = args.model_type == "deit_tiny_patch16_224"
-        metric = (("images/sec UVC Stage-1 step, DeiT-Tiny budget=0.5" if tiny else f"images/sec UVC Stage-1 step, {args.model_type} budget=0.5 (not the headline model)")
+        headline = tiny and args.budget == 0.5 and not args.enable_deit and not args.enable_patch_gating and args.enable_block_gating
+        opts = (f"budget={args.budget:g}" + (", distillation token (enable_deit)" if args.enable_deit else "")
+                + (f", patch gating (ratio {args.patch_ratio:g})" if args.enable_patch_gating else "")
+                + (", block gating" if args.enable_block_gating else ", no block gating"))
+        metric = (("images/sec UVC Stage-1 step, DeiT-Tiny budget=0.5" if headline else f"images/sec UVC Stage-1 step, {args.model_type} {opts} (not the headline configuration)")
                   if args.phase == "train" else
                   "images/sec UVC Stage-1 WARM-UP-phase step, DeiT-Tiny (for reference, not the headline)") if args.stage == 1 else \
                  "images/sec UVC Stage-2 masked fine-tune step, DeiT-Tiny (SURVEY 8 f-1, not the headline)"
@@ -356,8 +373,10 @@ def main():
                 "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if args.precision.startswith("bf16") else "f32", "data": "synthetic",
-                "config": {"workload": (f"{args.model_type} Stage-1 UVC-train step, budget 0.5, per-GPU batch {args.batch}, "
-                                        f"224x224x3 synthetic, soft distillation alpha 0.1, block gating on") if args.stage == 1 else
+                "config": {"workload": (f"{args.model_type} Stage-1 UVC-train step, budget {args.budget:g}, per-GPU batch {args.batch}, "
+                                        f"224x224x3 synthetic, soft distillation alpha 0.1, block gating {'on' if args.enable_block_gating else 'off'}"
+                                        + (", distillation token (N = 198, two heads)" if args.enable_deit else "")
+                                        + (f", patch gating on (patch_ratio {args.patch_ratio:g})" if args.enable_patch_gating else "")) if args.stage == 1 else
                                        (f"{args.model_type} Stage-2 masked fine-tune step, per-GPU batch {args.batch}, masks at the "
                                         f"budget-0.5 operating point, 2 of 12 blocks hard-skipped, soft distillation alpha 0.1"),
                            "global_batch": world * args.batch, "parallelism": f"dp{world}"},

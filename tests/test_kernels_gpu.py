@@ -954,6 +954,10 @@ def test_keyed_exp_noise_is_a_pure_function_of_its_key():
     y0, y1 = b((12, 2)), b((512, 196))
     assert torch.equal(x0, y0) and torch.equal(x1, y1)
     assert not torch.equal(x1.flatten()[:24].reshape(12, 2), x0)                      # another site: another stream
+    b.begin_step(7)                                                                     # the same step number again REPLAYS the key ...
+    assert torch.equal(b((12, 2)), x0)
+    b.begin_step(7, resume_window=True)                                                 # ... unless the caller says the window is carried over
+    assert torch.equal(b((512, 196)), x1)
     b.begin_step(8)
     z0 = b((12, 2))
     assert not torch.equal(z0, x0)                                                      # another step

@@ -247,3 +247,36 @@ def test_training_backward_skipping_pruned_heads_is_exact(precision):
     assert res[0][2].keys() == res[1][2].keys()
     for n in res[0][2]:
         assert torch.equal(res[0][2][n], res[1][2][n]), n
+
+
+def test_loading_other_masks_rederives_the_pruned_head_table():
+    """the training backward writes dq / dk / dv of a head marked pruned as zeros, so a table derived from the masks at construction must
+    not survive a load_state_dict that brings other masks: model.load_state_dict and Stage2Trainer.load_state_dict derive the pruned-head table and the
+    MLP compaction again.  Here a state with NO pruned head is loaded into a trainer built from masks with pruned heads: the gradients of the step
+    equal those of a trainer built from the loaded state directly (with a stale table the formerly pruned heads' dq / dk / dv would be zeros)."""
+    name = "stage2_tiny8"
+    r, cfg, tr = build(name, "fp32", compact=1)
+    assert tr.head_keep is not None and int((tr.head_keep == 0).sum()) > 0
+    sd = tr.state_dict()
+    for k in sd["model"]:
+        if k.endswith("attn.proj.mask"):
+            sd["model"][k] = torch.ones_like(sd["model"][k])
+    r2, _, fresh = build(name, "fp32", compact=1)
+    fresh.model.load_state_dict(sd["model"])                 # model-level load: derives again, but the trainer's copy is the caller's business ...
+    assert fresh.model._head_keep is None
+    tr.load_state_dict(sd)                                    # ... the trainer-level load refreshes both
+    assert tr.head_keep is None or bool(tr.head_keep.all())
+    assert tr.model._head_keep is None and not tr.model.skip_pruned_head_grads
+    x_all, y_all = SC.make_inputs(r)
+    grads = []
+    for t in (tr, fresh):
+        t.model.skip_pruned_head_grads = t.model._head_keep is not None
+        t.begin_epoch(r["epoch_of_step"][0])
+        t.optimizer.zero_grad()
+        t.step(torch.from_numpy(x_all[0]).cuda(), torch.from_numpy(y_all[0]).cuda(), zero_grad=False)
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.detach().clone() for n, p in t.model.named_parameters() if p.grad is not None})
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
+    qkv = [n for n in grads[0] if n.endswith("attn.qkv.weight")]
+    assert qkv and all(float(grads[0][n].abs().sum()) > 0 for n in qkv)

@@ -132,7 +132,7 @@ def main():
         do = torch.randn(B, N, D, device=dev).to(bf)
         dq = torch.empty(B, N, 3 * D, device=dev, dtype=bf)
         dl = torch.empty(B, H, N, device=dev)
-        rec("attn_bwd (dq + dkv)", timeit(lambda: ops.attention_bwd(qkv, o, lse, do, dq, dl, B, N, H, dt)), M * D * 16, fl * 3.5)
+        rec("attn_bwd", timeit(lambda: ops.attention_bwd(qkv, o, lse, do, dq, dl, B, N, H, dt)), M * D * 16, fl * 3.5)
     if want("colsum"):
         part = torch.empty(ops.colsum_blocks(M) * F, device=dev)
         out = torch.empty(F, device=dev)

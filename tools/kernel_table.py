@@ -148,9 +148,10 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     do = rn(B, N, D).to(bf)
     dq = torch.empty(B, N, 3 * D, device=dev, dtype=bf)
     dl = torch.empty(B, H, N, device=dev)
-    # algorithmic bytes: every operand ONCE for the pair of kernels -- q, k, v, dO, O read (5 u), dq, dk, dv written (3 u); the dq and the dk / dv
-    # kernel each read q, k, v, dO, so the pair MOVES 12 u (PMC: 470 MB against 310 algorithmic at DeiT-Tiny batch 512)
-    add("attn_bwd (dq + dkv)", "k_attn_bwd", Lf, 8 * u, afl * 2.5, lambda: ops.attention_bwd(qkv3, o, lse, do, dq, dl, B, N, H, dt))
+    # algorithmic bytes: every operand ONCE -- q, k, v, dO, O read (5 u), dq, dk, dv written (3 u).  r5: at N = 193 .. 200 in bf16 this is ONE kernel
+    # (k_attn_bwd_one: S and dP once per tile pair, every operand crosses HBM once); the dq + dk/dv pair (other shapes, float32) moved 12 u
+    # (PMC: 470 MB against 310 algorithmic at DeiT-Tiny batch 512).  The launch is the one the step makes (variant 0: at H <= 3 on 7/8 of the CUs)
+    add("attn_bwd", "k_attn_bwd", Lf, 8 * u, afl * 2.5, lambda: ops.attention_bwd(qkv3, o, lse, do, dq, dl, B, N, H, dt))
     # ---- backward, weight-gradient stream (each entry = the split-M GEMM + its fixed-order reduction)
     ws = torch.empty(max(ops.gemm_tn_workspace_bytes(M, F, D), ops.gemm_tn_workspace_bytes(M, D, F), ops.gemm_tn_workspace_bytes(M, 3 * D, D), ops.gemm_tn_workspace_bytes(M, D, D)) // 4, device=dev)
     C1, C2, C3, C4 = torch.empty(D, F, device=dev), torch.empty(F, D, device=dev), torch.empty(D, D, device=dev), torch.empty(3 * D, D, device=dev)

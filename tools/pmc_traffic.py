@@ -30,7 +30,7 @@ NAMES = {
     "dfc1+ln2_bwd": ["k_gemm_wsn_lnbwd_dma<24"],
     "dqkv+ln1_bwd": ["k_gemm_wsn_lnbwd_dma<18"],
     "dproj": ["k_gemm_ws<unsigned short, unsigned short, 0"],
-    "attn_bwd (dq + dkv)": ["k_attn_bwd_dq", "k_attn_bwd_dkv"],
+    "attn_bwd": ["k_attn_bwd_one", "k_attn_bwd_dq", "k_attn_bwd_dkv"],
     "dW2 (+reduce)": ["k_gemm_tn_dma<192, 256"],
     "dW1 (+reduce)": ["k_gemm_tn_dma<256, 192"],
     "dWproj (+reduce)": ["k_gemm_tn<unsigned short"],

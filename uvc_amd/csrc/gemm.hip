@@ -3447,11 +3447,12 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   int64_t need; int splits;
   uvc_gemm_tn_workspace_bytes(p->M, p->N1, p->N2, &need, &splits);
   if (p->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_tn: workspace too small");
-  if ((size_t)(p->M + 256) * (p->lda > p->ldb ? p->lda : p->ldb) * 2 >= (1ull << 31) && p->dtype == UVC_BF16 && tn_config(p->N1, p->N2) == 5)
-    return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_tn: operand beyond 2 GB (32-bit buffer offsets of the 256 x 256 kernel)");
   int cfg = (p->dtype == UVC_BF16 && p->lda % 8 == 0 && p->ldb % 8 == 0) ? tn_config(p->N1, p->N2) : 0;
   if (cfg == 4 && p->a_is_f32) cfg = 0;                      // the 96x192 tile exists as an LDS-DMA (bf16 operands) kernel only
   if (cfg == 5 && p->a_is_f32) cfg = (p->N1 % 192 == 0 && p->N2 % 256 == 0) ? 1 : (p->N1 % 256 == 0 && p->N2 % 192 == 0) ? 2 : 0;
+  // the 256 x 256 kernel addresses its operands with 32-bit buffer offsets: beyond 2 GB the problem goes to the generic kernel (64-bit
+  // addresses; the workspace is sized for either, see uvc_gemm_tn_workspace_bytes) -- checked on the configuration that will RUN
+  if (cfg == 5 && (size_t)(p->M + 256) * (p->lda > p->ldb ? p->lda : p->ldb) * 2 >= (1ull << 31)) cfg = 0;
   splits = tn_splits(p->M, p->N1, p->N2, cfg);
   TnArgs a;
   a.A = p->A; a.B = p->B; a.part = (float*)p->workspace; a.M = p->M; a.N1 = p->N1; a.N2 = p->N2; a.lda = p->lda; a.ldb = p->ldb;

@@ -429,6 +429,8 @@ class DistilledVisionTransformer(nn.Module):
         ``keep=False`` switches compaction off.  Returns the list of widths."""
         cfg = self._cfg
         Lz, D, F = cfg.depth, cfg.embed_dim, cfg.hidden
+        # (how the table was made: one derived from the mask buffers is derived again when load_state_dict replaces them)
+        self._mlp_compact_derived = int(multiple) if keep is None else None
         if keep is False:
             self._mlp_compact, self._mlp_bufs = None, None
             return [F] * Lz
@@ -474,6 +476,7 @@ class DistilledVisionTransformer(nn.Module):
         the masks (a head is pruned when every attn.proj mask column of its 64 inputs is zero: its output then meets only
         zero weights, so skipping it is exact once ``apply_masks()`` has run); ``False`` switches it off.  Training forwards
         never skip heads: the reference's global-norm clip includes the gradients of the masked proj columns."""
+        self._head_keep_derived = keep is None
         if keep is False:
             self._head_keep = None
             return None
@@ -507,9 +510,17 @@ class DistilledVisionTransformer(nn.Module):
         self.mark_weights_changed()
 
     def load_state_dict(self, *a, **k):
+        """nn.Module.load_state_dict, then everything that was DERIVED from the mask buffers is derived again from the loaded ones: the
+        pruned-head table (since r4 the training backward writes dq / dk / dv of a head marked pruned as zeros -- a table from other
+        masks would silently drop the gradients of live heads) and the MLP compaction.  Tables the caller passed explicitly
+        (``keep=`` a tensor) are the caller's to refresh."""
         r = super().load_state_dict(*a, **k)
         self.mark_weights_changed()
         self._run_block_host = None
+        if getattr(self, "_head_keep_derived", False):
+            self.set_head_skipping()
+        if getattr(self, "_mlp_compact_derived", None) is not None:
+            self.set_mlp_compaction(multiple=self._mlp_compact_derived)
         return r
 
     # -- engine calls ---------------------------------------------------------------------------------

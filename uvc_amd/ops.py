@@ -420,12 +420,15 @@ class KeyedExpSource:
         self.seed, self.device = int(seed) & 0xFFFFFFFFFFFFFFFF, device
         self.step, self.site = -1, 0
 
-    def begin_step(self, step):
-        """First call of an accumulation window.  A window left unfinished at an epoch boundary is followed by a new window with the SAME
-        optimiser step number (the reference restarts its window count per epoch, joint_train.py:423): its draws continue the site
-        numbering instead of replaying the key (seed, step, 0..)."""
-        if int(step) != self.step:
-            self.step, self.site = int(step), 0
+    def begin_step(self, step, resume_window=False):
+        """First call of an accumulation window.  The default REPLAYS: the key restarts at (seed, step, 0) also when ``step`` repeats the
+        current number (a retried step, an A/B replay, a determinism test get the same numbers again).  ``resume_window=True`` is for the
+        one case that must continue instead: a window left unfinished at an epoch boundary is followed by a new window with the SAME
+        optimiser step number (the reference restarts its window count per epoch, joint_train.py:423) -- the trainer knows when that is
+        (the previous window ended without an optimiser step) and says so; the draws then continue the site numbering."""
+        if resume_window and int(step) == self.step:
+            return
+        self.step, self.site = int(step), 0
 
     def __call__(self, shape):
         import torch

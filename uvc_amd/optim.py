@@ -20,7 +20,11 @@ def clip_grad_norm_(model_or_params, max_norm: float):
     computes the global L2 norm of all live gradients on the device and ARMS the clip; the scaling is
     applied inside ``FusedAdamW.step()`` (same arithmetic, one pass less over the gradients), which also
     rescales block_skip_gating.grad in place because uvc_optimizer reads it afterwards.  Returns the
-    (lazy, device) total norm."""
+    (lazy, device) total norm.
+
+    LIFETIME of the returned tensor: it is a 0-dim VIEW into a ring of 64 slots, not a fresh tensor as torch returns -- it holds this
+    call's norm until the 64th later call of clip_grad_norm_ on the same model overwrites the slot.  A caller that keeps norms longer
+    (a per-epoch log read lazily) takes ``float(norm)`` or ``norm.clone()``.  The trainers' ``step()`` return this view as ``gnorm``."""
     model = model_or_params if hasattr(model_or_params, "_flat_grad") else getattr(model_or_params, "_uvc_model", None)
     if model is None:
         raise L.UvcHipError("clip_grad_norm_: pass the uvc_amd model (or the generator from model.parameters() wrapped by FusedAdamW)")
@@ -41,7 +45,7 @@ def _clip_state(model):
         dev = model._flat.device
         ring = torch.zeros(64, 2, device=dev)
         model._clip = dict(partial=torch.empty(1024, device=dev), ring=ring, slot=0, sq=ring[0], armed=None,
-                           gnorm=torch.zeros(1, device=dev))
+                           gnorm=torch.zeros(1, device=dev), zero=torch.zeros(2, device=dev))
     return model._clip
 
 
@@ -127,6 +131,7 @@ class FusedAdamW(torch.optim.Optimizer):
         max_norm = st["armed"] if st["armed"] is not None else self.max_grad_norm
         if max_norm is None:
             max_norm = float("inf")
+            st["sq"] = st["zero"]                  # a scratch slot of its own: the ring slot a caller may still hold a norm in is not touched
             st["sq"].zero_()
         elif st["armed"] is None:
             clip_grad_norm_(m, max_norm)

@@ -155,7 +155,11 @@ class Stage2Trainer:
     def load_state_dict(self, sd):
         if sd.get("format") != "uvc_amd.stage2.v1":
             raise ValueError("not a uvc_amd Stage-2 training state")
-        self.model.load_state_dict(sd["model"])
+        self.model.load_state_dict(sd["model"])      # (re-derives the pruned-head table and the MLP compaction from the loaded masks)
+        if getattr(self.args, "compact_mlp", 1):
+            self.head_keep = self.model.set_head_skipping()
+            self.mlp_widths = self.model.set_mlp_compaction(multiple=getattr(self.args, "compact_multiple", 256))
+            self.model.skip_pruned_head_grads = self.head_keep is not None
         a, o = sd["adamw"], self.optimizer
         o.exp_avg.copy_(a["exp_avg"]); o.exp_avg_sq.copy_(a["exp_avg_sq"]); o.steps = dict(a["steps"]); o.param_groups[0]["lr"] = a["lr"]
         self.global_step, self.epoch = int(sd["progress"]["global_step"]), int(sd["progress"]["epoch"])

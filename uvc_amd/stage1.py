@@ -155,6 +155,7 @@ class Stage1Trainer:
         self.gating_grad_list = []
         # the reference counts accumulation windows with the loader index of the epoch, `(step + 1) % k` (:423): a window never straddles
         # an epoch boundary; gradients of an unfinished window stay in .grad (zero_grad sits inside the `if`) and join the next one
+        self._window_carried = self._micro % self.accum != 0    # its noise draws continue under the same step number (KeyedExpSource.begin_step)
         self._micro = 0
         # The reference keys the warm-up phase on the epoch alone (:343): --enable_warmup never reaches the model
         # (`enable_warmpup` typo in build_minimax_model's kwargs), so `--enable_warmup 0 --warmup_epochs 5` still warms up.
@@ -186,7 +187,8 @@ class Stage1Trainer:
     def step(self, x, y, tau=None, zero_grad=True):
         a = self.args
         if self._micro % self.accum == 0:
-            self.noise.begin_step(self.global_step)
+            self.noise.begin_step(self.global_step, resume_window=getattr(self, "_window_carried", False))
+            self._window_carried = False
         if getattr(a, "overlap_teacher", 1):
             self.criterion.prefetch(x)              # teacher forward on a side stream, under the student forward
         outputs, _ = self.model(x, self.get_tau() if tau is None else tau, a.patch_ratio)
@@ -275,7 +277,7 @@ class Stage1Trainer:
                      dual=[g["lr"] for g in self.dual_opt.param_groups]),
             progress=dict(global_step=self.global_step, epoch=self.epoch, gating_grad_list_len=len(self.gating_grad_list),
                           enable_warmup=int(self.model.enable_warmup), args_enable_warmup=int(self.args.enable_warmup), micro=self._micro,
-                          noise_step=int(self.noise.step), noise_site=int(self.noise.site)),
+                          noise_step=int(self.noise.step), noise_site=int(self.noise.site), window_carried=int(getattr(self, "_window_carried", False))),
             # Gumbel / mixup draws continue where they stopped: torch CPU + this device's generator, numpy's global RNG
             rng=dict(torch_cpu=torch.get_rng_state(), torch_cuda=torch.cuda.get_rng_state(self.model._flat.device),
                      numpy=_np_rng_state()),
@@ -313,6 +315,7 @@ class Stage1Trainer:
         self.model.block_skip_gating.requires_grad = not self.model.enable_warmup
         self._micro = int(pr.get("micro", 0))
         self.noise.step, self.noise.site = int(pr.get("noise_step", -1)), int(pr.get("noise_site", 0))
+        self._window_carried = bool(pr.get("window_carried", 0))
         rng = sd.get("rng")
         if rng is not None:
             torch.set_rng_state(rng["torch_cpu"].cpu())

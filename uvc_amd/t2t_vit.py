@@ -358,6 +358,14 @@ class T2T_ViT(DistilledVisionTransformer):
         st = b.get(key)
         f, sh = self._front[name], self._front_weights()
         fp, fg = self._fp, self._fg
+        # the struct caches raw device pointers: it is valid as long as the tensors behind them are the same allocations (and the precision /
+        # mode the same) -- checked by address instead of trusting that every re-allocation also drops the cache
+        w0 = sh[name + ".kqv"][0]
+        sig = (self._flat.data_ptr(), self._flat_grad.data_ptr() if training and self._flat_grad is not None else 0, w0.data_ptr(),
+               bufs["tn_ws"].data_ptr() if training and bufs is not None and "tn_ws" in bufs else 0, self._dt(), int(training))
+        if st is not None and b.get("_stage_sig") != sig:
+            st = None
+        b["_stage_sig"] = sig
         if st is None:
             st = L.uvc_t2t_stage()
             st.B, st.C, st.H, st.W, st.k, st.s, st.p = B, C_, H, W, k, s, p

@@ -99,7 +99,7 @@ class Stage2Trainer:
         # ... and training BACKWARDS skip their dq / dk / dv: step() multiplies the weights by the masks before every forward (:343-346), so
         # dL/d(attention output) of a head whose 64 attn.proj input columns are masked is exactly zero (the forward keeps the head: the
         # reference's clip norm sees dW_proj of the masked columns, which needs its output)
-        model.skip_pruned_head_grads = self.head_keep is not None
+        model.skip_pruned_head_grads = model._head_keep is not None
         # post_training(): DDP, scaled learning rate, timm optimiser + schedule (:289-301)
         self.ddp = DistributedDataParallel(model, message_size=250000000, gradient_predivide_factor=1.0) if distributed else None
         args.train_batch_size = args.train_batch_size // args.gradient_accumulation_steps
@@ -159,7 +159,7 @@ class Stage2Trainer:
         if getattr(self.args, "compact_mlp", 1):
             self.head_keep = self.model.set_head_skipping()
             self.mlp_widths = self.model.set_mlp_compaction(multiple=getattr(self.args, "compact_multiple", 256))
-            self.model.skip_pruned_head_grads = self.head_keep is not None
+            self.model.skip_pruned_head_grads = self.model._head_keep is not None
         a, o = sd["adamw"], self.optimizer
         o.exp_avg.copy_(a["exp_avg"]); o.exp_avg_sq.copy_(a["exp_avg_sq"]); o.steps = dict(a["steps"]); o.param_groups[0]["lr"] = a["lr"]
         self.global_step, self.epoch = int(sd["progress"]["global_step"]), int(sd["progress"]["epoch"])

@@ -104,8 +104,8 @@ typedef struct uvc_attn_args {
                                 Backward: dq / dk / dv of heads with 0 are written as zeros without being computed -- exact when dout is
                                 zero on the head's 64 columns, i.e. when attn.proj's input columns of that head are zero in the weights
                                 the dgrad used (Stage-2 masked fine-tuning) */
-  int32_t variant;   /* backward, tuning / A-B: 0 = kernel picked by shape (bf16, 193 <= N <= 200: the one-pass persistent kernel k_attn_bwd_one,
-                        otherwise the dq + dk/dv pair); 1 = the pair; 2 = the one-pass kernel or UVC_ERR_UNSUPPORTED */
+  int32_t variant;   /* backward, tuning / A-B: 0 = kernel picked by shape (bf16, 193 <= N <= 200, B * H >= 1024: the one-pass persistent kernel
+                        k_attn_bwd_one, otherwise the dq + dk/dv pair); 1 = the pair; 2 = the one-pass kernel or UVC_ERR_UNSUPPORTED */
   int32_t grid;      /* backward, one-pass kernel: 0 = one persistent workgroup per CU; > 0 = that many (tests: several heads per workgroup
                         at small B * H) */
 } uvc_attn_args;

@@ -906,6 +906,9 @@ int launch_one_pass(const AttnArgs& a, int grid_arg, hipStream_t st) {
   // 12.70 ms with 256 workgroups, 12.62 with 232, 11.98 with 224 (the dq + dk/dv pair: 12.20), 12.02 with 200: one free CU in EVERY
   // shader engine (256 CUs = 32 engines x 8) is what the other stream's dispatch needs -- with one engine full it stalls as if all were.
   // DeiT-Small (H = 6) is 2 % faster with the whole chip, DeiT-Base indifferent: the narrow model alone leaves the CUs.
+#ifdef UVC_ATTN_ONE_GRID                               // A/B builds only (tools/exp_ab.sh)
+  if (grid_arg <= 0) grid_arg = UVC_ATTN_ONE_GRID;
+#endif
   const int ncu_use = a.H <= 3 && ncu >= 64 ? ncu - ncu / 8 : ncu;
   const int grid = grid_arg > 0 ? (grid_arg < nbh ? grid_arg : nbh) : (nbh < ncu_use ? nbh : ncu_use);
   static std::atomic<unsigned> seq{0};
@@ -944,7 +947,10 @@ extern "C" int uvc_attention_bwd(const uvc_attn_args* p, void* stream) {
 #ifdef UVC_ATTN_BWD_PAIR_DEFAULT                       // A/B builds (tools/exp_ab.sh): variant 0 = the pair
   if (p->variant == 2) return launch_one_pass(a, p->grid, st);
 #else
-  if (p->variant != 1 && one_pass_supported(p)) return launch_one_pass(a, p->grid, st);
+  // variant 0: the one-pass kernel where a persistent workgroup gets at least ~4 heads (its prologue, and the CUs it keeps from the other stream, have to
+  // pay: T2T-ViT-14 at batch 128 -- 768 heads on 256 CUs -- is 2.8 % faster in the step with the pair, profiles/r5h_ab_attn_t2t.txt); 1024 heads stand
+  // for 4 x 256 CUs: the choice must not depend on the device the call happens to run on
+  if (p->variant == 2 || (p->variant == 0 && one_pass_supported(p) && (int64_t)p->B * p->H >= 1024)) return launch_one_pass(a, p->grid, st);
 #endif
   if (int e = dispatch<bf16_t>(a, 1, st)) return e;
   return dispatch<bf16_t>(a, 2, st);

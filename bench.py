@@ -291,7 +291,21 @@ def main():
     if os.environ.get("UVC_BENCH_SHARE_DEVICE", "0") not in ("", "0"):
         local = 0
     torch.cuda.set_device(local)
+    pinned = None
     if world > 1:
+        # one slice of the host cores per rank (the enqueue thread of a rank must not migrate or share a core with another rank's: with 8
+        # ranks on one host the ~3 ms of enqueue per 12-ms step is the first thing that can surface), and as many intra-op threads
+        ncpu = os.cpu_count() or 1
+        per = max(1, ncpu // world)
+        try:
+            avail = sorted(os.sched_getaffinity(0))
+            per = max(1, len(avail) // world)
+            mine = avail[(int(os.environ.get("LOCAL_RANK", 0)) * per) % len(avail):][:per] or avail
+            os.sched_setaffinity(0, mine)
+            pinned = [mine[0], mine[-1]]
+        except (AttributeError, OSError):
+            pass
+        torch.set_num_threads(max(1, min(per, 8)))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend)
     torch.manual_seed(730)
@@ -341,19 +355,33 @@ def main():
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     evs[0].record(st)
+    host = []
     for i in range(args.steps):
+        h0 = time.perf_counter()
         out = tr.step(x, y)
         evs[i + 1].record(st)
+        host.append(time.perf_counter() - h0)
+    t_enq = time.perf_counter() - t0                 # the host has enqueued everything; the GPU is still running if the host runs ahead
     sync()
     dt = time.perf_counter() - t0
+    host_ms = sorted(host)[len(host) // 2] * 1e3
     per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]  # noqa: E731
     exposed_ms = None
+    ranks_seen, backend_name = (dist.get_world_size(), dist.get_backend()) if world > 1 else (1, None)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
         exposed_ms = tr.ddp.exposed_comm_ms() if tr.ddp is not None else None
+        hm = torch.tensor([host_ms, t_enq], device=dev, dtype=torch.float64)
+        dist.all_reduce(hm, op=dist.ReduceOp.MAX)
+        host_ms, t_enq = float(hm[0]), float(hm[1])
+        # the ranks other than 0 are DONE here: rank 0's stand-alone kernel table below must not keep N - 1 GPUs waiting on a barrier
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
     loss = float(out["loss"])
     if rank == 0:
         imgs = world * args.batch * args.steps / dt
@@ -370,7 +398,10 @@ def main():
         line = {"metric": metric, "value": round(imgs, 1), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                 "ms_per_step_device": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3)},
-                "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
+                "ranks_seen": ranks_seen, "backend": backend_name,
+                # host side: median wall time of one tr.step() call (enqueue only, nothing synchronises inside the timed region), MAX over ranks,
+                # and how far the host ran ahead: the enqueue loop's share of the timed region (1.0 = the host is the bottleneck)
+                "host_enqueue_ms_per_step": round(host_ms, 3), "host_enqueue_share_of_wall": round(t_enq / dt, 3), "host_cores_pinned": pinned,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if args.precision.startswith("bf16") else "f32", "data": "synthetic",
                 "config": {"workload": (f"{args.model_type} Stage-1 UVC-train step, budget {args.budget:g}, per-GPU batch {args.batch}, "
@@ -433,9 +464,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.stage == 1:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), file=_real_stdout, flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 def _free_port():

@@ -123,3 +123,28 @@ def test_two_ranks_over_rccl_match_single_process(model):
         outs.append((p.returncode, o, e))
     assert all(rc == 0 for rc, _, _ in outs), "\n".join(o[-1500:] + e[-3000:] for _, o, e in outs)
     assert "DDP_TWO_RANK_OK" in outs[0][1]
+
+
+def test_bench_two_ranks_at_the_headline_batch():
+    """VERDICT r4 next #7 (first-contact hardening for 8 ranks, no node needed): the two-rank bench at the HEADLINE per-GPU batch (512, not 32), both
+    ranks on the box's GPU over gloo: the line carries the host side -- median enqueue time of a step (MAX over ranks), the enqueue loop's share of the
+    timed region, the core slice the rank was pinned to -- next to exposed_allreduce_ms_per_step; ranks other than 0 leave before rank 0's stand-alone
+    kernel table runs (the table is in the line, and the launch returns)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UVC_BENCH_BACKEND="gloo", UVC_BENCH_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "512"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["config"]["global_batch"] == 1024
+    assert 0.0 < j["host_enqueue_ms_per_step"] < j["ms_per_step"] * 1.5
+    assert 0.0 < j["host_enqueue_share_of_wall"] <= 1.0
+    assert j["host_cores_pinned"] is None or len(j["host_cores_pinned"]) == 2
+    assert j["exposed_allreduce_ms_per_step"] >= 0.0
+    assert j["roofline"] is not None and j["top_kernels"]           # rank 0 went on alone
+    print("two ranks, batch 512 each, one GPU, gloo: %.1f ms / step, host enqueue %.2f ms / step (share of wall %.2f), exposed all-reduce %.3f ms"
+          % (j["ms_per_step"], j["host_enqueue_ms_per_step"], j["host_enqueue_share_of_wall"], j["exposed_allreduce_ms_per_step"]))

@@ -57,8 +57,7 @@ def main(d, out, commit=None):
         for s in subs:
             names = [k for k in per if s in k]
             if not names:
-                ok = False
-                break
+                continue                  # (a key lists every kernel that may serve it)
             for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "GRBM_GUI_ACTIVE"):
                 vals = [v for k in names for v in per[k].get(c, [])]
                 if vals:

@@ -67,9 +67,9 @@ def main(fd, wd, out, commit=None):
             a, na = mean_for(fe, s)
             b, nb = mean_for(wr, s)
             if a is None or b is None:
-                ok = False
-                break
+                continue                      # (a key lists every kernel that may serve it: the attention backward is one kernel or a pair)
             f_kib += a; w_kib += b; n = max(n, na)
+        ok = n > 0
         if ok:
             kernels[key] = dict(fetch_kib=round(f_kib, 1), write_kib=round(w_kib, 1), hbm_bytes=int((2 * f_kib + w_kib) * 1024), launches=n)
     json.dump(dict(commit=commit, method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/kernel_table.py; "

@@ -167,6 +167,36 @@ template <> struct Store4<bf16_t> {
   }
 };
 
+// A 16 x 64 result tile in the accumulator layout (lane (row li, g): columns dt * 16 + 4 g .. + 3 of dt = 0 .. 3) leaves as 16 bytes per lane: lanes
+// g and g ^ 1 exchange halves (v_permlane16_swap: the odd 16-lane rows of one register with the even rows of the other), after which an even g holds
+// columns 8 (g >> 1) .. + 7 of block dtA and an odd g those of block dtB -- two store instructions of 64-byte row pieces where the 8-byte form
+// issues four of 32-byte pieces (the store ISSUE, not HBM, was what the one-pass backward's first form spent half its time on; float32: as before).
+template <typename T> __device__ __forceinline__ void store_tile16(T* rowp, int g, const f32x4 (&t)[4], float mul) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x2 x, y;
+      x[0] = pack_bf16x2(t[2 * h][0] * mul, t[2 * h][1] * mul); x[1] = pack_bf16x2(t[2 * h][2] * mul, t[2 * h][3] * mul);
+      y[0] = pack_bf16x2(t[2 * h + 1][0] * mul, t[2 * h + 1][1] * mul); y[1] = pack_bf16x2(t[2 * h + 1][2] * mul, t[2 * h + 1][3] * mul);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x[e], y[e], false, false);
+        o[e] = r[0]; o[2 + e] = r[1];
+      }
+      *reinterpret_cast<u32x4*>(rowp + (2 * h + (g & 1)) * 16 + (g >> 1) * 8) = o;
+    }
+  } else {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 v = t[dt];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= mul;
+      Store4<T>::st(rowp + dt * 16 + g * 4, v);
+    }
+  }
+}
+
 struct AttnArgs {
   const void* qkv;   // [B, N, 3, H, 64]
   void* o;           // [B, N, H, 64]
@@ -326,13 +356,7 @@ __global__ __launch_bounds__(sizeof(T) == 2 ? 512 : 256, sizeof(T) == 2 ? 4 : 1)
         const int q = qt * 16 + li;
         if (q < a.N) {
           const float inv = 1.0f / l_run;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            f32x4 v = ot[dt];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= inv;
-            Store4<T>::st(ob + (size_t)q * a.H * HD + dt * 16 + g * 4, v);
-          }
+          store_tile16<T>(ob + (size_t)q * a.H * HD, g, ot, inv);
           if (g == 0 && a.lse) a.lse[((size_t)b * a.H + h) * a.N + q] = m_run * a.scale + __logf(l_run);
         }
       }
@@ -413,10 +437,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_dq(AttnArgs a) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dq[dt] = MM::mma(TrFrag<T>::ld(sK, G::ROWB, s * MM::KSTEP, dt * 16, lane), dsf, dq[dt]);
     }
-    if (q < a.N) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) Store4<T>::st(dqb + (size_t)q * ldq + dt * 16 + g * 4, dq[dt]);
-    }
+    if (q < a.N) store_tile16<T>(dqb + (size_t)q * ldq, g, dq, 1.0f);
   }
 }
 
@@ -498,11 +519,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_dkv(AttnArgs a) {
       }
     }
     if (key < a.N) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        Store4<T>::st(dkb + (size_t)key * ldq + dt * 16 + g * 4, dk[dt]);
-        Store4<T>::st(dvb + (size_t)key * ldq + dt * 16 + g * 4, dv[dt]);
-      }
+      store_tile16<T>(dkb + (size_t)key * ldq, g, dk, 1.0f);
+      store_tile16<T>(dvb + (size_t)key * ldq, g, dv, 1.0f);
     }
   }
 }

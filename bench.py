@@ -29,7 +29,7 @@ _real_stdout = sys.stdout
 GFLOP_PER_IMG = {"deit_tiny_patch16_224": 9.972, "deit_small_patch16_224": 36.675, "deit_base_patch16_224": 140.28,
                  "t2t_vit_14": 37.42}      # T2T: 2*(3E + 4*L*Bk + 4*C) with E = 256,647,680; the tokens-to-token dgrad (<= 0.51) not counted
 # Of the last block only the class-token row reaches the head, so the engine runs that block's attention output, proj, LayerNorm2, MLP
-# and their backward on B rows instead of B*N (uvc_vit_io.full_tail = 0): the same loss, logits and gradients
+# and their backward on B rows instead of B*N (uvc_vit_io.full_tail = 0, NOTEBOOK.md section 5b): the same loss, logits and gradients
 # with 4 * (2 N^2 D + N D^2 + 2 N D F) * (1 - 1/N) fewer multiply-adds per image (student + teacher forward, 2x backward).  The
 # TFLOP/s figures of the JSON line use the EXECUTED count; `--full_tail 1` runs every row as the reference does.
 def executed_gflop_per_img(model_type, full_tail):

@@ -7,7 +7,7 @@ Build container only (needs /root/reference).  Usage: python tests/golden/make_t
 This is the pin for the BACKWARD of the tokens-to-token module (soft split, Performer linear attention, LayerNorms,
 project): the gradients below come from the reference's modules.  Harness changes, all stated here:
   * the Performer's Dropout(0.1) layers (token_performer.py:13,24) are set to p = 0 -- they draw from the global RNG in
-    train mode; the engine does not apply them (DESIGN 10b);
+    train mode; the engine does not apply them (NOTEBOOK 10b);
   * block_skip_gating is replaced by a real [L, 2] parameter before loading (the reference's rows alias one storage);
   * timm's add_weight_decay / cosine epoch schedule are restated as in make_stage2_golden.py (parity for those unpinned).
 """

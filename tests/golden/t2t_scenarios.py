@@ -81,7 +81,7 @@ def stage1_draws(r, depth):
 
 # Stage-2 masked fine-tune steps on T2T-ViT: the reference CAN run these (post_train.py:165-167 builds t2t_vit_14() with the
 # default flags = hard block skip, and calls model(x)); make_t2t_stage2_golden.py runs its own T2T_ViT, loss and autograd
-# with the Performer's Dropout(0.1) layers set to p = 0 (RNG-free fixture; the engine does not apply them).
+# with the Performer's Dropout(0.1) layers set to p = 0 (RNG-free fixture; the engine does not apply them, NOTEBOOK 10b).
 STAGE2 = {
     "t2t_stage2_micro": dict(model="micro3", batch=4, steps=2, seed=61, skip_blocks=[1], epoch_of_step=[1, 2], weight_gain=3.0),
 }

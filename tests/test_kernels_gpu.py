@@ -633,7 +633,7 @@ def test_fused_training_mlp(M, F_, gated):
     backward reads -- LayerNorm(x) (bf16), mean / rstd, GELU'(a), GELU(a) (bf16 [M, F]) -- against float64 math on the same
     bf16-rounded operands and against the three kernels it would replace; deterministic; rows do not depend on the batch.
     (r2d kernel: 218 us against 187 us for the three kernels at batch 512, so the engine keeps the unfused training forward by default
-    -- uvc_vit_io.fused_train_mlp opts in)"""
+    -- uvc_vit_io.fused_train_mlp opts in; NOTEBOOK section 11.)"""
     from uvc_amd import ops
     D = 192
     x = rnd(M, D, seed=111) * 1.5 + 0.2

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Upper-bound probes for the two byte items VERDICT r3 next #5 asks to MEASURE before building:
+# Upper-bound probes for the two byte items VERDICT r3 next #5 asks to MEASURE before building (NOTEBOOK §11 / §12):
 #   (a) teacher qkv projected inside its attention kernel   -> library variant "noteacherqkv": the no-grad forward (the teacher) skips its qkv GEMM
 #       altogether (attention reads whatever the buffer holds): what the step would gain if that GEMM cost NOTHING
 #   (b) fc1 stores ONE tensor instead of GELU(a) and GELU'(a) -> variant "onegelu": the training fc1 writes GELU(a) only, the backward reads the stale

@@ -6,7 +6,7 @@
 //   training (the student's forward, opt-in: uvc_vit_io.fused_train_mlp): the same pass also stores what the backward reads --
 //     LayerNorm(x1) (bf16 [M, D], operand of dW1), its mean / rstd, GELU'(a) and GELU(a) (bf16 [M, F]) -- from the accumulator
 //     registers.  Measured 218 us against 187 us for LayerNorm + fc1 + fc2: its 64-byte row pieces of GELU / GELU' write badly.
-// History: round 1-2's kernel ran 8 waves x 32 rows in lockstep with the weights staged through registers
+// History (NOTEBOOK.md 5c / 11): round 1-2's kernel ran 8 waves x 32 rows in lockstep with the weights staged through registers
 // (133 us); the structure below is the result of the s_memtime traces and probes of round 2.
 #include "common.h"
 #include "../../include/uvc_kernels.h"
@@ -30,7 +30,7 @@ __device__ __forceinline__ u32x4 pack8u(const f32x4& lo, const f32x4& hi) {
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) { return __builtin_bit_cast(bf16x8, pack8u(lo, hi)); }
 
-// What the probes of round 2 showed (tools/probe/*.hip, s_memtime traces of the kernel itself):
+// What the probes of round 2 showed (tools/probe/*.hip, s_memtime traces of the kernel itself; NOTEBOOK.md 5c):
 //   * one wave issues v_mfma_f32_16x16x32_bf16 every 18.3 ticks; two waves on a SIMD reach 12.3 together;
 //   * a dense VALU stream (the GELU) on one wave of a SIMD stalls the other wave's MFMAs almost completely -- matrix and VALU
 //     phases of the two waves of a SIMD ADD, whatever s_setprio says; only memory waits overlap with either; inside ONE wave an
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(V3_NTH, 2) void k_mlp_fused_v3(uvc_mlp_args a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// k_mlp_fused_p: the inference form for the bf16 residual stream as ONE persistent 8-wave workgroup per CU.
+// k_mlp_fused_p: the inference form for the bf16 residual stream as ONE persistent 8-wave workgroup per CU (NOTEBOOK.md 5g).
 // k_mlp_fused_v3 at batch 512 is two generations of workgroups (788 = 512 + 276), each [rows in: two serial HBM round trips + LayerNorm]
 // [24 chunks][rows out], all workgroups of the chip in the same phase.  Here:
 //   * a workgroup owns a contiguous range of 16-row tiles (24 or 25 at batch 512) and walks it in passes of up to 13 tiles: tile k of a

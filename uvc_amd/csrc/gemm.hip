@@ -2465,7 +2465,7 @@ bool nt256_takes(const NtArgs& a, bool a_f32, bool any_size) { return nt256_ok(a
 //        NT on (32 RI) x 256 tiles with two wave groups half a phase apart ("8-phase" schedule)
 // ================================================================================================
 // k_gemm_nt256 keeps its eight waves in lock step: everybody reads fragments, everybody issues MFMAs, everybody waits at the one
-// barrier of a k-step -- the matrix pipe idles ~27 % of every step.  Here the workgroup's two M groups (waves 0-3 /
+// barrier of a k-step -- the matrix pipe idles ~27 % of every step (NOTEBOOK.md 5f).  Here the workgroup's two M groups (waves 0-3 /
 // 4-7: one wave of each on every SIMD) run HALF A PHASE apart: a k-step of 64 is four phases, a phase is
 //     [fragment reads + LDS-DMA requests] s_barrier [16 MFMAs] s_barrier
 // and group 1 passes one extra barrier up front, so that while one wave of a SIMD issues its MFMA block the other one is in its

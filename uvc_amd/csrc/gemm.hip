@@ -2426,7 +2426,10 @@ int launch_row384_fwd(const NtArgs& a, int epi, hipStream_t st) {
   f.bias = a.bias; f.R = a.R; f.R2 = a.R2; f.dptr = a.dptr; f.C = a.C; f.ln_gamma = a.ln_gamma; f.ln_beta = a.ln_beta; f.ln_out = a.ln_out;
   f.ln_mean = a.ln_mean; f.ln_rstd = a.ln_rstd; f.ln_eps = a.ln_eps; f.gate = epi == UVC_EPI_BIAS_RESID_GATE ? 1 : 0;
   const int tiles_m = ceil_div(a.M, R3_BM);
-  const int grid = tiles_m < 256 ? tiles_m : 256;
+#ifndef UVC_ROW384_FWD_GRID
+#define UVC_ROW384_FWD_GRID 256                         // (A/B builds: tools/exp_ab.sh)
+#endif
+  const int grid = tiles_m < UVC_ROW384_FWD_GRID ? tiles_m : UVC_ROW384_FWD_GRID;
   UVC_MAX_LDS(R3_LDS, k_gemm_row384_lnbwd<true, 1>);
   k_gemm_row384_lnbwd<true, 1><<<grid, 512, R3_LDS, st>>>(b, tiles_m, f);
   UVC_CHECK_LAUNCH();

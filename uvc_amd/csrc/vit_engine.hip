@@ -471,7 +471,25 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     const int64_t* q = o.blk[l];
     if (!h1_ready) TRY(ln_fwd(c, xin, q[0], q[1], b.h1, b.mean1, b.rstd1, d.M, 1, d.D));      // else: written by the previous block's MLP kernel
     h1_ready = false;
-    TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, d.qkv_bias ? UVC_EPI_BIAS : UVC_EPI_NONE, d.qkv_bias ? P + q[3] : nullptr));
+    // r5: the qkv Linear and the attention forward as ONE kernel where it exists (DeiT-Tiny's shape, bf16): the same bits as the two kernels, h1 in and o out
+    // -- qkv is written only for a backward to read.  Not in the last block (its attention runs on the token rows, its K / V on all of them), not with pruned
+    // heads skipped (inference on a pruned model), not under force_generic = 1.
+    const bool head_skip = io->head_keep && !io->training;
+#ifdef UVC_NO_QKV_ATTN_FUSION                            // A/B builds only (tools/exp_ab.sh)
+    const bool qkv_attn_fused = false;
+#else
+    const bool qkv_attn_fused = !tail && !head_skip && io->force_generic != 1 && uvc_qkv_attention_supported(d.B, d.N, d.H, d.D, d.dtype);
+#endif
+    if (qkv_attn_fused) {
+      uvc_qkv_attn_args qa;
+      memset(&qa, 0, sizeof(qa));
+      qa.h = b.h1; qa.w = wmat(c, q[2], c.soff.blk_w[l][0]); qa.bias = d.qkv_bias ? P + q[3] : nullptr;
+      qa.qkv = io->training ? b.qkv : nullptr; qa.o = b.o; qa.lse = b.lse;
+      qa.B = d.B; qa.N = d.N; qa.H = d.H; qa.D = d.D; qa.dtype = d.dtype; qa.scale = 0.125f;
+      TRY(uvc_qkv_attention_fwd(&qa, c.st));
+    } else {
+      TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, d.qkv_bias ? UVC_EPI_BIAS : UVC_EPI_NONE, d.qkv_bias ? P + q[3] : nullptr));
+    }
     // From here on the last block works on its token rows only (rows = B * ntok, compact buffers): nothing else of it reaches the head
     const int rows = tail ? Rt : d.M;
     const void* xres = xin;                  // the block's input rows: residual of proj, R2 of the gate mix
@@ -483,7 +501,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
       TRY(attn_tok(c, b, false, l));
       TRY(gather_tok(c, xin, t.xc, d.rsz));
       xres = t.xc;
-    } else {
+    } else if (!qkv_attn_fused) {
       TRY(attn(c, b, false, l));
     }
     // Stage-2 compaction: pruned hidden units are skipped (compact weights gathered by the host, uvc_mlp_compact)

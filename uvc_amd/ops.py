@@ -113,6 +113,19 @@ def attention_bwd(qkv, o, lse, dout, dqkv, delta, B, N, H, dtype, head_keep=None
     L.check(L.lib().uvc_attention_bwd(C.byref(a), L.cur_stream()), "uvc_attention_bwd")
 
 
+def qkv_attention_supported(B, N, H, D, dtype):
+    return bool(L.lib().uvc_qkv_attention_supported(B, N, H, D, dtype))
+
+
+def qkv_attention_fwd(h, w, bias, o, lse, B, N, H, dtype, qkv=None, grid=0):
+    """The qkv Linear + attention forward as one kernel (include/uvc_kernels.h: uvc_qkv_attention_fwd); qkv is written when given."""
+    _chk(h, w, o)
+    a = L.uvc_qkv_attn_args()
+    a.h, a.w, a.bias, a.qkv, a.o, a.lse = (L.ptr(t) for t in (h, w, bias, qkv, o, lse))
+    a.B, a.N, a.H, a.D, a.dtype, a.scale, a.grid = B, N, H, H * 64, dtype, 64 ** -0.5, int(grid)
+    L.check(L.lib().uvc_qkv_attention_fwd(C.byref(a), L.cur_stream()), "uvc_qkv_attention_fwd")
+
+
 def _attn_tok_args(qkv, o, B, N, H, ntok, dtype, dout=None, dqkv=None):
     a = L.uvc_attn_tok_args()
     for t in (qkv, o, dout, dqkv):

@@ -77,13 +77,23 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     n_ln1 = 1 if fuse_ln else L
     add("ln_fwd", "k_ln_fwd_v", (1 + T) * n_ln1 + (0 if fuse_ln else Lf), ru + u, 0, lambda: ops.layernorm_fwd(xr, gam, bet, y, m_, r_, M, D, dt), wfrac=u / (ru + u))
     qkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
-    add("qkv", "k_gemm_ws<unsigned short, unsigned short, 1" if tiny else "k_gemm", (1 + T) * L, 4 * u, 2.0 * M * D * 3 * D,
-        lambda: ops.gemm_nt(xb, Wqkv, qkv, dtype=dt, epilogue=ops.EPI_BIAS, bias=b3))
     qkv3 = rn(B, N, 3 * D).to(bf)
     o = torch.empty(B, N, D, device=dev, dtype=bf)
     lse = torch.empty(B, H, N, device=dev)
     afl = 4.0 * B * H * N * N * 64
-    add("attn_fwd", "k_attn_fwd", (1 + T) * Lf, 4 * u, afl, lambda: ops.attention_fwd(qkv3, o, lse, B, N, H, dt))
+    # r5: where uvc_qkv_attention_fwd exists (DeiT-Tiny's shape) the qkv Linear and the attention forward of every block but the last are ONE kernel:
+    # h in, o out, qkv written only by the student (the backward reads it); the last block keeps the qkv GEMM (its attention runs on the token rows)
+    fused_qa = tail and ops.qkv_attention_supported(B, N, H, D, dt)
+    if fused_qa:
+        add("qkv+attn_fwd (student)", "k_qkv_attn_fwd<true", Lf, 5 * u, 2.0 * M * D * 3 * D + afl,
+            lambda: ops.qkv_attention_fwd(xb, Wqkv, b3, o, lse, B, N, H, dt, qkv=qkv.view(B, N, 3 * D)), wfrac=0.8)
+        if T:
+            add("qkv+attn_fwd (teacher)", "k_qkv_attn_fwd<false", Lf, 2 * u, 2.0 * M * D * 3 * D + afl,
+                lambda: ops.qkv_attention_fwd(xb, Wqkv, b3, o, lse, B, N, H, dt), wfrac=0.5)
+    add("qkv", "k_gemm_ws<unsigned short, unsigned short, 1" if tiny else "k_gemm", (1 + T) * (L - Lf if fused_qa else L), 4 * u, 2.0 * M * D * 3 * D,
+        lambda: ops.gemm_nt(xb, Wqkv, qkv, dtype=dt, epilogue=ops.EPI_BIAS, bias=b3))
+    if not fused_qa:
+        add("attn_fwd", "k_attn_fwd", (1 + T) * Lf, 4 * u, afl, lambda: ops.attention_fwd(qkv3, o, lse, B, N, H, dt))
     if tail:
         oc, doc = torch.empty(B, 1, D, device=dev, dtype=bf), rn(B, 1, D).to(bf)
         dq_t = torch.empty(B, N, 3 * D, device=dev, dtype=bf)

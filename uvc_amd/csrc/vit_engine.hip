@@ -486,6 +486,9 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
       qa.h = b.h1; qa.w = wmat(c, q[2], c.soff.blk_w[l][0]); qa.bias = d.qkv_bias ? P + q[3] : nullptr;
       qa.qkv = io->training ? b.qkv : nullptr; qa.o = b.o; qa.lse = b.lse;
       qa.B = d.B; qa.N = d.N; qa.H = d.H; qa.D = d.D; qa.dtype = d.dtype; qa.scale = 0.125f;
+#ifdef UVC_QKV_ATTN_GRID
+      qa.grid = UVC_QKV_ATTN_GRID;
+#endif
       TRY(uvc_qkv_attention_fwd(&qa, c.st));
     } else {
       TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, d.qkv_bias ? UVC_EPI_BIAS : UVC_EPI_NONE, d.qkv_bias ? P + q[3] : nullptr));

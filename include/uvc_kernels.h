@@ -115,7 +115,7 @@ int uvc_attention_bwd(const uvc_attn_args* args, void* stream);
 /* The qkv Linear and the attention forward of a block as ONE kernel (UVC/models/model_distilled.py:175-185: `self.qkv(x)` ... `attn @ v`):
  * h [B*N, D] (the LayerNorm-1 rows) and the qkv weight [3D, D] in, o [B,N,H*64] and lse out; qkv [B,N,3,H,64] is written only when the
  * pointer is given (the backward needs it; a no-grad forward does not).  Same bits as uvc_gemm_nt (UVC_EPI_BIAS) + uvc_attention_fwd.
- * Where uvc_qkv_attention_supported() (bf16, D = 192, H = 3, 193 <= N <= 208). */
+ * Where uvc_qkv_attention_supported() (bf16, D = 64 H = 192 or 384, 193 <= N <= 208). */
 typedef struct uvc_qkv_attn_args {
   const void* h;       /* T [B*N, D] */
   const void* w;       /* T [3D, D]   qkv weight, out-major (the bf16 shadow) */
@@ -125,7 +125,7 @@ typedef struct uvc_qkv_attn_args {
   float* lse;          /* [B,H,N] or NULL */
   int32_t B, N, H, D, dtype;
   float scale;
-  int32_t grid;        /* 0 = one persistent workgroup per CU; > 0 = that many (tests) */
+  int32_t grid;        /* 0 = one persistent workgroup per CU (a workgroup takes (image, group of 3 heads) items); > 0 = that many (tests) */
 } uvc_qkv_attn_args;
 int uvc_qkv_attention_supported(int32_t B, int32_t N, int32_t H, int32_t D, int32_t dtype);
 int uvc_qkv_attention_fwd(const uvc_qkv_attn_args* args, void* stream);

@@ -217,14 +217,15 @@ def test_attention_fwd_bwd(dtype, B, N, H):
     torch.testing.assert_close(dqkv.double(), x.grad, **tb)
 
 
-@pytest.mark.parametrize("B,N,grid,bias", [(2, 197, 0, True), (7, 197, 3, True), (5, 198, 2, False), (3, 193, 0, True), (2, 208, 1, True)])
-def test_qkv_attention_forward_fused_equals_the_two_kernels(B, N, grid, bias):
+@pytest.mark.parametrize("B,N,H,grid,bias", [(2, 197, 3, 0, True), (7, 197, 3, 3, True), (5, 198, 3, 2, False), (3, 193, 3, 0, True), (2, 208, 3, 1, True),
+                                             (3, 197, 6, 0, True), (5, 197, 6, 4, False), (2, 198, 6, 3, True)])
+def test_qkv_attention_forward_fused_equals_the_two_kernels(B, N, H, grid, bias):
     """uvc_qkv_attention_fwd (the qkv Linear + attention forward as one persistent kernel, r5) against uvc_gemm_nt (bias epilogue) + uvc_attention_fwd on the
     same inputs: o, lse and the stored qkv BIT for bit (same accumulation chain, same rounding points), with and without storing qkv, several images per
     workgroup (grid < B), both ends of the N range; and against float64."""
     from uvc_amd import ops
-    H, D = 3, 192
-    assert ops.qkv_attention_supported(B, N, H, D, BF16) and not ops.qkv_attention_supported(B, 64, H, D, BF16) and not ops.qkv_attention_supported(B, N, 6, 384, BF16)
+    D = 64 * H                              # D = 192: one work item per image; D = 384: two groups of three heads per image, 32-row weight chunks
+    assert ops.qkv_attention_supported(B, N, H, D, BF16) and not ops.qkv_attention_supported(B, 64, H, D, BF16) and not ops.qkv_attention_supported(B, N, 12, 768, BF16)
     h = to_t(rnd(B * N, D, seed=41), BF16)
     W = to_t(rnd(3 * D, D, seed=42) * 0.08, BF16)
     bvec = rnd(3 * D, seed=43) * 0.1 if bias else None

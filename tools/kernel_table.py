@@ -83,7 +83,7 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     afl = 4.0 * B * H * N * N * 64
     # r5: where uvc_qkv_attention_fwd exists (DeiT-Tiny's shape) the qkv Linear and the attention forward of every block but the last are ONE kernel:
     # h in, o out, qkv written only by the student (the backward reads it); the last block keeps the qkv GEMM (its attention runs on the token rows)
-    fused_qa = tail and ops.qkv_attention_supported(B, N, H, D, dt)
+    fused_qa = tail and D == 192 and ops.qkv_attention_supported(B, N, H, D, dt)      # (the engine's condition: vit_engine.hip)
     if fused_qa:
         add("qkv+attn_fwd (student)", "k_qkv_attn_fwd<true", Lf, 5 * u, 2.0 * M * D * 3 * D + afl,
             lambda: ops.qkv_attention_fwd(xb, Wqkv, b3, o, lse, B, N, H, dt, qkv=qkv.view(B, N, 3 * D)), wfrac=0.8)

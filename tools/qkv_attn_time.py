@@ -4,7 +4,8 @@ import torch
 from uvc_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 grid = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-N, H, D = 197, 3, 192
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+N, D = 197, 64 * H
 g = torch.Generator(device="cuda").manual_seed(0)
 h = torch.randn(B * N, D, device="cuda", generator=g).bfloat16()
 W = (torch.randn(3 * D, D, device="cuda", generator=g) * 0.08).bfloat16()

@@ -197,6 +197,20 @@ template <typename T> __device__ __forceinline__ void store_tile16(T* rowp, int 
   }
 }
 
+// the same for a 16 x 32 tile (two column blocks): one 16-byte store per lane
+__device__ __forceinline__ void store_tile16_half(bf16_t* rowp, int g, const f32x4 (&t)[2]) {
+  u32x2 x, y;
+  x[0] = pack_bf16x2(t[0][0], t[0][1]); x[1] = pack_bf16x2(t[0][2], t[0][3]);
+  y[0] = pack_bf16x2(t[1][0], t[1][1]); y[1] = pack_bf16x2(t[1][2], t[1][3]);
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x[e], y[e], false, false);
+    o[e] = r[0]; o[2 + e] = r[1];
+  }
+  *reinterpret_cast<u32x4*>(rowp + (g & 1) * 16 + (g >> 1) * 8) = o;
+}
+
 struct AttnArgs {
   const void* qkv;   // [B, N, 3, H, 64]
   void* o;           // [B, N, H, 64]
@@ -867,58 +881,67 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a, int
 namespace qa {
 constexpr int NT = 13;                                         // token tiles (N <= 208) = compute waves
 constexpr int NHW = 3;                                         // helper waves
-constexpr int KS = 6;                                          // k-steps of 32 over D = 192
-constexpr int WROW = KS * 64;                                  // bytes of a weight row
-constexpr int WCH = 64 * WROW;                                 // a chunk: the 64 rows of one of Wq / Wk / Wv of a head (24 KB)
+constexpr int HG = 3;                                          // heads per work item: a workgroup owns (image, group of 3 heads) -- DeiT-Tiny: the image
+constexpr int WCH = 24576;                                     // a weight chunk in LDS: 24 KB = 64 rows at D = 192, 32 rows at D = 384
 constexpr int IMG = 224 * Geom<bf16_t>::ROWB;                  // Q / K / V image of a head: 14 tiles of 160-byte rows (rows >= N stay zero)
 constexpr int OFF_W = 3 * IMG;
 constexpr int TOTAL = OFF_W + 2 * WCH;                         // 156 672
 static_assert(TOTAL <= 163840, "LDS");
-__device__ __forceinline__ int swzw(int row) { return (row >> 1) & 7; }      // 384-byte rows: 16-byte slot ^ ((row >> 1) & 7) (k_mlp_fused_p's W1 image)
+// conflict-free ds_read_b128 of row fragments (lane li = row, g = 16-byte slot) from unpadded weight rows: 384-byte rows alternate bank halves, so
+// slot ^ ((row >> 1) & 7) (k_mlp_fused_p's W1 image); 768-byte rows all start on bank 0, so slot ^ (row & 15)
+template <int KS> __device__ __forceinline__ int swzw(int row) { return KS == 6 ? (row >> 1) & 7 : row & 15; }
 
 struct Args {
   const bf16_t* h; const bf16_t* w; const float* bias; bf16_t* qkv; bf16_t* o; float* lse;
   int B, N, H; float scale;
 };
 
-template <bool STORE, int NFULL>
+// KS = D / 32 (6: DeiT-Tiny; 12: DeiT-Small, T2T-ViT-14)
+template <int KS, bool STORE, int NFULL>
 __global__ __launch_bounds__((NT + NHW) * 64) void k_qkv_attn_fwd(Args a) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   typedef Geom<T> G;
+  constexpr int WROW = KS * 64;                                 // bytes of a weight row
+  constexpr int CR = WCH / WROW;                                // rows of a chunk (64 / 32)
+  constexpr int NCM = 64 / CR;                                  // chunks per matrix and head (1 / 2)
+  constexpr int NJB = CR / 16;                                  // 16-row blocks of a chunk (4 / 2)
+  constexpr int NCH = HG * 3 * NCM;                             // chunks per work item
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int D = a.H * HD;
+  const int D = a.H * HD, ngrp = a.H / HG;
+  const int nitems = a.B * ngrp;
   {
     const u32x4 z = {0u, 0u, 0u, 0u};
     for (int i = tid * 16; i < OFF_W; i += (NT + NHW) * 64 * 16) *reinterpret_cast<u32x4*>(smem + i) = z;
   }
   __syncthreads();
-  const int nimg = ((int)a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // images of this workgroup
-  const int nchunk = nimg * a.H * 3;
+  const int nmine = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // work items of this workgroup
 
   if (w >= NT) {
     // ------------------------------------------------------------------ helper waves: the weight chunks, one ahead of their use
     const int j = w - NT;
     auto issue = [&](int c) {
-      const int hm = c % (a.H * 3), hh = hm / 3, m = hm % 3;
-      const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(m * D + hh * HD) * WROW;
+      const int item = (int)blockIdx.x + (c / NCH) * (int)gridDim.x, cc = c % NCH;
+      const int hh = (item % ngrp) * HG + cc / (3 * NCM), m = (cc / NCM) % 3, part = cc % NCM;
+      const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(m * D + hh * HD + part * CR) * WROW;
       char* dst = smem + OFF_W + (c & 1) * WCH;
 #pragma unroll
       for (int i = 0; i < 24 / NHW; ++i) {
-        const int p = j + NHW * i;                               // 1-KB piece: 16-byte slots 64 p .. 64 p + 63 of the chunk's 64 x 24
-        const int L = p * 64 + lane, row = L / 24, slot = L % 24;
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + row * WROW + ((slot ^ swzw(row)) << 4)),
+        const int p = j + NHW * i;                               // 1-KB piece: 16-byte slots 64 p .. 64 p + 63 of the chunk
+        const int L = p * 64 + lane, row = L / (KS * 4), slot = L % (KS * 4);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + row * WROW + ((slot ^ swzw<KS>(row)) << 4)),
                                          (void __attribute__((address_space(3)))*)(dst + p * 1024), 16, 0, 0);
       }
     };
+    const int nchunk = nmine * NCH;
     if (nchunk > 0) issue(0);
     for (int c = 0; c < nchunk; ++c) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunk c has landed
       __syncthreads();                                          // X_c: ... and the chunk before it has been used
       if (c + 1 < nchunk) issue(c + 1);
-      if (c % 3 == 2) __syncthreads();                          // A: the head's K / V images are complete (the compute waves' barrier)
+      if (c % (3 * NCM) == 3 * NCM - 1) __syncthreads();        // A: the head's K / V images are complete (the compute waves' barrier)
     }
     return;
   }
@@ -928,46 +951,52 @@ __global__ __launch_bounds__((NT + NHW) * 64) void k_qkv_attn_fwd(Args a) {
   const float c2 = a.scale * 1.44269504088896340736f;
   char* sQ = smem; char* sK = smem + IMG; char* sV = smem + 2 * IMG;
   int c = 0;
-  for (int img = blockIdx.x; img < a.B; img += gridDim.x) {
-    // this wave's 16 LayerNorm rows as B fragments (rows past the sequence: zeros)
-    typename MM::Frag hf[KS];
-    {
-      const bf16_t* hp = a.h + ((size_t)img * a.N + tok) * D;
-      const u32x4 z = {0u, 0u, 0u, 0u};
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int img = item / ngrp, h0 = (item % ngrp) * HG;
+    const bf16_t* hp = a.h + ((size_t)img * a.N + tok) * D;
+    for (int hh = h0; hh < h0 + HG; ++hh) {
+      // this wave's 16 LayerNorm rows as B fragments (rows past the sequence: zeros); asked for again per head (L1 / L2): not live under the attention phase
+      typename MM::Frag hf[KS];
+      {
+        const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) hf[ks] = __builtin_bit_cast(typename MM::Frag, tok < a.N ? *reinterpret_cast<const u32x4*>(hp + (ks * 4 + g) * 8) : z);
-    }
-    for (int hh = 0; hh < a.H; ++hh) {
+        for (int ks = 0; ks < KS; ++ks) hf[ks] = __builtin_bit_cast(typename MM::Frag, tok < a.N ? *reinterpret_cast<const u32x4*>(hp + (ks * 4 + g) * 8) : z);
+      }
 #pragma unroll 1
-      for (int m = 0; m < 3; ++m, ++c) {
+      for (int mp = 0; mp < 3 * NCM; ++mp, ++c) {
+        const int m = mp / NCM, part = mp % NCM;
         __syncthreads();                                        // X_c
         const char* wb = smem + OFF_W + (c & 1) * WCH;
-        f32x4 acc[4];
+        f32x4 acc[NJB];
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
+        for (int jb = 0; jb < NJB; ++jb) {
           acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
           const int row = jb * 16 + li;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
-            acc[jb] = MM::mma(*reinterpret_cast<const typename MM::Frag*>(wb + row * WROW + (((ks * 4 + g) ^ swzw(row)) << 4)), hf[ks], acc[jb]);
+            acc[jb] = MM::mma(*reinterpret_cast<const typename MM::Frag*>(wb + row * WROW + (((ks * 4 + g) ^ swzw<KS>(row)) << 4)), hf[ks], acc[jb]);
         }
-        // lane (token li, g) holds outputs d = 16 jb + 4 g + e of this matrix and head: + bias, rounded once
+        // lane (token li, g) holds outputs d = part * CR + 16 jb + 4 g + e of this matrix and head: + bias, rounded once
         if (a.bias) {
 #pragma unroll
-          for (int jb = 0; jb < 4; ++jb) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + m * D + hh * HD + jb * 16 + g * 4);
+          for (int jb = 0; jb < NJB; ++jb) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + m * D + hh * HD + part * CR + jb * 16 + g * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[jb][e] += b4[e];
           }
         }
         if (tok < a.N) {
-          char* ip = smem + m * IMG + tok * G::ROWB + g * 8;
+          char* ip = smem + m * IMG + tok * G::ROWB + part * CR * 2 + g * 8;
 #pragma unroll
-          for (int jb = 0; jb < 4; ++jb) {
+          for (int jb = 0; jb < NJB; ++jb) {
             u32x2 r; r[0] = pack_bf16x2(acc[jb][0], acc[jb][1]); r[1] = pack_bf16x2(acc[jb][2], acc[jb][3]);
             *reinterpret_cast<u32x2*>(ip + jb * 32) = r;
           }
-          if (STORE) store_tile16<T>(a.qkv + ((size_t)img * a.N + tok) * 3 * D + m * D + hh * HD, g, acc, 1.0f);
+          if (STORE) {
+            bf16_t* qp = a.qkv + ((size_t)img * a.N + tok) * 3 * D + m * D + hh * HD + part * CR;
+            if constexpr (NJB == 4) store_tile16<T>(qp, g, acc, 1.0f);
+            else store_tile16_half(qp, g, acc);
+          }
         }
       }
       __syncthreads();                                          // A: every wave's K / V rows are in the images
@@ -1082,24 +1111,26 @@ AttnArgs conv(const uvc_attn_args* p) {
 }  // namespace
 
 extern "C" int uvc_qkv_attention_supported(int32_t B, int32_t N, int32_t H, int32_t D, int32_t dtype) {
-  return dtype == UVC_BF16 && D == 192 && H == 3 && N > 192 && N <= 208 && B >= 1;
+  return dtype == UVC_BF16 && (D == 192 || D == 384) && H * 64 == D && N > 192 && N <= 208 && B >= 1;
 }
 
 extern "C" int uvc_qkv_attention_fwd(const uvc_qkv_attn_args* p, void* stream) {
   if (!p || !p->h || !p->w || !p->o) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_qkv_attention_fwd: null pointer");
-  if (!uvc_qkv_attention_supported(p->B, p->N, p->H, p->D, p->dtype)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_qkv_attention_fwd: bf16, D = 192, H = 3, 193 <= N <= 208");
+  if (!uvc_qkv_attention_supported(p->B, p->N, p->H, p->D, p->dtype)) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_qkv_attention_fwd: bf16, D = 64 H = 192 or 384, 193 <= N <= 208");
   if ((((uintptr_t)p->h | (uintptr_t)p->w | (uintptr_t)p->o | (uintptr_t)p->qkv | (uintptr_t)p->bias) & 15) != 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_qkv_attention_fwd: 16-byte alignment");
   qa::Args a;
   a.h = (const bf16_t*)p->h; a.w = (const bf16_t*)p->w; a.bias = p->bias; a.qkv = (bf16_t*)p->qkv; a.o = (bf16_t*)p->o; a.lse = p->lse;
   a.B = p->B; a.N = p->N; a.H = p->H; a.scale = p->scale;
   int ncu = 256;
   { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n; } }
-  const int grid = p->grid > 0 ? (p->grid < p->B ? p->grid : p->B) : (p->B < ncu ? p->B : ncu);
+  const int nitems = p->B * (p->H / qa::HG);
+  const int grid = p->grid > 0 ? (p->grid < nitems ? p->grid : nitems) : (nitems < ncu ? nitems : ncu);
   hipStream_t st = (hipStream_t)stream;
   const bool nf12 = p->N / 16 == 12;
-#define QA_LAUNCH(ST_, NF_) { UVC_MAX_LDS(qa::TOTAL, qa::k_qkv_attn_fwd<ST_, NF_>); qa::k_qkv_attn_fwd<ST_, NF_><<<grid, (qa::NT + qa::NHW) * 64, qa::TOTAL, st>>>(a); }
-  if (p->qkv) { if (nf12) QA_LAUNCH(true, 12) else QA_LAUNCH(true, -1) }
-  else { if (nf12) QA_LAUNCH(false, 12) else QA_LAUNCH(false, -1) }
+#define QA_LAUNCH(KS_, ST_, NF_) { UVC_MAX_LDS(qa::TOTAL, qa::k_qkv_attn_fwd<KS_, ST_, NF_>); qa::k_qkv_attn_fwd<KS_, ST_, NF_><<<grid, (qa::NT + qa::NHW) * 64, qa::TOTAL, st>>>(a); }
+#define QA_KS(KS_) { if (p->qkv) { if (nf12) QA_LAUNCH(KS_, true, 12) else QA_LAUNCH(KS_, true, -1) } else { if (nf12) QA_LAUNCH(KS_, false, 12) else QA_LAUNCH(KS_, false, -1) } }
+  if (p->D == 192) QA_KS(6) else QA_KS(12)
+#undef QA_KS
 #undef QA_LAUNCH
   UVC_CHECK_LAUNCH();
   return UVC_OK;

@@ -478,7 +478,9 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
 #ifdef UVC_NO_QKV_ATTN_FUSION                            // A/B builds only (tools/exp_ab.sh)
     const bool qkv_attn_fused = false;
 #else
-    const bool qkv_attn_fused = !tail && !head_skip && io->force_generic != 1 && uvc_qkv_attention_supported(d.B, d.N, d.H, d.D, d.dtype);
+    // (D = 192 only: at D = 384 the kernel exists and is bit-identical too, but its weight-fragment reads -- every wave reads the whole chunk from LDS -- make
+    //  it no faster than the pair: DeiT-Small 15.70 against 15.67 ms, T2T-ViT-14 12.52 against 12.55, profiles/r5m)
+    const bool qkv_attn_fused = !tail && !head_skip && io->force_generic != 1 && d.D == 192 && uvc_qkv_attention_supported(d.B, d.N, d.H, d.D, d.dtype);
 #endif
     if (qkv_attn_fused) {
       uvc_qkv_attn_args qa;

@@ -399,9 +399,11 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                 "ms_per_step_device": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3)},
                 "ranks_seen": ranks_seen, "backend": backend_name,
-                # host side: median wall time of one tr.step() call (enqueue only, nothing synchronises inside the timed region), MAX over ranks,
-                # and how far the host ran ahead: the enqueue loop's share of the timed region (1.0 = the host is the bottleneck)
-                "host_enqueue_ms_per_step": round(host_ms, 3), "host_enqueue_share_of_wall": round(t_enq / dt, 3), "host_cores_pinned": pinned,
+                # host side: MEDIAN wall time of one tr.step() call (enqueue only, nothing synchronises inside the timed region), MAX over ranks: what a
+                # step costs the host when it is not held back; and the enqueue loop's share of the timed region -- that one INCLUDES the time the runtime
+                # blocks the launching thread on a full queue (a host that runs ahead is throttled to the GPU's pace: a share near 1 with a median far
+                # below ms_per_step means "ran ahead until the queue was full", not "host-bound")
+                "host_enqueue_ms_per_step": round(host_ms, 3), "host_enqueue_loop_share_of_wall": round(t_enq / dt, 3), "host_cores_pinned": pinned,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if args.precision.startswith("bf16") else "f32", "data": "synthetic",
                 "config": {"workload": (f"{args.model_type} Stage-1 UVC-train step, budget {args.budget:g}, per-GPU batch {args.batch}, "

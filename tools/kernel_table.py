@@ -85,10 +85,10 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     # h in, o out, qkv written only by the student (the backward reads it); the last block keeps the qkv GEMM (its attention runs on the token rows)
     fused_qa = tail and D == 192 and ops.qkv_attention_supported(B, N, H, D, dt)      # (the engine's condition: vit_engine.hip)
     if fused_qa:
-        add("qkv+attn_fwd (student)", "k_qkv_attn_fwd<true", Lf, 5 * u, 2.0 * M * D * 3 * D + afl,
+        add("qkv+attn_fwd (student)", "k_qkv_attn_fwd<6, true", Lf, 5 * u, 2.0 * M * D * 3 * D + afl,
             lambda: ops.qkv_attention_fwd(xb, Wqkv, b3, o, lse, B, N, H, dt, qkv=qkv.view(B, N, 3 * D)), wfrac=0.8)
         if T:
-            add("qkv+attn_fwd (teacher)", "k_qkv_attn_fwd<false", Lf, 2 * u, 2.0 * M * D * 3 * D + afl,
+            add("qkv+attn_fwd (teacher)", "k_qkv_attn_fwd<6, false", Lf, 2 * u, 2.0 * M * D * 3 * D + afl,
                 lambda: ops.qkv_attention_fwd(xb, Wqkv, b3, o, lse, B, N, H, dt), wfrac=0.5)
     add("qkv", "k_gemm_ws<unsigned short, unsigned short, 1" if tiny else "k_gemm", (1 + T) * (L - Lf if fused_qa else L), 4 * u, 2.0 * M * D * 3 * D,
         lambda: ops.gemm_nt(xb, Wqkv, qkv, dtype=dt, epilogue=ops.EPI_BIAS, bias=b3))

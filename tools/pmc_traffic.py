@@ -21,8 +21,8 @@ NAMES = {
     "ln_fwd": ["k_ln_fwd_v"],
     "qkv": ["k_gemm_ws<unsigned short, unsigned short, 1"],
     "attn_fwd": ["k_attn_fwd"],
-    "qkv+attn_fwd (student)": ["k_qkv_attn_fwd<true"],
-    "qkv+attn_fwd (teacher)": ["k_qkv_attn_fwd<false"],
+    "qkv+attn_fwd (student)": ["k_qkv_attn_fwd<6, true", "k_qkv_attn_fwd<12, true"],
+    "qkv+attn_fwd (teacher)": ["k_qkv_attn_fwd<6, false", "k_qkv_attn_fwd<12, false"],
     "proj+resid": ["k_gemm_wsn16_dma<3, 6, false"],
     "proj+resid+norm2": ["k_gemm_wsn16_dma<3, 6, true"],
     "fc1+gelu,gelu'": ["k_gemm_ws<unsigned short, unsigned short, 7"],

@@ -2426,10 +2426,10 @@ int launch_row384_fwd(const NtArgs& a, int epi, hipStream_t st) {
   f.bias = a.bias; f.R = a.R; f.R2 = a.R2; f.dptr = a.dptr; f.C = a.C; f.ln_gamma = a.ln_gamma; f.ln_beta = a.ln_beta; f.ln_out = a.ln_out;
   f.ln_mean = a.ln_mean; f.ln_rstd = a.ln_rstd; f.ln_eps = a.ln_eps; f.gate = epi == UVC_EPI_BIAS_RESID_GATE ? 1 : 0;
   const int tiles_m = ceil_div(a.M, R3_BM);
-#ifndef UVC_ROW384_FWD_GRID
-#define UVC_ROW384_FWD_GRID 256                         // (A/B builds: tools/exp_ab.sh)
-#endif
-  const int grid = tiles_m < UVC_ROW384_FWD_GRID ? tiles_m : UVC_ROW384_FWD_GRID;
+  // (r5, measured and not kept: tiles in whole rounds of the grid -- 512 frames of 98-99 rows instead of 394 of 128 at DeiT-Small batch 256, the frame rows past
+  //  the tile requested out of the descriptor's range -- DeiT-Small 15.70 -> 16.57 ms, T2T-ViT-14 12.50 -> 12.78: the 30 % more k-loops cost more than the
+  //  shorter row passes return, profiles/r5o; fewer workgroups than CUs for this launch: +- 0, profiles/r5k)
+  const int grid = tiles_m < 256 ? tiles_m : 256;
   UVC_MAX_LDS(R3_LDS, k_gemm_row384_lnbwd<true, 1>);
   k_gemm_row384_lnbwd<true, 1><<<grid, 512, R3_LDS, st>>>(b, tiles_m, f);
   UVC_CHECK_LAUNCH();

@@ -844,10 +844,8 @@ extern "C" int uvc_mlp_fused_fwd(const uvc_mlp_args* p, void* stream) {
     if (p->rows_lowp && !train && p->M >= P_MIN_ROWS && p->F >= 256) {
       const int ntiles = ceil_div(p->M, 16);
       UVC_MAX_LDS(P_LDS, k_mlp_fused_p);
-#ifndef UVC_MLP_P_GRID
-#define UVC_MLP_P_GRID 256                            // (A/B builds: tools/exp_ab.sh)
-#endif
-      k_mlp_fused_p<<<std::min(UVC_MLP_P_GRID, ceil_div(ntiles, P_PASS)), P_NTH, P_LDS, st>>>(*p, ntiles);   // one workgroup per CU
+      // one workgroup per CU (r5, profiles/r5j: on 224 / 192 / 128 workgroups the step does not move -- the teacher's MLP hides under the student's forward)
+      k_mlp_fused_p<<<std::min(256, ceil_div(ntiles, P_PASS)), P_NTH, P_LDS, st>>>(*p, ntiles);
     } else if (p->rows_lowp) { if (train) MLP_ONE(true, true) else MLP_ONE(false, true) }
     else { if (train) MLP_ONE(true, false) else MLP_ONE(false, false) }
 #undef MLP_ONE

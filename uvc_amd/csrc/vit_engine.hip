@@ -488,9 +488,8 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
       qa.h = b.h1; qa.w = wmat(c, q[2], c.soff.blk_w[l][0]); qa.bias = d.qkv_bias ? P + q[3] : nullptr;
       qa.qkv = io->training ? b.qkv : nullptr; qa.o = b.o; qa.lse = b.lse;
       qa.B = d.B; qa.N = d.N; qa.H = d.H; qa.D = d.D; qa.dtype = d.dtype; qa.scale = 0.125f;
-#ifdef UVC_QKV_ATTN_GRID
-      qa.grid = UVC_QKV_ATTN_GRID;
-#endif
+      // (persistent workgroups: one per CU.  Measured in the step, profiles/r5l, r5q: 224 / 171 / 128 workgroups for both passes 11.66 / 11.74 / 11.73 ms against 11.61;
+      //  the teacher's pass alone on 192 / 128 / 64: within the noise)
       TRY(uvc_qkv_attention_fwd(&qa, c.st));
     } else {
       TRY(nt(c, b.h1, 0, wmat(c, q[2], c.soff.blk_w[l][0]), b.qkv, 0, d.M, 3 * d.D, d.D, d.qkv_bias ? UVC_EPI_BIAS : UVC_EPI_NONE, d.qkv_bias ? P + q[3] : nullptr));

@@ -992,10 +992,15 @@ __global__ __launch_bounds__((NT + NHW) * 64) void k_qkv_attn_fwd(Args a) {
             u32x2 r; r[0] = pack_bf16x2(acc[jb][0], acc[jb][1]); r[1] = pack_bf16x2(acc[jb][2], acc[jb][3]);
             *reinterpret_cast<u32x2*>(ip + jb * 32) = r;
           }
-          if (STORE) {
-            bf16_t* qp = a.qkv + ((size_t)img * a.N + tok) * 3 * D + m * D + hh * HD + part * CR;
-            if constexpr (NJB == 4) store_tile16<T>(qp, g, acc, 1.0f);
-            else store_tile16_half(qp, g, acc);
+        }
+        if (STORE && part == NCM - 1) {
+          // the tile's rows leave from the LDS image (this wave's own writes: DS operations of a wave execute in order) as WHOLE 128-byte rows, 8 lanes a row:
+          // from the accumulator layout a store instruction covered 64 bytes of a row, and the PMC counted 1.38 x the kernel's algorithmic bytes
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int r = w * 16 + half * 8 + (lane >> 3);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + m * IMG + r * G::ROWB + (lane & 7) * 16);
+            if (r < a.N) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.qkv + ((size_t)img * a.N + r) * 3 * D + m * D + hh * HD) + (lane & 7) * 16) = v;
           }
         }
       }
@@ -1010,10 +1015,24 @@ __global__ __launch_bounds__((NT + NHW) * 64) void k_qkv_attn_fwd(Args a) {
         for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         float m_run = -INFINITY, l_run = 0.f;
         attn_key_blocks<T, 0, 14, 8, NFULL>(sK, sV, qf, a.N, c2, lane, g, li, m_run, l_run, ot);
-        if (tok < a.N) {
+        {
+          // o leaves the same way, through this wave's rows of the Q image (dead since qf was read; only this wave ever reads them)
           const float inv = 1.0f / l_run;
-          store_tile16<T>(a.o + ((size_t)img * a.N + tok) * D + hh * HD, g, ot, inv);
-          if (g == 0 && a.lse) a.lse[((size_t)img * a.H + hh) * a.N + tok] = m_run * a.scale + __logf(l_run);
+          char* ip = sQ + tok * G::ROWB + g * 8;
+          if (tok < a.N) {                                      // (rows past the sequence stay zero)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              u32x2 r; r[0] = pack_bf16x2(ot[dt][0] * inv, ot[dt][1] * inv); r[1] = pack_bf16x2(ot[dt][2] * inv, ot[dt][3] * inv);
+              *reinterpret_cast<u32x2*>(ip + dt * 32) = r;
+            }
+          }
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int r = w * 16 + half * 8 + (lane >> 3);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(sQ + r * G::ROWB + (lane & 7) * 16);
+            if (r < a.N) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o + ((size_t)img * a.N + r) * D + hh * HD) + (lane & 7) * 16) = v;
+          }
+          if (tok < a.N && g == 0 && a.lse) a.lse[((size_t)img * a.H + hh) * a.N + tok] = m_run * a.scale + __logf(l_run);
         }
       }
     }

@@ -3420,7 +3420,15 @@ static void tn_tile(int cfg, int& b1, int& b2) { b1 = (cfg == 2 || cfg == 5) ? 2
 static int tn_splits(int M, int N1, int N2, int cfg) {
   int tiles, target;
   if (cfg == 0) { tiles = ceil_div(N1, TN_B1) * ceil_div(N2, TN_B2); target = 768; }
-  else { int b1, b2; tn_tile(cfg, b1, b2); tiles = (N1 / b1) * (N2 / b2); target = 256; }   // one 8-wave group per CU
+  else {
+    int b1, b2; tn_tile(cfg, b1, b2); tiles = (N1 / b1) * (N2 / b2);
+    // one 8-wave group per CU -- on HALF the CUs where the output is a handful of tiles (DeiT-Tiny's 192-wide weights: 2-3 tiles): a split writes a float32 partial
+    // tile and the reduce reads it back, so 128 workgroups of twice the rows move half the partial bytes (50 MB of dW2's 245), and the dgrad chain on the other
+    // stream gets the CUs this HBM-bound GEMM does not need.  Measured in the step, same box (profiles/r5t): 256 / 192 / 128 / 96 / 64 workgroups
+    // 11.58 / 11.44 / 11.38 / 11.64 / 12.31 ms (the stand-alone sum RISES, 11.2 -> 11.9 ms: these GEMMs are slower alone on half the chip).
+    // The wider models keep the whole chip: DeiT-Small 15.6 -> 16.7 ms and DeiT-Base 23.4 -> 24.5 at 128 (192: +- 0 / -0.7 %), T2T-ViT-14 +0.7 %.
+    target = tiles <= 4 ? 128 : 256;
+  }
   int splits = cfg == 0 ? ceil_div(target, tiles) : target / tiles;       // big tiles: one workgroup per CU (LDS), so at most 256 of them -- one more is a second round
   const int max_splits = ceil_div(M, TN_BM);
   if (splits > max_splits) splits = max_splits;

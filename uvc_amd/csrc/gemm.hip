@@ -590,7 +590,7 @@ template <typename TA, typename TC, int KT, int WS_NW>
 static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
   const int ngroups = ceil_div(a.N, 64 * WS_NW);
   const int ntiles = ceil_div(a.M, WS_BM);
-  int nslots = (512 / ngroups) & ~7;                       // ~2 workgroups per CU in total, slots a multiple of the 8 XCDs
+  int nslots = (512 / ngroups) & ~7;                       // ~2 workgroups per CU in total, slots a multiple of the 8 XCDs (r5: these main-stream kernels on 224 / 192 CUs: +1 % step time, profiles/r5u)
   if (nslots < 8) nslots = 8;
   if (nslots > ((ntiles + 7) & ~7)) nslots = (ntiles + 7) & ~7;
   const int grid = nslots * ngroups;

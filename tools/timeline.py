@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Concurrency / phase breakdown of one bench step from a rocprofv3 kernel trace (rocpd sqlite db or kernel_trace.csv).
-usage: timeline.py results.db [step_index_from_end]"""
+usage: timeline.py results.db [step_index_from_end] [--list]   (--list: every kernel of the step: start offset, duration, queue)"""
 import csv
 import sqlite3
 import sys
@@ -19,6 +19,9 @@ def load(path):
 
 
 def main():
+    want_list = "--list" in sys.argv
+    if want_list:
+        sys.argv.remove("--list")
     rows = sorted(load(sys.argv[1]), key=lambda r: r[1])
     # a step ends with k_dual_step; take the window between the last two (or chosen) occurrences
     marks = [i for i, r in enumerate(rows) if r[0].startswith("k_dual_step")]
@@ -76,6 +79,11 @@ def main():
         cur += d
     gaps.sort(reverse=True)
     print("largest idle gaps (us @ ms):", [(round(g / 1e3, 1), round(at, 2)) for g, at in gaps[:8]])
+    if want_list:
+        qs = {q: i for i, q in enumerate(sorted(byq))}
+        print("start_us dur_us queue kernel")
+        for n, s, e, q, st in step:
+            print("%9.1f %7.1f  q%d %s%s" % ((s - t0) / 1e3, (e - s) / 1e3, qs[q], "    " * qs[q], n[:70]))
 
 
 if __name__ == "__main__":

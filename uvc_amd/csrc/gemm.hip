@@ -3427,6 +3427,8 @@ static int tn_splits(int M, int N1, int N2, int cfg) {
     // stream gets the CUs this HBM-bound GEMM does not need.  Measured in the step, same box (profiles/r5t): 256 / 192 / 128 / 96 / 64 workgroups
     // 11.58 / 11.44 / 11.38 / 11.64 / 12.31 ms (the stand-alone sum RISES, 11.2 -> 11.9 ms: these GEMMs are slower alone on half the chip).
     // The wider models keep the whole chip: DeiT-Small 15.6 -> 16.7 ms and DeiT-Base 23.4 -> 24.5 at 128 (192: +- 0 / -0.7 %), T2T-ViT-14 +0.7 %.
+    // Measured again once the side stream had become the backward's critical path (one event per block, vit_engine.hip): 128 / 160 / 192 / 256 workgroups
+    // 11.14 / 11.18 / 11.23 / 11.44 ms (profiles/r5z_ab_wgrad_targets.txt).
     target = tiles <= 4 ? 128 : 256;
   }
   int splits = cfg == 0 ? ceil_div(target, tiles) : target / tiles;       // big tiles: one workgroup per CU (LDS), so at most 256 of them -- one more is a second round

@@ -67,7 +67,11 @@ struct Work {
   void* gA; void* gB;      // dL/dx streams of the backward: T (bf16 in the throughput mode: every consumer is a bf16 GEMM
                            // operand or a LayerNorm backward that accumulates in float32), float32 in the exact mode
   void* dA; void* dH; void* dqkv; float* delta; float* ln_partial; int64_t ln_region; float* cs_partial;
+  // every block has its OWN copies of the streams its weight gradients read (gAs[l]: dL/dx_l, written by block l; gAs[L]: the top), so the main stream never
+  // overwrites what the side stream may still be reading and needs no event wait inside a backward call; gA / gB / dA / dqkv above point at the current block's
+  void* gAs[UVC_VIT_MAX_DEPTH + 1]; void* gBs[UVC_VIT_MAX_DEPTH]; void* dAs[UVC_VIT_MAX_DEPTH]; void* dqkvs[UVC_VIT_MAX_DEPTH];
   void* tn_ws; int64_t tn_ws_bytes; float* dotsraw; void* dhc; void* dpe;
+  void* tn_ws_main;        // split-M partials of the weight gradients that run on the MAIN stream beside the side stream's (tn_ws_bytes too)
 };
 
 int64_t max_tn_ws(const Dims& d) {
@@ -106,8 +110,10 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
   w.hc = c.take((int64_t)d.B * d.ntok * d.D * d.tsz);
   w.meanf = (float*)c.take((int64_t)d.B * d.ntok * 4); w.rstdf = (float*)c.take((int64_t)d.B * d.ntok * 4);
   if (training) {
-    w.gA = c.take(MD * d.tsz); w.gB = c.take(MD * d.tsz);
-    w.dA = c.take(MF * d.tsz); w.dH = c.take(MD * d.tsz); w.dqkv = c.take(3 * MD * d.tsz);
+    for (int l = 0; l <= d.L; ++l) w.gAs[l] = c.take(MD * d.tsz);
+    for (int l = 0; l < d.L; ++l) { w.gBs[l] = c.take(MD * d.tsz); w.dAs[l] = c.take(MF * d.tsz); w.dqkvs[l] = c.take(3 * MD * d.tsz); }
+    w.gA = w.gAs[d.L]; w.gB = w.gBs[0]; w.dA = w.dAs[0]; w.dqkv = w.dqkvs[0];
+    w.dH = c.take(MD * d.tsz);
     w.delta = (float*)c.take((int64_t)d.B * d.H * d.N * 4);
     // one private region of per-block dgamma/dbeta/dots partials per LayerNorm-backward call of a pass (2 per block + final norm):
     // the calls leave their partials there and ONE batched launch per backward call finishes them (49 tiny launches less per step)
@@ -123,6 +129,7 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
     w.cs_partial = (float*)c.take((int64_t)uvc_colsum_blocks(d.M) * (maxN > d.NC ? maxN : d.NC) * 4);
     w.tn_ws_bytes = max_tn_ws(d);
     w.tn_ws = c.take(w.tn_ws_bytes);
+    w.tn_ws_main = c.take(w.tn_ws_bytes);
     w.dotsraw = (float*)c.take((int64_t)(d.L + 1) * 2 * 4);
     w.dhc = c.take((int64_t)d.B * d.ntok * d.D * d.tsz);
     w.dpe = c.take((int64_t)d.B * d.np * d.D * d.tsz);
@@ -145,32 +152,41 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
 struct Ctx {
   const uvc_vit_cfg* cfg; Dims d; uvc_vit_offsets off; uvc_vit_shadow_offsets soff; const uvc_vit_io* io; void* st; Work w;
   void* side;            // optional second stream for the weight-gradient GEMMs (backward)
-  bool done_set[5];      // ev_done[k] recorded in this call
+  struct PendingTn { const void* A; int a_f32; const void* B; float* C; float* bias_grad; int M, N1, N2; const float* alpha_ptr; int lda, ldb; bool scratch; };
+  PendingTn pend[8]; int n_pend = 0;      // weight gradients of the block in progress: launched together on the side stream behind ONE event (flush_tn)
+  bool tn_inline = false;                 // the next weight gradients run on the main stream, in order (the call's last block, see uvc_vit_backward)
   uvc_ln_reduce_item ln_items[64]; int n_ln = 0;   // LayerNorm-backward calls of this pass whose reductions are still pending
 };
 
 // Events for the two-stream backward.  Created once per process (host objects, no device memory).
-hipEvent_t g_ev_raw = nullptr, g_ev_join = nullptr, g_ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+// What an event costs the MAIN stream (tools/probe/event_cost_probe.py, profiles/r5z): a record between two of its kernels 10.6 us, a wait for another stream's
+// event 18.5 us more -- packets the command processor handles between the kernels.  Rounds 2-5 recorded one event per weight gradient and waited before every
+// buffer a weight gradient might still be reading (4 + 4 per block: 50 us of gaps per block in the step's timeline, profiles/r5w_timeline.txt).  Now: the block's
+// four weight gradients are launched together behind ONE record at the block's end, and nothing is waited for (per-block buffers, Work::gAs) until the call's end.
+hipEvent_t g_ev_raw = nullptr, g_ev_join = nullptr;
 int ensure_events() {
   if (g_ev_raw) return UVC_OK;
   hipError_t e = hipEventCreateWithFlags(&g_ev_raw, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming);
-  for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&g_ev_done[i], hipEventDisableTiming);
   if (e != hipSuccess) { g_ev_raw = nullptr; return uvc_set_error(e, __FILE__, __LINE__); }
   return UVC_OK;
 }
-// buffers the side-stream wgrads read and the main stream later overwrites
-enum { BUF_GA = 0, BUF_DA = 1, BUF_GB = 2, BUF_DQKV = 3, BUF_OTHER = 4 };
-// main stream is about to overwrite buffer k: wait for the side-stream reader launched earlier in this call
-int guard_overwrite(Ctx& c, int k) {
-  if (c.side && c.done_set[k]) {
-    hipError_t e = hipStreamWaitEvent((hipStream_t)c.st, g_ev_done[k], 0);
-    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-  }
+int launch_tn(Ctx& c, const Ctx::PendingTn& t, void* stream);
+// the weight gradients collected since the last flush go to the side stream, behind everything the main stream has enqueued so far
+int flush_tn(Ctx& c) {
+  if (!c.side || c.n_pend == 0) return UVC_OK;
+  hipError_t e = hipEventRecord(g_ev_raw, (hipStream_t)c.st);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)c.side, g_ev_raw, 0);
+  if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
+  // (the four split-M reductions of a block as ONE launch behind the four GEMMs -- built, bit-identical, 11.31 against 11.30 ms in the step: not kept,
+  //  tools/probe/tn_batched_reduce.diff.txt, profiles/r5z)
+  for (int i = 0; i < c.n_pend; ++i) { if (int r = launch_tn(c, c.pend[i], c.side)) return r; }
+  c.n_pend = 0;
   return UVC_OK;
 }
 int join_side(Ctx& c) {
   if (!c.side) return UVC_OK;
+  if (int r = flush_tn(c)) return r;
   hipError_t e = hipEventRecord(g_ev_join, (hipStream_t)c.side);
   if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)c.st, g_ev_join, 0);
   if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
@@ -196,29 +212,23 @@ int nt(const Ctx& c, const void* A, int a_f32, const void* B, void* C, int c_f32
   a.force_generic = ln ? 0 : c.io->force_generic;      // (a producer that also writes the next LayerNorm exists in one form only)
   return uvc_gemm_nt(&a, c.st);
 }
-// weight gradient + (same pass over A) bias gradient.  With a side stream the launch goes there: it waits for
-// everything the main stream has enqueued so far (its operands) and records ev_done[buf] for the overwrite guard.
-int tn(Ctx& c, const void* A, int a_f32, const void* B, float* C, float* bias_grad, int M, int N1, int N2, const float* alpha_ptr = nullptr,
-       int lda = 0, int ldb = 0, int buf = BUF_OTHER, bool scratch = false) {
-  void* stream = c.st;
-  if (c.side) {
-    hipError_t e = hipEventRecord(g_ev_raw, (hipStream_t)c.st);
-    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)c.side, g_ev_raw, 0);
-    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-    stream = c.side;
-  }
+// weight gradient + (same pass over A) bias gradient.  With a side stream the launch is deferred to the next flush_tn (the block's end): its operands live in
+// the block's own buffers until the call's end.
+int launch_tn(Ctx& c, const Ctx::PendingTn& t, void* stream) {
   uvc_gemm_tn_args a;
   memset(&a, 0, sizeof(a));
-  a.colsum_out = bias_grad;
-  a.A = A; a.B = B; a.C = C; a.workspace = c.w.tn_ws; a.workspace_bytes = c.w.tn_ws_bytes; a.alpha_ptr = alpha_ptr; a.alpha = 1.0f;
-  a.beta = scratch ? 0.f : c.io->accumulate; a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda ? lda : N1; a.ldb = ldb ? ldb : N2; a.ldc = N2;
-  a.dtype = c.d.dtype; a.a_is_f32 = a_f32 || c.d.dtype == UVC_F32;
-  if (int e = uvc_gemm_tn(&a, stream)) return e;
-  if (c.side) {
-    hipError_t e = hipEventRecord(g_ev_done[buf], (hipStream_t)c.side);
-    if (e != hipSuccess) return uvc_set_error(e, __FILE__, __LINE__);
-    c.done_set[buf] = true;
-  }
+  a.colsum_out = t.bias_grad;
+  a.A = t.A; a.B = t.B; a.C = t.C; a.workspace = (c.side && stream == c.st) ? c.w.tn_ws_main : c.w.tn_ws; a.workspace_bytes = c.w.tn_ws_bytes; a.alpha_ptr = t.alpha_ptr; a.alpha = 1.0f;
+  a.beta = t.scratch ? 0.f : c.io->accumulate; a.M = t.M; a.N1 = t.N1; a.N2 = t.N2; a.lda = t.lda ? t.lda : t.N1; a.ldb = t.ldb ? t.ldb : t.N2; a.ldc = t.N2;
+  a.dtype = c.d.dtype; a.a_is_f32 = t.a_f32 || c.d.dtype == UVC_F32;
+  return uvc_gemm_tn(&a, stream);
+}
+int tn(Ctx& c, const void* A, int a_f32, const void* B, float* C, float* bias_grad, int M, int N1, int N2, const float* alpha_ptr = nullptr,
+       int lda = 0, int ldb = 0, bool scratch = false) {
+  const Ctx::PendingTn t = {A, a_f32, B, C, bias_grad, M, N1, N2, alpha_ptr, lda, ldb, scratch};
+  if (!c.side || c.tn_inline) return launch_tn(c, t, c.st);
+  if (c.n_pend == 8) { if (int r = flush_tn(c)) return r; }
+  c.pend[c.n_pend++] = t;
   return UVC_OK;
 }
 int csum(const Ctx& c, const void* X, int x_f32, float* out, int M, int N, const float* alpha_ptr = nullptr, int ldx = 0) {
@@ -310,7 +320,7 @@ int setup(Ctx& c, const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream, bo
   if (!io->shadow) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: shadow buffer (W^T copies) missing");
   c.cfg = cfg; c.io = io; c.st = stream; c.d = dims_of(*cfg, io->batch);
   c.side = bwd ? io->side_stream : nullptr;
-  for (int i = 0; i < 5; ++i) c.done_set[i] = false;
+  c.n_pend = 0; c.tn_inline = false;
   if (c.side) TRY(ensure_events());
   TRY(uvc_vit_layout(cfg, &c.off, &c.soff));
   const int64_t need = carve(c.d, bwd ? 1 : io->training, (char*)io->workspace, c.w);
@@ -603,6 +613,15 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   if (sb < 0 || se > d.L + 3 || sb >= se) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit_backward: bad stage range");
   const int tl = tail_block(c);
   const TailBufs& t = w.tail;
+  // dL/dx_k lives in gAs[k] (written by block k; gAs[L]: the final norm's): block l reads the one of the nearest block above it that ran
+  auto runs = [&](int l) { return io->gate_d || !io->run_block || io->run_block[l]; };
+  auto g_in = [&](int l) { int k = l + 1; while (k < d.L && !runs(k)) ++k; return w.gAs[k]; };
+  w.gA = w.gAs[d.L];
+  // The side stream runs a block behind (a block's weight gradients start when the block is through), so the LAST block's would run after the main stream has
+  // finished, alone (370 us of the step's timeline, profiles/r5z_timeline.txt): the two MLP weight gradients of that block run on the main stream instead, in
+  // order behind their operands' producers (their own split-M workspace), beside the side stream's work on the block before.
+  int last_l = -1;
+  for (int l = 0; l < d.L; ++l) { const int stage = d.L - l; if (stage >= sb && stage < se && runs(l)) { last_l = l; break; } }
   if (sb == 0) {
   // heads: dhc = dlogits . W ; dW = dlogits^T . hc ; db = colsum(dlogits)
   TRY(nt(c, io->d_logits, 1, sh(c, so.head_wt), w.dhc, 0, d.B, d.D, d.NC, UVC_EPI_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
@@ -635,42 +654,43 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     // streams up to the attention are the compact ones, with the same kernels at rows = B * ntok.
     const bool tail = l == tl;
     const int rows = tail ? d.B * d.ntok : d.M;
-    void* gA = tail ? t.gAc : w.gA; void* gB = tail ? t.gBc : w.gB; void* dA = tail ? t.dAc : w.dA; void* dH = tail ? t.dHc : w.dH;
+    void* const gA_in = g_in(l);                                       // dL/d(this block's output); w.gA: where this block leaves dL/dx_l
+    w.gA = w.gAs[l]; w.gB = w.gBs[l]; w.dA = w.dAs[l]; w.dqkv = w.dqkvs[l];
+    void* gA = tail ? t.gAc : gA_in; void* gB = tail ? t.gBc : w.gB; void* dA = tail ? t.dAc : w.dA; void* dH = tail ? t.dHc : w.dH;
     const void* fa = tail ? t.ac : b.a; const void* fu = tail ? t.uc : b.u; const void* fh2 = tail ? t.h2c : b.h2;
     const void* fx1 = tail ? t.x1c : b.x1; const float* fm2 = tail ? t.mean2c : b.mean2; const float* fr2 = tail ? t.rstd2c : b.rstd2;
-    const int bGA = tail ? BUF_OTHER : BUF_GA, bDA = tail ? BUF_OTHER : BUF_DA, bGB = tail ? BUF_OTHER : BUF_GB;
     const uvc_mlp_compact* mc = (io->mlp_compact && io->mlp_compact[l].width > 0 && io->mlp_compact[l].width < d.F) ? &io->mlp_compact[l] : nullptr;
     const bool fuse2 = !mc && !tail && lnb_fused_ok(c, d.F);
-    if (!tail) TRY(guard_overwrite(c, BUF_DA));
+    c.tn_inline = c.side && l == last_l && !mc;
     if (!mc) {
       TRY(nt(c, gA, gf, sh(c, so.blk_wt[l][3]), dA, 0, rows, d.F, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, fa, nullptr, nullptr, g1));
-      TRY(tn(c, gA, gf, fu, G + q[10], G + q[11], rows, d.D, d.F, g1, 0, 0, bGA));
+      TRY(tn(c, gA, gf, fu, G + q[10], G + q[11], rows, d.D, d.F, g1));
       if (!fuse2) TRY(nt(c, dA, 0, sh(c, so.blk_wt[l][2]), dH, 0, rows, d.D, d.F, UVC_EPI_NONE));
-      TRY(tn(c, dA, 0, fh2, G + q[8], G + q[9], rows, d.F, d.D, nullptr, 0, 0, bDA));
+      TRY(tn(c, dA, 0, fh2, G + q[8], G + q[9], rows, d.F, d.D));
     } else {
       const int Fe = mc->width;
       if (io->accumulate != 0.f) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit_backward: gradient accumulation with MLP compaction");
       TRY(nt(c, gA, gf, mc->w2t, dA, 0, rows, Fe, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, fa, nullptr, nullptr, g1));
-      TRY(tn(c, gA, gf, fu, mc->dw2, G + q[11], rows, d.D, Fe, g1, 0, 0, bGA, true));     // db2 goes straight to its place
+      TRY(tn(c, gA, gf, fu, mc->dw2, G + q[11], rows, d.D, Fe, g1, 0, 0, true));     // db2 goes straight to its place
       TRY(nt(c, dA, 0, mc->w1t, dH, 0, rows, d.D, Fe, UVC_EPI_NONE));
-      TRY(tn(c, dA, 0, fh2, mc->dw1, mc->db1, rows, Fe, d.D, nullptr, 0, 0, bDA, true));
+      TRY(tn(c, dA, 0, fh2, mc->dw1, mc->db1, rows, Fe, d.D, nullptr, 0, 0, true));
+      TRY(flush_tn(c));                       // (the two compact gradients must be on the side stream before their expansion)
       // expand into the full gradient tensors on the stream the wgrads ran on (rank-1 columns for the pruned units)
       TRY(uvc_mlp_scatter_grads(mc->dw1, mc->dw2, mc->db1, mc->inv, P + q[9], G + q[11], d.D, d.F, Fe, G + q[8], G + q[10], G + q[9], 0.f, d.dtype,
                                 c.side ? c.side : c.st));
     }
-    if (!tail) TRY(guard_overwrite(c, BUF_GB));
+    c.tn_inline = false;
     if (fuse2)      // gB = dL/dx1 = LN2'(dA . W1) + d1*gA, the dgrad of fc1 consumed in its epilogue
-      TRY(dgrad_ln_bwd(c, w.dA, sh(c, so.blk_wt[l][2]), d.F, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, w.gA, g1, nullptr, nullptr, nullptr));
+      TRY(dgrad_ln_bwd(c, w.dA, sh(c, so.blk_wt[l][2]), d.F, b.x1, q[6], q[7], b.mean2, b.rstd2, w.gB, gA_in, g1, nullptr, nullptr, nullptr));
     else
     TRY(ln_bwd(c, dH, fx1, q[6], q[7], fm2, fr2, gB, gA, g1, nullptr, nullptr, nullptr, rows, 1, d.D));   // gB = dL/dx1
     // attention
     TRY(nt(c, gB, gf, sh(c, so.blk_wt[l][1]), tail ? t.dOc : w.dH, 0, rows, d.D, d.D, UVC_EPI_NONE));                          // dO
-    TRY(tn(c, gB, gf, tail ? t.oc : b.o, G + q[4], G + q[5], rows, d.D, d.D, nullptr, 0, 0, bGB));
-    TRY(guard_overwrite(c, BUF_DQKV));
+    // (dW_proj on the main stream in every / every second / every third block, to even the two streams out: 11.47 / 11.48 / 11.42 against 11.38 ms, profiles/r5z)
+    TRY(tn(c, gB, gf, tail ? t.oc : b.o, G + q[4], G + q[5], rows, d.D, d.D));
     if (tail) {
       TRY(attn_tok(c, b, true, l));         // writes all of dqkv: dq is zero off the token rows, dk / dv are dense
       // the full-row stream of dL/dx1 that the LayerNorm1 backward adds: zero but for the token rows
-      TRY(guard_overwrite(c, BUF_GB));
       const hipError_t he = hipMemsetAsync(w.gB, 0, (size_t)d.M * d.D * d.tsz, hs);
       if (he != hipSuccess) return uvc_set_error(he, __FILE__, __LINE__);
       TRY(scatter_tok(c, t.gBc, w.gB, d.tsz));
@@ -678,15 +698,18 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     TRY(attn(c, b, true, l));
     const bool fuse1 = lnb_fused_ok(c, 3 * d.D);
     if (!fuse1) TRY(nt(c, w.dqkv, 0, sh(c, so.blk_wt[l][0]), w.dH, 0, d.M, d.D, 3 * d.D, UVC_EPI_NONE));
-    TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], d.qkv_bias ? G + q[3] : nullptr, d.M, 3 * d.D, d.D, nullptr, 0, 0, BUF_DQKV));
-    // gA <- dL/dx_l = LN1'(dH) + gB + d0*gA ; dots: <new gA, x_l>, <old gA, x_l>
-    TRY(guard_overwrite(c, BUF_GA));
+    TRY(tn(c, w.dqkv, 0, b.h1, G + q[2], d.qkv_bias ? G + q[3] : nullptr, d.M, 3 * d.D, d.D));
+    // gA (this block's) <- dL/dx_l = LN1'(dH) + gB + d0 * (dL/d output) ; dots: <new gA, x_l>, <old gA, x_l>
+    // (a `tail` block's full-row output gradient is zero off its token rows, which is what its compact stream gAc holds: the d0 term reads the full-row
+    //  stream the final norm's backward left in gAs[L])
     if (fuse1)
-      TRY(dgrad_ln_bwd(c, w.dqkv, sh(c, so.blk_wt[l][0]), 3 * d.D, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0,
+      TRY(dgrad_ln_bwd(c, w.dqkv, sh(c, so.blk_wt[l][0]), 3 * d.D, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? gA_in : nullptr, g0,
                        w.dotsraw + 2 * l));
     else
-    TRY(ln_bwd(c, w.dH, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? w.gA : nullptr, g0, w.dotsraw + 2 * l, d.M, 1, d.D));
+    TRY(ln_bwd(c, w.dH, b.x, q[0], q[1], b.mean1, b.rstd1, w.gA, w.gB, nullptr, io->gate_d ? gA_in : nullptr, g0, w.dotsraw + 2 * l, d.M, 1, d.D));
+    TRY(flush_tn(c));                        // this block's four weight gradients (and, behind the first block, the heads'): one event
   }
+  w.gA = g_in(-1);                           // dL/dx_0: the lowest block that ran left it
   if (sb <= d.L + 1 && se > d.L + 1) {
     // gate logits (block_skip_gating) gradient
     TRY(flush_ln(c));                          // the gate gradient reads the dot products of the blocks' LayerNorm backwards

@@ -621,8 +621,11 @@ constexpr int CT_T = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void k_cast_transpose_multi(const float* __restrict__ base, T* __restrict__ sh, CtTable t) {
   __shared__ float tile[CT_T][CT_T + 1];
-  int m = 0;
-  while (m + 1 < t.n && (int)blockIdx.x >= t.tile0[m + 1]) ++m;
+  // which matrix this tile belongs to: lane l compares against tile0[l + 1] (n <= 64: one wave-wide compare + ballot instead of a chain of up to 64 dependent
+  // scalar loads from the 2.4-KB argument table -- r5: the launch took 61 us for 44 MB, almost all of it this loop)
+  const int lane = threadIdx.x & 63;
+  const unsigned long long ge = __ballot(lane + 1 < t.n && (int)blockIdx.x >= t.tile0[lane + 1 < 65 ? lane + 1 : 64]);
+  const int m = __popcll(ge);
   const int R = t.R[m], C = t.C[m];
   const int lt = blockIdx.x - t.tile0[m], tc = (C + CT_T - 1) / CT_T;
   const int r0 = (lt / tc) * CT_T, c0 = (lt % tc) * CT_T;

@@ -59,6 +59,7 @@ def parse():
     p.add_argument("--stage", type=int, default=1, choices=[1, 2],
                    help="1 = the headline Stage-1 UVC-train step; 2 = the Stage-2 masked fine-tune step (SURVEY §8 f-1)")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_next_batch", action="store_true", help="A/B: do not hand the next batch to Stage1Trainer.step (its teacher forward then starts with the step)")
     p.add_argument("--phase", default="train", choices=["train", "warmup"],
                    help="stage 1: 'train' = the UVC-train step the metric is quoted on; 'warmup' = the warm-up-phase step (gates fixed at .5/.5, "
                         "gate logits frozen, lr = warmup_lr), reported for reference (SURVEY 8d)")
@@ -346,8 +347,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # next_x: the trainer starts the NEXT step's teacher forward behind this step's backward (under the optimizer / UVC tail) when the caller already holds the
+    # next batch, as a prefetching loader does (Stage1Trainer.step; uvc_amd.cli reads one batch ahead).  The last timed step promises nothing, so the K timed
+    # steps contain exactly K teacher forwards: the first one's was started by the last warm-up step, the others' inside the region.
+    nx = dict(next_x=x) if args.stage == 1 and not args.no_next_batch else {}
     for _ in range(args.warmup):
-        tr.step(x, y)
+        tr.step(x, y, **nx)
     sync()
     # K timed steps between two barrier + synchronize points (the contract's wall clock); an event at every step boundary on the
     # launch stream gives the per-step device times (median / p10 / p90) without a host sync inside the timed region
@@ -358,7 +363,7 @@ def main():
     host = []
     for i in range(args.steps):
         h0 = time.perf_counter()
-        out = tr.step(x, y)
+        out = tr.step(x, y, **(nx if i + 1 < args.steps else {}))
         evs[i + 1].record(st)
         host.append(time.perf_counter() - h0)
     t_enq = time.perf_counter() - t0                 # the host has enqueued everything; the GPU is still running if the host runs ahead

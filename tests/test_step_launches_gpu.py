@@ -59,3 +59,42 @@ def test_loss_backward_with_and_without_the_unit_gradient_agree():
         grads.append(oo.grad.clone())
     assert torch.equal(grads[0], grads[1])
     torch.testing.assert_close(grads[2], grads[0] * 0.5, rtol=1e-6, atol=0)
+
+
+def test_step_with_the_next_batch_starts_its_teacher_forward_early_and_changes_nothing():
+    """Stage1Trainer.step(x, y, next_x=...) starts the frozen teacher's forward for the NEXT batch behind this step's backward (it runs under the optimizer / UVC
+    tail); the next step picks it up only for that very tensor.  Same losses, same weights, bit for bit, as steps without it -- also when the promise is broken
+    (another tensor arrives) -- and exactly one teacher forward per step (the pending one is consumed)."""
+    import bench
+    from uvc_amd.stage1 import Stage1Trainer, default_args
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    xs = [torch.randn(8, 3, 224, 224, device="cuda", generator=g) for _ in range(4)]
+    ys = [torch.softmax(torch.randn(8, 1000, device="cuda", generator=g), -1) for _ in range(4)]
+
+    def run(mode):
+        torch.manual_seed(0)                                            # (the trainer draws its initial weights from torch's generator)
+        a = default_args(model_type="deit_tiny_patch16_224", precision="bf16", train_batch_size=8, local_rank=0)
+        tr = Stage1Trainer(a, device="cuda:0", distributed=False)
+        bench.pruned_state(tr)
+        tr.begin_epoch(a.warmup_epochs + 1)
+        calls = [0]
+        fwd = tr.criterion.teacher_model.forward
+        tr.criterion.teacher_model.forward = lambda *aa, **kk: (calls.__setitem__(0, calls[0] + 1), fwd(*aa, **kk))[1]
+        losses = []
+        if mode == "lookahead":
+            for (x, y), nx in tr.lookahead(zip(xs, ys)):
+                losses.append(tr.step(x, y, next_x=nx)["loss"].clone())
+        else:
+            for i, (x, y) in enumerate(zip(xs, ys)):
+                nx = None if mode == "plain" else xs[0]                 # "broken": always promises batch 0
+                losses.append(tr.step(x, y, next_x=nx)["loss"].clone())
+        torch.cuda.synchronize()
+        return torch.stack(losses), tr.model._flat.clone(), calls[0], tr.criterion._pref
+
+    l0, w0, c0, p0 = run("plain")
+    l1, w1, c1, p1 = run("lookahead")
+    l2, w2, c2, p2 = run("broken")
+    assert torch.equal(l0, l1) and torch.equal(w0, w1) and torch.equal(l0, l2) and torch.equal(w0, w2)
+    assert c0 == 4 and c1 == 4 and p0 is None and p1 is None
+    assert c2 == 8 and p2 is not None                                   # every promise missed: 4 forwards wasted, results untouched

@@ -41,7 +41,7 @@ a.overlap_teacher = 0
 
 
 def student_only():
-    crit._pref = (x.data_ptr(), x._version, tout, ev)
+    crit._pref = (x.data_ptr(), x._version, tout, ev, tuple(x.shape))
     return tr.step(x, y)
 
 

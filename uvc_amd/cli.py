@@ -180,8 +180,8 @@ def main(argv=None):
             print(f"Start [Epoch {epoch}] at Stage {stage}")
             print(f"[Initial Sparsity|Epoch {epoch}] Parameter size: {remained:.2f}M / {float(args.total_param):.2f}M = {remained / float(args.total_param) * 100:.2f}%")
         t0 = time.time()
-        for step, (x, y) in enumerate(iterate_batches(args, device, rank, mixup_fn, epoch)):
-            out = tr.step(x, y)
+        for step, ((x, y), next_x) in enumerate(tr.lookahead(iterate_batches(args, device, rank, mixup_fn, epoch))):
+            out = tr.step(x, y, next_x=next_x)
             if not out["stepped"]:                      # gradient accumulation: not an optimiser step yet (:417)
                 continue
             gs = tr.global_step

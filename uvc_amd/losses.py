@@ -88,11 +88,16 @@ class DistillationLoss(torch.nn.Module):
             out, _ = self.teacher_model(inputs)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        self._pref = (inputs.data_ptr(), inputs._version, out, ev)
+        self._pref = (inputs.data_ptr(), inputs._version, out, ev, tuple(inputs.shape))
+
+    def has_prefetch(self, inputs):
+        """True when ``prefetch`` has already started the teacher forward for exactly this tensor (same storage, same version)."""
+        p = self._pref
+        return p is not None and p[0] == inputs.data_ptr() and p[1] == inputs._version and p[4] == tuple(inputs.shape)
 
     def _teacher(self, inputs):
         p, self._pref = self._pref, None
-        if p is not None and p[0] == inputs.data_ptr() and p[1] == inputs._version:
+        if p is not None and p[0] == inputs.data_ptr() and p[1] == inputs._version and p[4] == tuple(inputs.shape):
             torch.cuda.current_stream().wait_event(p[3])
             p[2].record_stream(torch.cuda.current_stream())
             return p[2]

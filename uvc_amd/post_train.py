@@ -122,18 +122,21 @@ class Stage2Trainer:
         self.model.block_skip_gating.requires_grad = False
         self.scheduler.step(epoch)
 
-    def step(self, x, y, zero_grad=True):
+    def step(self, x, y, zero_grad=True, next_x=None):
         """post_train.py:341-377 after the odd-batch trim and mixup: mask, forward (hard block skip), loss, backward,
-        clip, AdamW."""
+        clip, AdamW.  ``next_x``: as Stage1Trainer.step."""
         a = self.args
         self.model.apply_masks()                                                                    # :343-346
-        if getattr(a, "overlap_teacher", 1):
+        overlap = bool(getattr(a, "overlap_teacher", 1))
+        if overlap and not self.criterion.has_prefetch(x):
             self.criterion.prefetch(x)
         outputs, _ = self.model(x)                                                                  # :363
         loss = self.criterion(x, outputs, y)
         if self.accum > 1:
             loss = loss / self.accum                                                                # :365-366
         loss.backward(unit_gradient(loss.device))
+        if overlap and next_x is not None:
+            self.criterion.prefetch(next_x)
         self._micro += 1
         if self._micro % self.accum != 0:                                                           # :372: the backward added into .grad
             return dict(loss=loss.detach() * self.accum, outputs=outputs, stepped=False)

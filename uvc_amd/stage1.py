@@ -184,18 +184,25 @@ class Stage1Trainer:
     # -- one loader iteration (joint_train.py:395-450), x / y already mixed.  With --gradient_accumulation_steps k only every
     # k-th call is an optimiser step (:417-426): the others return after the backward, which ADDS into the flat gradient
     # buffer (model.grad_accumulate), and their result carries `stepped=False`.
-    def step(self, x, y, tau=None, zero_grad=True):
+    def step(self, x, y, tau=None, zero_grad=True, next_x=None):
+        """One training step on the batch (x, y).  ``next_x`` (optional): the NEXT step's input batch, if the caller already holds it (a prefetching loader does;
+        ``lookahead`` below wraps one): the frozen teacher's forward for it is started on the side stream as soon as this step's backward is enqueued, so it runs
+        under the optimizer / UVC tail of small launches, where the chip is otherwise nearly idle, instead of in front of the next step's student forward (the two
+        forwards are whole-chip kernels that alternate).  Results do not depend on it: the next step picks the forward up only for that very tensor."""
         a = self.args
         if self._micro % self.accum == 0:
             self.noise.begin_step(self.global_step, resume_window=getattr(self, "_window_carried", False))
             self._window_carried = False
-        if getattr(a, "overlap_teacher", 1):
+        overlap = bool(getattr(a, "overlap_teacher", 1))
+        if overlap and not self.criterion.has_prefetch(x):
             self.criterion.prefetch(x)              # teacher forward on a side stream, under the student forward
         outputs, _ = self.model(x, self.get_tau() if tau is None else tau, a.patch_ratio)
         loss = self.criterion(x, outputs, y)
         if self.accum > 1:
             loss = loss / self.accum                                                                # :413-414
         loss.backward(unit_gradient(loss.device))       # d(loss) = 1 without a ones_like fill or a multiply by it (losses.unit_gradient)
+        if overlap and next_x is not None:
+            self.criterion.prefetch(next_x)
         self._micro += 1
         if self._micro % self.accum != 0:                                                           # :417
             return dict(loss=loss.detach() * self.accum, outputs=outputs, stepped=False)
@@ -213,6 +220,19 @@ class Stage1Trainer:
             self.optimizer.zero_grad()
         return dict(loss=loss.detach() * self.accum if self.accum > 1 else loss.detach(), outputs=outputs, gnorm=gnorm, cur=cur, s=s, r=r, g=g,
                     stepped=True)
+
+    @staticmethod
+    def lookahead(batches):
+        """(x, y) batches -> ((x, y), next_x or None): what ``step(..., next_x=)`` wants, one batch read ahead."""
+        it = iter(batches)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        for nxt in it:
+            yield cur, nxt[0]
+            cur = nxt
+        yield cur, None
 
     def check_replicas(self):
         """Data-parallel invariant: every rank holds bit-identical parameters and primal / dual state (the reference assumes it and

@@ -688,6 +688,7 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     TRY(nt(c, gB, gf, sh(c, so.blk_wt[l][1]), tail ? t.dOc : w.dH, 0, rows, d.D, d.D, UVC_EPI_NONE));                          // dO
     // (dW_proj on the main stream in every / every second / every third block, to even the two streams out: 11.47 / 11.48 / 11.42 against 11.38 ms, profiles/r5z)
     TRY(tn(c, gB, gf, tail ? t.oc : b.o, G + q[4], G + q[5], rows, d.D, d.D));
+    // (the last block's dW_proj flushed to the idle side stream here, under the attention backward: 11.10 against 11.08 ms -- nothing, profiles/r5zz_ab_early_last_flush.txt)
     if (tail) {
       TRY(attn_tok(c, b, true, l));         // writes all of dqkv: dq is zero off the token rows, dk / dv are dense
       // the full-row stream of dL/dx1 that the LayerNorm1 backward adds: zero but for the token rows

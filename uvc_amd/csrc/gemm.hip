@@ -2997,6 +2997,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_big(TnArgs g) {
 // stages stay in flight across the barrier (hipcc would drain vmcnt(0) at a __syncthreads()).  The LDS destination of a
 // DMA instruction is wave-base + lane*16, so an image is the lane-linear sequence of 16-byte slots [row][chunk] with the two
 // pad slots of every row (conflict-free transpose reads) filled by lanes that re-load chunk 0.
+// (r5: a ring of FIVE stages, 151 KB: dW2 on 128 workgroups 84 us against 78 -- at 19.6 GB/s per CU the kernel is not waiting for a deeper ring; profiles/r5zz)
 constexpr int TD_BM = 32, TD_NST = 4;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

@@ -20,12 +20,16 @@ for M, gated in ((100864, True), (16 * 4133 + 9, False), (100864 + 5, True)):
         nan = float("nan")
         out, nh, h = (torch.full((M, D), nan, device=dev, dtype=bf) for _ in range(3))
         nm, nr, mean, rstd = (torch.full((M,), nan, device=dev) for _ in range(4))
-        gp, u = (torch.full((M, F_), nan, device=dev, dtype=bf) for _ in range(2))
+        BL = bool(os.environ.get("BLOCKED")) and step >= M
+        Mp = (M + 15) // 16 * 16
+        gp, u = (torch.full((Mp, F_), nan, device=dev, dtype=bf) for _ in range(2))
         for lo in range(0, M, step):
             hi = min(M, lo + step)
             ops.mlp_fused_fwd(x[lo:hi], gamma, beta, W1, b1, W2, b2, out[lo:hi], next_gamma=g2, next_beta=b2n, next_h=nh[lo:hi], next_mean=nm[lo:hi], next_rstd=nr[lo:hi],
-                              x_prev=xp[lo:hi] if gated else None, gate=gate, h=h[lo:hi], mean=mean[lo:hi], rstd=rstd[lo:hi], gp=gp[lo:hi], u=u[lo:hi])
-        return out, nh, nm, nr, h, mean, rstd, gp, u
+                              x_prev=xp[lo:hi] if gated else None, gate=gate, h=h[lo:hi], mean=mean[lo:hi], rstd=rstd[lo:hi], gp=gp[lo:hi] if not BL else gp, u=u[lo:hi] if not BL else u, hidden_blocked=BL)
+        if BL:
+            gp, u = ops.hidden_blocked_to_rows(gp, M, F_), ops.hidden_blocked_to_rows(u, M, F_)
+        return out, nh, nm, nr, h, mean, rstd, gp[:M], u[:M]
     whole = run(M)
     if os.environ.get("TIME_ONLY"):
         sliced = whole
@@ -51,7 +55,8 @@ for M, gated in ((100864, True), (16 * 4133 + 9, False), (100864 + 5, True)):
             for _ in range(n): fn()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / n * 1e3
-        tr = lambda: ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, out, next_gamma=g2, next_beta=b2n, next_h=nh, next_mean=nm, next_rstd=nr, x_prev=xp, gate=gate, h=h, mean=mean, rstd=rstd, gp=gp, u=u)
+        gpb, ub = (torch.empty((M + 15) // 16 * 16, F_, device=dev, dtype=bf) for _ in range(2))
+        tr = lambda: ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, out, next_gamma=g2, next_beta=b2n, next_h=nh, next_mean=nm, next_rstd=nr, x_prev=xp, gate=gate, h=h, mean=mean, rstd=rstd, gp=gpb, u=ub, hidden_blocked=bool(os.environ.get("BLOCKED")))
         inf = lambda: ops.mlp_fused_fwd(x, gamma, beta, W1, b1, W2, b2, out, next_gamma=g2, next_beta=b2n, next_h=nh, x_prev=xp, gate=gate)
         print("training form %.1f us, inference form %.1f us" % (t(tr), t(inf)))
         if os.environ.get("TIME_ONLY"):

@@ -409,6 +409,8 @@ def main():
                 # blocks the launching thread on a full queue (a host that runs ahead is throttled to the GPU's pace: a share near 1 with a median far
                 # below ms_per_step means "ran ahead until the queue was full", not "host-bound")
                 "host_enqueue_ms_per_step": round(host_ms, 3), "host_enqueue_loop_share_of_wall": round(t_enq / dt, 3), "host_cores_pinned": pinned,
+                # every timed step runs one teacher forward; with next_x it is the NEXT step's batch, started behind this step's backward (Stage1Trainer.step)
+                "teacher_forward": "next batch's, started behind the backward (K per K timed steps)" if nx else "this batch's, started with the step",
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if args.precision.startswith("bf16") else "f32", "data": "synthetic",
                 "config": {"workload": (f"{args.model_type} Stage-1 UVC-train step, budget {args.budget:g}, per-GPU batch {args.batch}, "

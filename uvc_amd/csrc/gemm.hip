@@ -105,6 +105,11 @@ template <> struct OutVec<bf16_t> {
     r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]); r[2] = pack_bf16x2(v[4], v[5]); r[3] = pack_bf16x2(v[6], v[7]);
     *reinterpret_cast<u32x4*>(p) = r;
   }
+  static __device__ __forceinline__ void st_nt(bf16_t* p, const float* v) {      // streaming output: not read again before the caches have turned over
+    u32x4 r;
+    r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]); r[2] = pack_bf16x2(v[4], v[5]); r[3] = pack_bf16x2(v[6], v[7]);
+    __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(p));
+  }
 };
 template <typename T, int VN> __device__ __forceinline__ void load_vec(const T* p, float* v);
 template <> __device__ __forceinline__ void load_vec<float, 4>(const float* p, float* v) {
@@ -542,13 +547,20 @@ __global__ __launch_bounds__(64 * WS_NW, (KT > 6 && WS_NW > 6) ? 1 : (NJ == 4 ||
 #pragma unroll
           for (int e = 0; e < VN; ++e) { float fo, go; Gelu<T>::fg(v[e], fo, go); u[e] = fo; v[e] = go; }
         }
-        OutVec<TC>::st(C + mo * g.ldc + n, v);
+        // GELU'(a) and GELU(a) of the training forward are STREAMING outputs (310 MB per block, read again in the backward / by fc2 after the caches have
+        // turned over): non-temporal stores.  Alone 90.2 -> 83.1 us; in the step 11.19 -> 10.96 ms (GELU' only: 79.8 us alone, 11.09 in the step) -- the rest of
+        // the step keeps the Infinity Cache (profiles/r5zz_ab_nt_stores.txt)
+        if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD && sizeof(TC) == 2) OutVec<TC>::st_nt(C + mo * g.ldc + n, v);
+        // (also tried, each within +- 0.4 % of the step: non-temporal dA stores of dfc2 x GELU', non-temporal loads of its GELU' operand, nt on the LDS-DMA loads
+        //  of the weight gradients and of the attention backward -- profiles/r5zz_ab_nt_sites.txt)
+        else OutVec<TC>::st(C + mo * g.ldc + n, v);
         if (EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_GRAD) {
           if (EPI == UVC_EPI_BIAS_GELU) {
 #pragma unroll
             for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
           }
-          OutVec<TC>::st(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
+          if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD && sizeof(TC) == 2) OutVec<TC>::st_nt(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
+          else OutVec<TC>::st(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
         }
       }
     }

@@ -263,7 +263,11 @@ __device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, float* stg, in
         for (int e = 0; e < VN; ++e) { float fo, go; Gelu<T>::fg(v[e], fo, go); u[e] = fo; v[e] = go; }
       }
       TC* cp = C + mo * g.ldc + n;
+      // (GELU' / GELU of the training forward: streaming outputs, non-temporal -- DeiT-Base 23.31 -> 23.06 ms, profiles/r5zz_ab_nt_wide.txt)
+      if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD && sizeof(TC) == 2) { if (nfull) OutVec<TC>::st_nt(cp, v); }
+      else
       if (nfull) OutVec<TC>::st(cp, v);
+      if (nfull) {}
       else {
 #pragma unroll
         for (int e = 0; e < VN; ++e) if (n + e < g.N) ElemIO<TC>::store(cp + e, v[e]);
@@ -274,7 +278,10 @@ __device__ __forceinline__ void nt_epilogue_rows(const NtArgs& g, float* stg, in
 #pragma unroll
           for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
         }
+        if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD && sizeof(TC) == 2) { if (nfull) OutVec<TC>::st_nt(c2, u); }
+        else
         if (nfull) OutVec<TC>::st(c2, u);
+        if (nfull) {}
         else {
 #pragma unroll
           for (int e = 0; e < VN; ++e) if (n + e < g.N) ElemIO<TC>::store(c2 + e, u[e]);
@@ -549,18 +556,21 @@ __global__ __launch_bounds__(64 * WS_NW, (KT > 6 && WS_NW > 6) ? 1 : (NJ == 4 ||
         }
         // GELU'(a) and GELU(a) of the training forward are STREAMING outputs (310 MB per block, read again in the backward / by fc2 after the caches have
         // turned over): non-temporal stores.  Alone 90.2 -> 83.1 us; in the step 11.19 -> 10.96 ms (GELU' only: 79.8 us alone, 11.09 in the step) -- the rest of
-        // the step keeps the Infinity Cache (profiles/r5zz_ab_nt_stores.txt)
-        if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD && sizeof(TC) == 2) OutVec<TC>::st_nt(C + mo * g.ldc + n, v);
+        // the step keeps the Infinity Cache (profiles/r5zz_ab_nt_stores.txt).  K = 192 only: at K = 384 (DeiT-Small, T2T-ViT-14) the same stores are within
+        // noise or 0.5 % slower (profiles/r5zz_ab_nt_wide.txt)
+        if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD && sizeof(TC) == 2 && KT == 6) OutVec<TC>::st_nt(C + mo * g.ldc + n, v);
+        else
         // (also tried, each within +- 0.4 % of the step: non-temporal dA stores of dfc2 x GELU', non-temporal loads of its GELU' operand, nt on the LDS-DMA loads
         //  of the weight gradients and of the attention backward -- profiles/r5zz_ab_nt_sites.txt)
-        else OutVec<TC>::st(C + mo * g.ldc + n, v);
+        OutVec<TC>::st(C + mo * g.ldc + n, v);
         if (EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_GRAD) {
           if (EPI == UVC_EPI_BIAS_GELU) {
 #pragma unroll
             for (int e = 0; e < VN; ++e) u[e] = Gelu<T>::f(v[e]);
           }
-          if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD && sizeof(TC) == 2) OutVec<TC>::st_nt(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
-          else OutVec<TC>::st(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
+          if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD && sizeof(TC) == 2 && KT == 6) OutVec<TC>::st_nt(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
+          else
+          OutVec<TC>::st(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
         }
       }
     }

@@ -1634,6 +1634,7 @@ __global__ __launch_bounds__(768) void k_gemm_wsn16_dma(NtArgs g) {
     for (int q = 0; q < NPW; ++q) {
       const char* src = rb[q] + ((unsigned long long)r0 * (unsigned long long)rstride[q] + (unsigned long long)loff[q]);
       char* dst = smem + st * STAGE + rdst[q];
+      // (nt on these loads -- fc2's GELU(a) operand only, or every operand of the kernel: 0.3-0.6 % slower in the step, profiles/r5zz_ab_nt_wsn.txt)
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
     }
   };

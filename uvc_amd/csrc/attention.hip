@@ -729,6 +729,7 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a, int
             u32x4 x = {0u, 0u, 0u, 0u};
             if (!zero) x = *reinterpret_cast<const u32x4*>(stg + m * L::IMG + p * 1024 + lane * 16);
             if (p & 1) x = u32x4{x[2], x[3], x[0], x[1]};
+            // (non-temporal: 10.96 against 10.94 ms -- dqkv is read again at once, profiles/r5zz_ab_nt_dqkv.txt)
             *reinterpret_cast<u32x4*>(dqb + (size_t)m * a.H * HD * 2 + (size_t)i * NH * 8 * ldq * 2 + lq) = x;
           }
         }

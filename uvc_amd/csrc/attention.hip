@@ -1110,6 +1110,8 @@ int launch_one_pass(const AttnArgs& a, int grid_arg, hipStream_t st) {
   // 12.70 ms with 256 workgroups, 12.62 with 232, 11.98 with 224 (the dq + dk/dv pair: 12.20), 12.02 with 200: one free CU in EVERY
   // shader engine (256 CUs = 32 engines x 8) is what the other stream's dispatch needs -- with one engine full it stalls as if all were.
   // DeiT-Small (H = 6) is 2 % faster with the whole chip, DeiT-Base indifferent: the narrow model alone leaves the CUs.
+  // (measured again with one event per block and the weight-gradient stream as the backward's critical path: 256 / 240 / 224 / 208 / 192 / 176 / 160 workgroups
+  //  +0.09 / +0.11 / 0 / +0.06 / +0.18 / +0.19 / +0.23 ms, profiles/r5end_ab_attn_bwd_cus.txt)
   const int ncu_use = a.H <= 3 && ncu >= 64 ? ncu - ncu / 8 : ncu;
   const int grid = grid_arg > 0 ? (grid_arg < nbh ? grid_arg : nbh) : (nbh < ncu_use ? nbh : ncu_use);
   static std::atomic<unsigned> seq{0};

@@ -59,6 +59,7 @@ def parse():
     p.add_argument("--stage", type=int, default=1, choices=[1, 2],
                    help="1 = the headline Stage-1 UVC-train step; 2 = the Stage-2 masked fine-tune step (SURVEY §8 f-1)")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_mode_legs", action="store_true", help="skip the short fp32 / bf16_f32resid legs behind the timed region (--no_cpu_baseline, the A/B scripts' switch, skips them too)")
     p.add_argument("--no_next_batch", action="store_true", help="A/B: do not hand the next batch to Stage1Trainer.step (its teacher forward then starts with the step)")
     p.add_argument("--phase", default="train", choices=["train", "warmup"],
                    help="stage 1: 'train' = the UVC-train step the metric is quoted on; 'warmup' = the warm-up-phase step (gates fixed at .5/.5, "
@@ -134,54 +135,79 @@ def _git_head():
         return None
 
 
-def pmc_traffic(key):
-    """HBM bytes per launch of kernel `key` from the newest PMC pass committed under profiles/ (tools/pmc_traffic.py writes
+def _profile_file(kind, pattern, args=None):
+    """The committed profile file of `kind` that the JSON line may cite.  profiles/MANIFEST.json (written by tools/profiles_manifest.py when a round's
+    profile run is copied into profiles/) NAMES the current file of every kind together with the model / batch it was measured on; without a manifest the
+    newest file by modification time is taken.  (Round 5 picked `sorted(glob)[-1]`: lexicographically r5zz > r5end, so the line cited a superseded pass.)
+    A PMC pass is a measurement of ONE model's kernels: with `args` given, a file measured on another model or batch is not returned (the Tiny
+    pass's mfma_busy_frac appeared in the DeiT-Small / Base / T2T lines, looked up by kernel key)."""
+    import glob
+    man = {}
+    try:
+        man = json.load(open(os.path.join(ROOT, "profiles", "MANIFEST.json")))
+    except Exception:
+        pass
+    ent = man.get(kind)
+    path = None
+    if ent and os.path.exists(os.path.join(ROOT, "profiles", ent["file"])):
+        path = os.path.join(ROOT, "profiles", ent["file"])
+        model, batch = ent.get("model", "deit_tiny_patch16_224"), ent.get("batch", 512)
+    else:
+        files = glob.glob(os.path.join(ROOT, "profiles", pattern))
+        if files:
+            path = max(files, key=os.path.getmtime)
+            model, batch = "deit_tiny_patch16_224", 512          # tools/kernel_table.py's and bench.py's defaults, which every un-manifested pass ran
+    if path is None:
+        return None
+    if args is not None and (model != args.model_type or int(batch) != int(args.batch) or args.enable_deit or args.enable_patch_gating):
+        return None
+    return path
+
+
+def pmc_traffic(key, args=None):
+    """HBM bytes per launch of kernel `key` from the current PMC pass committed under profiles/ (tools/pmc_traffic.py writes
     profiles/<round>_pmc_traffic.json from two rocprofv3 --pmc runs, FETCH_SIZE and WRITE_SIZE, with the guide's gfx950 correction).
-    None when no pass covers the kernel: the number is a measurement, never a constant in this file."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        ent = d.get("kernels", {}).get(key)
-        if ent:
-            best = dict(bytes=int(ent["hbm_bytes"]), source=os.path.basename(f), commit=d.get("commit"))
-    return best
+    None when no pass covers the kernel (or the pass is another model's): the number is a measurement, never a constant in this file."""
+    f = _profile_file("pmc_traffic", "*_pmc_traffic.json", args)
+    if f is None:
+        return None
+    try:
+        d = json.load(open(f))
+    except Exception:
+        return None
+    ent = d.get("kernels", {}).get(key)
+    return dict(bytes=int(ent["hbm_bytes"]), source=os.path.basename(f), commit=d.get("commit")) if ent else None
 
 
-def pmc_mfma():
-    """Matrix-pipe utilisation per kernel key from the newest rocprofv3 SQ pass committed under profiles/ (tools/pmc_mfma.py:
-    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)); {} when no pass is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma.json")))
-    if not files:
+def pmc_mfma(args=None):
+    """Matrix-pipe utilisation per kernel key from the current rocprofv3 SQ pass committed under profiles/ (tools/pmc_mfma.py:
+    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)); {} when no pass of THIS model is committed."""
+    f = _profile_file("pmc_mfma", "*_pmc_mfma.json", args)
+    if f is None:
         return {}, None
     try:
-        d = json.load(open(files[-1]))
+        d = json.load(open(f))
     except Exception:
         return {}, None
-    return d.get("kernels", {}), f"{os.path.basename(files[-1])} @ {d.get('commit')}"
+    return d.get("kernels", {}), f"{os.path.basename(f)} @ {d.get('commit')}"
 
 
-def in_step_top():
-    """Row 1 of the newest committed in-step rocprofv3 table (profiles/*_kernel_stats_uvc_train_steps_only.csv): the kernel with the
+def in_step_top(args=None):
+    """Row 1 of the current committed in-step rocprofv3 table (profiles/*_kernel_stats_uvc_train_steps_only.csv): the kernel with the
     largest summed duration INSIDE the step.  Reported next to `roofline` because the two rankings differ by construction: the step
     runs two or three streams that time-slice one memory system, so in-step durations are inflated by whatever ran beside the
     kernel (k_tn_reduce: ~10 us alone, 64 us beside the dgrad stream) and do not add up to the step time, while the stand-alone
     launch times do (their sum per step equals the measured step time to ~2 %: `kernel_ms_per_step_standalone_sum`)."""
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats_uvc_train_steps_only.csv")))
-    if not files:
+    f = _profile_file("steps_only", "*_kernel_stats_uvc_train_steps_only.csv", args)
+    if f is None:
         return None
-    rows = [r for r in csv.reader(l for l in open(files[-1]) if not l.startswith("#"))]
+    rows = [r for r in csv.reader(l for l in open(f) if not l.startswith("#"))]
     if len(rows) < 2:
         return None
     r = rows[1]
     return {"kernel": r[0], "calls_per_step": float(r[1]), "avg_us_in_step": float(r[2]), "ms_per_step_in_step": float(r[3]),
-            "percent_of_kernel_time": float(r[4]), "source": "profiles/" + os.path.basename(files[-1])}
+            "percent_of_kernel_time": float(r[4]), "source": "profiles/" + os.path.basename(f)}
 
 
 def kernel_table(args):
@@ -203,7 +229,7 @@ def kernel_table(args):
         inten = (r["tflops"] * 1e12) / (r["gbs"] * 1e9) if r["gbs"] else 0.0
         r["bound"] = "mfma" if inten > ridge else "hbm"
         r["frac"] = round((r["tflops"] / PEAK_BF16_TFLOPS) if r["bound"] == "mfma" else (r["gbs"] / PEAK_HBM_GBS), 4)
-    tr = pmc_traffic(top["key"])
+    tr = pmc_traffic(top["key"], args)
     roof = {"bound": top["bound"], "kernel": f"{top['key']} ({top['rocprof']})", "calls_per_step": top["calls"],
             "achieved": top["gbs"] if top["bound"] == "hbm" else top["tflops"], "peak": PEAK_HBM_GBS if top["bound"] == "hbm" else PEAK_BF16_TFLOPS,
             "unit": "GB/s" if top["bound"] == "hbm" else "TFLOP/s", "frac": top["frac"], "traffic": tr["bytes"] if tr else None,
@@ -214,7 +240,7 @@ def kernel_table(args):
         r["frac_of_mix_ceiling"] = round(r["gbs"] / r["hbm_mix_ceiling_gbs"], 4) if r.get("hbm_mix_ceiling_gbs") and r["bound"] == "hbm" else None
     roof["hbm_mix_ceiling"] = top.get("hbm_mix_ceiling_gbs")
     roof["frac_of_mix_ceiling"] = top.get("frac_of_mix_ceiling")
-    mf, mf_src = pmc_mfma()
+    mf, mf_src = pmc_mfma(args)
     for r in rows:
         e = mf.get(r["key"])
         r["mfma_busy_frac"] = e.get("mfma_busy_frac") if e else None
@@ -466,9 +492,39 @@ def main():
             line["roofline"] = roof
             line["top_kernels"] = top
             line["kernel_ms_per_step_standalone_sum"] = total_ms
-            line["in_step_top_kernel"] = in_step_top()
+            line["in_step_top_kernel"] = in_step_top(args)
         else:
             line["roofline"] = None
+        if args.stage == 1 and args.phase == "train" and world == 1 and args.precision == "bf16" and not (args.no_mode_legs or args.no_cpu_baseline):
+            # the same step in the two parity-grade modes, outside the timed region (VERDICT r5 #4a): `fp32` is the mode the reference goldens are held to at
+            # 1e-3 (exact-float32 MFMA, float32 activations), `bf16_f32resid` keeps float32 residual-stream rows under bf16 operands
+            try:
+                del tr, out
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            for prec, key in (("bf16_f32resid", "images_per_sec_bf16_f32resid"), ("fp32", "images_per_sec_fp32_mode")):
+                from uvc_amd.stage1 import Stage1Trainer, default_args
+                torch.manual_seed(730)
+                a2 = default_args(model_type=args.model_type, precision=prec, train_batch_size=args.batch, local_rank=local, budget=args.budget,
+                                  enable_deit=args.enable_deit, enable_patch_gating=args.enable_patch_gating, patch_ratio=args.patch_ratio,
+                                  enable_block_gating=args.enable_block_gating)
+                t2 = Stage1Trainer(a2, device=f"cuda:{local}", distributed=False)
+                pruned_state(t2)
+                t2.begin_epoch(a2.warmup_epochs + 1)
+                for _ in range(3):
+                    t2.step(x, y, **nx)
+                torch.cuda.synchronize()
+                tw = time.perf_counter()
+                n2 = 12 if prec == "fp32" else 30
+                for i in range(n2):
+                    t2.step(x, y, **(nx if i + 1 < n2 else {}))
+                torch.cuda.synchronize()
+                line[key] = round(n2 * args.batch / (time.perf_counter() - tw), 1)
+                del t2
+                torch.cuda.empty_cache()
+            line["parity_modes_note"] = ("fp32: tests hold it to the reference goldens at 1e-3; bf16_f32resid / bf16 (the headline): 2e-2 on loss / logits, "
+                                         "<= 2.5 % per gradient tensor against float32 autograd; 3 warm-up + 12 / 30 timed steps each, same batch and state")
         line["commit"] = _git_head()
         if world == 1 and not args.no_cpu_baseline and args.stage == 1:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -57,6 +57,8 @@ typedef struct uvc_vit_shadow_offsets {
 } uvc_vit_shadow_offsets;
 
 int uvc_vit_layout(const uvc_vit_cfg* cfg, uvc_vit_offsets* off, uvc_vit_shadow_offsets* soff);
+/* training: 0 = no-grad forward only; 1 = training, per-block backward streams (two-stream backward); 2 = training, one shared set of backward
+ * streams (uvc_vit_io.shared_bwd_streams = 1; no side stream) */
 int64_t uvc_vit_workspace_bytes(const uvc_vit_cfg* cfg, int32_t batch, int32_t training);
 /* A HIP stream for uvc_vit_io.side_stream with a scheduling class: -1 = lowest priority the device offers (weight
  * gradients / teacher forward that should only fill idle CUs), 0 = default, +1 = highest.  Never destroyed by the
@@ -137,6 +139,12 @@ typedef struct uvc_vit_io {
                                           post_train.py:343-346 multiplies weight by mask before every step): dL/d(attention output) of the head is then
                                           exactly zero and so are its dq, dk, dv.  The forward still computes the head (dW_proj of the masked columns
                                           needs its output: the reference's clip norm sees it).  0: every head's backward runs */
+  int32_t shared_bwd_streams;          /* 0 (default): the workspace (uvc_vit_workspace_bytes(.., training = 1)) holds per-block copies of the backward's
+                                          streams dL/dx_l, dL/dx1, dA, dqkv, so that weight gradients on `side_stream` can read a block's streams while the
+                                          main stream is blocks ahead (L x (5 M D + M F) elements more).  1: the workspace was sized with training = 2 --
+                                          ONE shared set (dL/dx ping-pongs between two buffers); forward and backward of a step must agree, and the
+                                          backward must run without a side stream (UVC_ERR_ARG otherwise).  Same results bit for bit. */
+  int32_t reserved;
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

@@ -280,3 +280,45 @@ def test_loading_other_masks_rederives_the_pruned_head_table():
         assert torch.equal(grads[0][n], grads[1][n]), n
     qkv = [n for n in grads[0] if n.endswith("attn.qkv.weight")]
     assert qkv and all(float(grads[0][n].abs().sum()) > 0 for n in qkv)
+
+
+def test_post_training_reads_one_batch_ahead_and_changes_nothing():
+    """post_training() hands every step the NEXT batch (Stage1Trainer.lookahead over the odd-batch-trimmed loader), so the frozen teacher's forward
+    for it starts behind this step's backward: same weights bit for bit as plain steps, one teacher forward per step, nothing left pending; an odd
+    batch is trimmed BEFORE it is promised (the trimmed view is what the next step receives)."""
+    from uvc_amd.post_train import post_training
+    r, cfg, a = build("stage2_micro_skip", "bf16")
+    x_all, y_all = SC.make_inputs(r)
+    xs = [torch.from_numpy(x).cuda() for x in x_all]; ys = [torch.from_numpy(y).cuda() for y in y_all]
+    if len(xs[0]) > 2:                                                  # one odd batch in the middle of the epoch
+        xs[1], ys[1] = xs[1][:len(xs[1]) - 1].clone(), ys[1][:len(ys[1]) - 1].clone()
+    a.begin_epoch(0)
+    for x, y in zip(xs, ys):
+        if len(x) % 2:
+            x, y = x[:-1], y[:-1]
+        a.step(x, y)
+    _, _, b = build("stage2_micro_skip", "bf16")
+    calls = [0]
+    fwd = b.criterion.teacher_model.forward
+    b.criterion.teacher_model.forward = lambda *aa, **kk: (calls.__setitem__(0, calls[0] + 1), fwd(*aa, **kk))[1]
+    post_training(b, lambda epoch: zip(xs, ys), epochs=1, valid_fn=None, log=lambda *_: None)
+    torch.cuda.synchronize()
+    assert torch.equal(a.model._flat, b.model._flat) and a.global_step == b.global_step == len(xs)
+    assert calls[0] == len(xs) and b.criterion._pref is None
+
+
+def test_a_pending_teacher_forward_holds_its_input_tensor():
+    """the pending forward is matched by the tensor it HOLDS (identity, or another handle on the same storage window), never by a bare
+    address: a promised batch that the caller drops cannot have its block recycled into a different batch that then picks up stale logits."""
+    r, cfg, tr = build("stage2_micro_skip", "bf16")
+    x_all, _ = SC.make_inputs(r)
+    crit = tr.criterion
+    x = torch.from_numpy(x_all[0]).cuda()
+    ptr = x.data_ptr()
+    crit.prefetch(x)
+    assert crit.has_prefetch(x) and crit.has_prefetch(x.detach()) and crit._pref[0] is x
+    assert not crit.has_prefetch(x.clone()) and not crit.has_prefetch(x[:-1])
+    del x                                                               # the caller drops the promised batch ...
+    z = torch.empty_like(crit._pref[0])                                 # ... and allocates another of the same shape: it cannot get that block
+    assert z.data_ptr() != ptr and not crit.has_prefetch(z)
+    torch.cuda.synchronize()

@@ -587,10 +587,17 @@ __device__ __forceinline__ int lds_poll(unsigned addr) {
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
   return __builtin_amdgcn_readfirstlane(v);
 }
-// (bounded: a protocol error must show as wrong numbers in a test, not as a hung GPU -- 2^18 polls are ~20 ms, a hand-over takes < 1 us)
+// (bounded: 2^18 polls are ~20 ms, a hand-over takes < 1 us.  A poll that runs out is a protocol error: the kernel TRAPS -- the launch fails and every later
+//  HIP call of the process reports it -- instead of carrying on with a tile that was never handed over and writing plausible wrong dq / dk / dv.  Probe builds,
+//  which break the protocol on purpose to time its parts, carry on.)
+__device__ __forceinline__ void spin_timeout() {
+  if (UVC_ATTN_PROBE == 0) __builtin_trap();
+}
 __device__ __forceinline__ void spin_ge(unsigned addr, int v) {
   if (UVC_ATTN_PROBE == 2) return;
-  for (int n = 0; lds_poll(addr) < v && n < (1 << 18); ++n) __builtin_amdgcn_s_sleep(1);
+  int n = 0;
+  for (; lds_poll(addr) < v && n < (1 << 18); ++n) __builtin_amdgcn_s_sleep(1);
+  if (n == (1 << 18)) spin_timeout();
 }
 __device__ __forceinline__ void post(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 constexpr int SPIN_MAX = 1 << 18;
@@ -631,12 +638,13 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a, int
   // the next head of this workgroup, published by the first helper wave at the START of a head, read by everybody else much later (polled: no
   // barrier lies between); heads only grow, so a value above the current head is the new one
   auto next_head = [&](int it, int cur) {
-    int v = 0;
-    for (int n = 0; n < SPIN_MAX; ++n) {
+    int v = 0, n = 0;
+    for (; n < SPIN_MAX; ++n) {
       v = lds_poll(fN + ((it + 1) & 1) * 4) - 1;
       if (v > cur) break;
       __builtin_amdgcn_s_sleep(1);
     }
+    if (n == SPIN_MAX) spin_timeout();
     return v;
   };
   float* sLD = reinterpret_cast<float*>(smem + L::OFF_LD);
@@ -743,6 +751,9 @@ __global__ __launch_bounds__((NT + NH) * 64) void k_attn_bwd_one(AttnArgs a, int
       if (j == 0) {                                             // draw the next head and publish it
         unsigned t = 0;
         if (lane == 0) t = atomicAdd(&g_ticket[slot].next, 1u);
+        // a launch makes exactly B * H draws (one per head it runs), so a ticket >= B * H means the pair was not zero when the launch started -- a launch before
+        // it on this slot died before its last workgroup reset the pair: heads would be skipped and their dq / dk / dv rows left unwritten.  Fail loudly instead.
+        if ((int)t >= nbh && UVC_ATTN_PROBE == 0) __builtin_trap();
         nxt = (int)gridDim.x + __builtin_amdgcn_readfirstlane((int)t);
         post(fN + ((it + 1) & 1) * 4, nxt + 1);
       } else {

@@ -70,6 +70,7 @@ struct Work {
   // every block has its OWN copies of the streams its weight gradients read (gAs[l]: dL/dx_l, written by block l; gAs[L]: the top), so the main stream never
   // overwrites what the side stream may still be reading and needs no event wait inside a backward call; gA / gB / dA / dqkv above point at the current block's
   void* gAs[UVC_VIT_MAX_DEPTH + 1]; void* gBs[UVC_VIT_MAX_DEPTH]; void* dAs[UVC_VIT_MAX_DEPTH]; void* dqkvs[UVC_VIT_MAX_DEPTH];
+  void* gA_pp[2];          // training == 2 (one shared set of backward streams): the two dL/dx buffers gAs[] alternates between
   void* tn_ws; int64_t tn_ws_bytes; float* dotsraw; void* dhc; void* dpe;
   void* tn_ws_main;        // split-M partials of the weight gradients that run on the MAIN stream beside the side stream's (tn_ws_bytes too)
 };
@@ -109,9 +110,19 @@ int64_t carve(const Dims& d, int training, char* base, Work& w) {
   }
   w.hc = c.take((int64_t)d.B * d.ntok * d.D * d.tsz);
   w.meanf = (float*)c.take((int64_t)d.B * d.ntok * 4); w.rstdf = (float*)c.take((int64_t)d.B * d.ntok * 4);
-  if (training) {
+  if (training == 2) {
+    // ONE set of backward streams for all blocks (uvc_vit_workspace_bytes(.., training = 2), uvc_vit_io.shared_bwd_streams): for a backward WITHOUT a side
+    // stream, where every weight gradient runs in order behind its operands' producers and the per-block copies buy nothing -- L x (5 MD + MF) elements less
+    // (17 GB for DeiT-Base at batch 512).  dL/dx ping-pongs between two buffers by the count of blocks that ran (assign_shared_streams).
+    w.gA_pp[0] = c.take(MD * d.tsz); w.gA_pp[1] = c.take(MD * d.tsz);
+    void* gB = c.take(MD * d.tsz); void* dA = c.take(MF * d.tsz); void* dqkv = c.take(3 * MD * d.tsz);
+    for (int l = 0; l <= d.L; ++l) w.gAs[l] = w.gA_pp[(d.L - l) & 1];
+    for (int l = 0; l < d.L; ++l) { w.gBs[l] = gB; w.dAs[l] = dA; w.dqkvs[l] = dqkv; }
+  } else if (training) {
     for (int l = 0; l <= d.L; ++l) w.gAs[l] = c.take(MD * d.tsz);
     for (int l = 0; l < d.L; ++l) { w.gBs[l] = c.take(MD * d.tsz); w.dAs[l] = c.take(MF * d.tsz); w.dqkvs[l] = c.take(3 * MD * d.tsz); }
+  }
+  if (training) {
     w.gA = w.gAs[d.L]; w.gB = w.gBs[0]; w.dA = w.dAs[0]; w.dqkv = w.dqkvs[0];
     w.dH = c.take(MD * d.tsz);
     w.delta = (float*)c.take((int64_t)d.B * d.H * d.N * 4);
@@ -323,7 +334,9 @@ int setup(Ctx& c, const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream, bo
   c.n_pend = 0; c.tn_inline = false;
   if (c.side) TRY(ensure_events());
   TRY(uvc_vit_layout(cfg, &c.off, &c.soff));
-  const int64_t need = carve(c.d, bwd ? 1 : io->training, (char*)io->workspace, c.w);
+  const int mode = (bwd || io->training) ? (io->shared_bwd_streams ? 2 : 1) : 0;
+  if (mode == 2 && c.side) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: shared_bwd_streams (workspace mode 2) cannot be combined with a side stream");
+  const int64_t need = carve(c.d, mode, (char*)io->workspace, c.w);
   if (io->workspace_bytes < need) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_vit: workspace too small");
   if (io->patches_in) c.w.patches = const_cast<void*>(io->patches_in);      // rearranged once for student and teacher
   return UVC_OK;
@@ -616,6 +629,13 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
   // dL/dx_k lives in gAs[k] (written by block k; gAs[L]: the final norm's): block l reads the one of the nearest block above it that ran
   auto runs = [&](int l) { return io->gate_d || !io->run_block || io->run_block[l]; };
   auto g_in = [&](int l) { int k = l + 1; while (k < d.L && !runs(k)) ++k; return w.gAs[k]; };
+  if (io->shared_bwd_streams) {
+    // dL/dx alternates between the two shared buffers by the number of blocks that RAN above (a hard-skipped block neither reads nor writes one), whichever
+    // stage range this call covers: block l must never write the buffer it reads
+    int cnt = 0;
+    w.gAs[d.L] = w.gA_pp[0];
+    for (int l = d.L - 1; l >= 0; --l) { if (runs(l)) ++cnt; w.gAs[l] = w.gA_pp[cnt & 1]; }
+  }
   w.gA = w.gAs[d.L];
   // The side stream runs a block behind (a block's weight gradients start when the block is through), so the LAST block's would run after the main stream has
   // finished, alone (370 us of the step's timeline, profiles/r5z_timeline.txt): the two MLP weight gradients of that block run on the main stream instead, in

@@ -84,20 +84,31 @@ class DistillationLoss(torch.nn.Module):
         if self._side is None:
             self._side = L.side_stream(inputs.device)
         self._side.wait_stream(main)
+        # the side stream reads `inputs` after this call returns: tell the caching allocator, so that a caller who drops the tensor does not get
+        # its block handed to another tensor on the main stream while the teacher still reads it
+        inputs.record_stream(self._side)
         with torch.cuda.stream(self._side), torch.no_grad():
             out, _ = self.teacher_model(inputs)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        self._pref = (inputs.data_ptr(), inputs._version, out, ev, tuple(inputs.shape))
+        # the pending forward HOLDS the tensor it was started for (a pending forward can outlive a step() call since `next_x`): identity + version
+        # + shape is the match, so a recycled block of the same address / shape / version can never pick up another batch's logits
+        self._pref = (inputs, inputs._version, out, ev, tuple(inputs.shape), inputs.data_ptr())
+
+    def _matches(self, p, inputs):
+        # the very tensor object, or another handle on the same storage window (x.detach(), a no-op .contiguous()): either way the reference held in
+        # `p` keeps the storage alive, so an equal data_ptr cannot belong to a different allocation
+        return (p is not None and p[1] == inputs._version and p[4] == tuple(inputs.shape)
+                and (p[0] is inputs or (p[5] == inputs.data_ptr() and p[0].untyped_storage().data_ptr() == inputs.untyped_storage().data_ptr()
+                                        and p[0].stride() == inputs.stride() and p[0].dtype == inputs.dtype)))
 
     def has_prefetch(self, inputs):
         """True when ``prefetch`` has already started the teacher forward for exactly this tensor (same storage, same version)."""
-        p = self._pref
-        return p is not None and p[0] == inputs.data_ptr() and p[1] == inputs._version and p[4] == tuple(inputs.shape)
+        return self._matches(self._pref, inputs)
 
     def _teacher(self, inputs):
         p, self._pref = self._pref, None
-        if p is not None and p[0] == inputs.data_ptr() and p[1] == inputs._version and p[4] == tuple(inputs.shape):
+        if self._matches(p, inputs):
             torch.cuda.current_stream().wait_event(p[3])
             p[2].record_stream(torch.cuda.current_stream())
             return p[2]

@@ -55,7 +55,8 @@ class uvc_vit_io(C.Structure):
                 ("batch", C.c_int32), ("training", C.c_int32), ("gate_mode", C.c_int32), ("gate_eps", C.c_float),
                 ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
                 ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("fused_train_mlp", C.c_int32), ("patches_in", C.c_void_p),
-                ("fuse_next_ln", C.c_int32), ("force_generic", C.c_int32), ("head_keep_bwd", C.c_int32)]
+                ("fuse_next_ln", C.c_int32), ("force_generic", C.c_int32), ("head_keep_bwd", C.c_int32), ("shared_bwd_streams", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class uvc_mlp_compact(C.Structure):
@@ -524,10 +525,19 @@ class DistilledVisionTransformer(nn.Module):
         return r
 
     # -- engine calls ---------------------------------------------------------------------------------
+    def _ws_mode(self, training):
+        """uvc_vit_workspace_bytes' `training` argument: 0 = no-grad forward; 1 = training with per-block copies of the backward's streams (what the weight
+        gradients on the side stream read while the main stream is blocks ahead); 2 = training WITHOUT the two-stream backward: one shared set, L x (5 M D + M F)
+        elements less (17 GB for DeiT-Base at batch 512).  Same results bit for bit (tests/test_streaming_batch_gpu.py)."""
+        if not training:
+            return 0
+        return 1 if self.two_stream_backward else 2
+
     def _workspace(self, B, training):
-        key = (B, bool(training))
+        mode = self._ws_mode(training)
+        key = (B, bool(training), mode)
         if key not in self._ws:
-            nbytes = _bind().uvc_vit_workspace_bytes(C.byref(self._cfg), B, int(training))
+            nbytes = _bind().uvc_vit_workspace_bytes(C.byref(self._cfg), B, mode)
             if nbytes < 0:
                 raise L.UvcHipError(f"uvc_vit_workspace_bytes: {L.lib().uvc_last_error().decode()}")
             self._ws = {k: v for k, v in self._ws.items() if k[1] != bool(training)}   # keep one per mode
@@ -545,6 +555,7 @@ class DistilledVisionTransformer(nn.Module):
         io.params, io.shadow, io.grads = L.ptr(self._flat), L.ptr(self._shadow), L.ptr(self._flat_grad)
         io.workspace, io.workspace_bytes = L.ptr(ws), ws.numel()
         io.batch, io.training = B, int(training)
+        io.shared_bwd_streams = int(self._ws_mode(training) == 2)
         io.gate_mode, io.gate_eps = self._gate_mode(), float(self.eps)
         io.accumulate = 1.0 if self.grad_accumulate else 0.0
         io.mlp_compact = C.addressof(self._mlp_compact) if self._mlp_compact is not None else None
@@ -567,7 +578,7 @@ class DistilledVisionTransformer(nn.Module):
             lib.uvc_vit_ws_offsets.restype = C.c_int
             lib._wsoff_bound = True
         pe_off, dpe_off = C.c_int64(), C.c_int64()
-        L.check(lib.uvc_vit_ws_offsets(C.byref(self._cfg), B, int(training), C.byref(pe_off), C.byref(dpe_off)), "uvc_vit_ws_offsets")
+        L.check(lib.uvc_vit_ws_offsets(C.byref(self._cfg), B, self._ws_mode(training), C.byref(pe_off), C.byref(dpe_off)), "uvc_vit_ws_offsets")
         ws = self._workspace(B, training)
         cfg = self._cfg
         rows = B * (cfg.img_size // cfg.patch_size) ** 2
@@ -648,7 +659,8 @@ class DistilledVisionTransformer(nn.Module):
             ops.gate_distrib(self.block_skip_gating.data, e, gate_d, cfg.depth, mode, float(self.eps))
         io.gate_d = L.ptr(gate_d)
         L.check(lib.uvc_vit_forward(C.byref(cfg), C.byref(io), stream), "uvc_vit_forward")
-        self._last = dict(x=x, gate_d=gate_d, patch=patch, B=B, run_block=run_block, front=self._front_state, patches=patches) if training else None
+        self._last = dict(x=x, gate_d=gate_d, patch=patch, B=B, run_block=run_block, front=self._front_state, patches=patches,
+                          ws_mode=self._ws_mode(True)) if training else None
         self.last_distrib = gate_d
         self.last_patch_mask = patch["mask"] if patch else None
         return logits, logits_dist
@@ -703,6 +715,8 @@ class DistilledVisionTransformer(nn.Module):
         if st is None:
             raise RuntimeError("backward without a training forward")
         patch = st["patch"]
+        if st.get("ws_mode", self._ws_mode(True)) != self._ws_mode(True):
+            raise RuntimeError("two_stream_backward was changed between a training forward and its backward (the two lay the workspace out differently)")
         self.grad_views(patch_mode2=bool(patch and patch["mode"] == 2))
         io = self._io(st["B"], True)
         io.patches_in = L.ptr(st.get("patches"))

@@ -27,7 +27,7 @@ from .losses import DistillationLoss, SoftTargetCrossEntropy, unit_gradient
 from .model_distilled import DistilledVisionTransformer
 from .optim import clip_grad_norm_, create_optimizer
 from .scheduler import create_scheduler
-from .stage1 import CONFIGS
+from .stage1 import CONFIGS, Stage1Trainer
 
 
 def default_args(**over) -> Namespace:
@@ -177,10 +177,15 @@ def post_training(trainer: Stage2Trainer, batches, epochs=None, valid_fn=None, l
         trainer.begin_epoch(epoch)
         t0 = time.time()
         last = None
-        for x, y in batches(epoch):
-            if len(x) % 2 != 0:                                                                     # :348-350
-                x, y = x[:-1], y[:-1]
-            last = trainer.step(x, y)
+        def trimmed():
+            for x, y in batches(epoch):
+                if len(x) % 2 != 0:                                                                 # :348-350
+                    x, y = x[:-1], y[:-1]
+                yield x, y
+        # one batch read ahead (as the reference's prefetching loader holds it): the frozen teacher's forward for the NEXT batch starts behind this
+        # step's backward (Stage2Trainer.step's next_x; same results, tests/test_stage2_gpu.py)
+        for (x, y), next_x in Stage1Trainer.lookahead(trimmed()):
+            last = trainer.step(x, y, next_x=next_x)
         lr = trainer.scheduler.get_epoch_values(epoch)[0]
         if last is not None:
             log(f"[Stage 2] epoch {epoch} steps {trainer.global_step} lr {lr:.6g} loss {float(last['loss']):.4f} "

@@ -155,7 +155,9 @@ class Stage1Trainer:
         self.gating_grad_list = []
         # the reference counts accumulation windows with the loader index of the epoch, `(step + 1) % k` (:423): a window never straddles
         # an epoch boundary; gradients of an unfinished window stay in .grad (zero_grad sits inside the `if`) and join the next one
-        self._window_carried = self._micro % self.accum != 0    # its noise draws continue under the same step number (KeyedExpSource.begin_step)
+        # (its noise draws continue under the same step number, KeyedExpSource.begin_step; `or`: a flag restored by load_state_dict from a checkpoint taken
+        #  AFTER a begin_epoch -- micro already 0 -- survives the begin_epoch of the resumed run, so the site numbering continues as in the uninterrupted run)
+        self._window_carried = bool(getattr(self, "_window_carried", False)) or (self._micro % self.accum != 0)
         self._micro = 0
         # The reference keys the warm-up phase on the epoch alone (:343): --enable_warmup never reaches the model
         # (`enable_warmpup` typo in build_minimax_model's kwargs), so `--enable_warmup 0 --warmup_epochs 5` still warms up.

@@ -30,8 +30,18 @@ enum {
   UVC_EPI_BIAS_GELU_OUT = 6,   /* C = GELU_erf(acc + bias)   (inference: pre-activation not kept)        */
   UVC_EPI_BIAS_GELU_GRAD = 7,  /* a = acc + bias ; C = GELU'(a) ; C2 = GELU_erf(a): training forward of fc1 -- the backward
                                   needs the pre-activation only through GELU'(a), so that is what is kept            */
-  UVC_EPI_MUL_AUX = 8          /* C = alpha*acc * aux[m,n]   (backward of the activation with aux = stored GELU'(a)) */
+  UVC_EPI_MUL_AUX = 8,         /* C = alpha*acc * aux[m,n]   (backward of the activation with aux = stored GELU'(a)) */
+  /* r6: GELU'(a) in ONE byte.  The backward needs the fc1 pre-activation only through GELU'(a), a BOUNDED quantity ([-0.1290, 1.1290]), and fc1 + GELU, GELU'
+   * is write-bound (profiles/r6b_bound_probes.txt: the step is 3.2 % faster with that tensor not written at all).  Uniform code over [UVC_Q8_LO, UVC_Q8_LO +
+   * 255 UVC_Q8_STEP] = [-0.13, 1.13]:  q = min(255, trunc(max(0, (GELU' - LO) / STEP + 0.5))),  GELU' ~ LO + q STEP,  |error| <= STEP / 2 = 2.47e-3 everywhere --
+   * finer than bf16 where GELU' >= 0.5 (bf16 spacing 3.9e-3 on [0.5, 1), 7.8e-3 on [1, 2)), coarser only where GELU' is small and weighs least; relative L2
+   * error of dA / dW1 / dh against float64 2.0e-3 - 2.6e-3 against 1.6e-3 - 2.0e-3 for bf16 GELU' (tools/gelu_grad_codes.py, profiles/r6_gelu_grad_codes_cpu.txt).
+   * bf16 compute, K = 192, N % 256 == 0, M >= 4096 (uvc_gemm_nt_q8_supported): the streaming kernel of DeiT-Tiny's width; UVC_ERR_UNSUPPORTED elsewhere. */
+  UVC_EPI_BIAS_GELU_GRAD_Q8 = 9,  /* a = acc + bias ; C [M, N] BYTES (ldc in bytes = elements) = code(GELU'(a)) ; C2 = GELU_erf(a) (T)          */
+  UVC_EPI_MUL_AUX_Q8 = 10         /* C = alpha*acc * (LO + STEP * aux[m,n]),  aux [M, N] bytes (ldaux in elements) written by _GELU_GRAD_Q8      */
 };
+#define UVC_Q8_LO (-0.13f)
+#define UVC_Q8_STEP (1.26f / 255.0f)
 
 /* C[M,N] = epilogue( A[M,K] . B[N,K]^T ); A, B row-major with K contiguous. */
 typedef struct uvc_gemm_nt_args {
@@ -65,6 +75,9 @@ typedef struct uvc_gemm_nt_args {
 } uvc_gemm_nt_args;
 int uvc_gemm_nt(const uvc_gemm_nt_args* args, void* stream);
 int uvc_gemm_nt_ln_supported(int32_t M, int32_t N, int32_t K, int32_t dtype, int32_t epilogue);
+/* 1 where UVC_EPI_BIAS_GELU_GRAD_Q8 (N = hidden width, K = embed_dim) AND its partner UVC_EPI_MUL_AUX_Q8 (N and K swapped roles: [M, K'] x [N', K'] with
+ * K' = embed_dim) exist: bf16, embed_dim 192, hidden % 256 == 0, M >= 4096.  Callers fall back to UVC_EPI_BIAS_GELU_GRAD / UVC_EPI_MUL_AUX elsewhere. */
+int uvc_gemm_nt_q8_supported(int32_t M, int32_t hidden, int32_t embed_dim, int32_t dtype);
 
 /* C[N1,N2] = beta*C + alpha * A[M,N1]^T . B[M,N2]  (weight gradients; float32 C).
  * Deterministic: M is cut into slices reduced in a fixed order through `workspace`. */

@@ -144,7 +144,11 @@ typedef struct uvc_vit_io {
                                           main stream is blocks ahead (L x (5 M D + M F) elements more).  1: the workspace was sized with training = 2 --
                                           ONE shared set (dL/dx ping-pongs between two buffers); forward and backward of a step must agree, and the
                                           backward must run without a side stream (UVC_ERR_ARG otherwise).  Same results bit for bit. */
-  int32_t reserved;
+  int32_t gelu_grad_bf16;              /* 0 (default): where uvc_gemm_nt_q8_supported (bf16, embed_dim 192, hidden % 256 == 0, >= 4096 rows) the training forward
+                                          leaves GELU'(a) of fc1 as ONE byte per activation (UVC_EPI_BIAS_GELU_GRAD_Q8: a uniform code over [-0.13, 1.13], |error|
+                                          <= 2.47e-3 -- as accurate as bf16 on this bounded quantity, include/uvc_kernels.h) and the dgrad of fc2 decodes it
+                                          (UVC_EPI_MUL_AUX_Q8): fc1 + GELU, GELU' is write-bound, 77 MB per block less at DeiT-Tiny batch 512.  1: bf16 GELU'(a)
+                                          everywhere, as before r6 (A/B runs, tests).  Forward and backward of a step must agree. */
 } uvc_vit_io;
 
 int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, void* stream);

@@ -1194,3 +1194,71 @@ def test_gemm_nt_row384_forward_with_layernorm_is_bit_identical_to_the_unfused_p
     h2 = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
     ops.gemm_nt(A, W, torch.empty_like(C0), ln_gamma=gm, ln_beta=bt, ln_out=h2, **kw)          # no statistics (no-grad forward)
     assert torch.equal(h2, h0)
+
+
+@pytest.mark.parametrize("M", [4096 + 37, 16 * 1031])
+def test_gelu_grad_one_byte_code_round_trip(M):
+    """r6: GELU'(a) of fc1 as ONE byte per activation (UVC_EPI_BIAS_GELU_GRAD_Q8 -> UVC_EPI_MUL_AUX_Q8; include/uvc_kernels.h).
+      * the byte decodes to GELU'(a) within STEP / 2 = 2.47e-3 of the float64 value EVERYWHERE (bf16's own spacing on [1, 2) is 7.8e-3), the code is
+        exactly the header's formula applied to the kernel's own bf16-mode GELU' (codes differ from it by at most one step at a rounding boundary), and
+        GELU(a) (C2) is bit-identical to the two-byte epilogue's;
+      * the backward's product (alpha * acc) * decode(code) equals the float64 product with the DECODED multiplier to bf16 rounding, and agrees with the
+        two-byte path (bf16 GELU') to the sum of the two codes' errors;
+      * ragged M, several tiles per workgroup; unsupported shapes are refused loudly."""
+    from uvc_amd import ops
+    K, N = 192, 768
+    A = rnd(M, K, seed=91).to(torch.bfloat16)
+    W = rnd(N, K, seed=92, scale=0.09).to(torch.bfloat16)           # pre-activations with a spread of ~1.2: both tails of GELU' are visited
+    bias = rnd(N, seed=93, scale=0.3)
+    a64 = A.double() @ W.double().t() + bias.double()
+    gp64 = 0.5 * (1 + torch.erf(a64 / math.sqrt(2))) + a64 * torch.exp(-0.5 * a64 * a64) / math.sqrt(2 * math.pi)
+    assert ops.gemm_nt_q8_supported(M, N, K, BF16)
+    q = torch.full((M, N), 77, device=dev(), dtype=torch.uint8)
+    u8 = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(A, W, q, dtype=BF16, epilogue=ops.EPI_BIAS_GELU_GRAD_Q8, bias=bias, C2=u8)
+    g16, u16 = torch.empty(M, N, device=dev(), dtype=torch.bfloat16), torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(A, W, g16, dtype=BF16, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bias, C2=u16)
+    assert torch.equal(u8, u16)
+    dec = q.double() * ops.Q8_STEP + ops.Q8_LO
+    err = (dec - gp64).abs()
+    assert float(err.max()) <= ops.Q8_STEP / 2 + 2e-4, float(err.max())       # (+ the bf16-mode GELU' approximation, <= 8.3e-5, and float32 rounding of the code)
+    assert float(err.pow(2).mean().sqrt()) <= 1.6e-3
+    assert int(q.min()) >= 0 and int(q.max()) <= 255 and int(q.max()) - int(q.min()) > 200           # the code's range is used
+    # the two-byte tensor of the same launch shape, coded on the host with the header's formula: same codes but for values on a rounding boundary
+    host = torch.clamp(torch.floor((g16.double() - ops.Q8_LO) / ops.Q8_STEP + 0.5), 0, 255)
+    d = (host - q.double()).abs()
+    assert float(d.max()) <= 1.0 and float((d > 0).double().mean()) <= 0.25            # (g16 is itself rounded to bf16: up to a step apart where it crosses a boundary)
+    # ---- the backward's product
+    G = rnd(M, K, seed=94).to(torch.bfloat16)
+    W2t = rnd(N, K, seed=95, scale=0.05).to(torch.bfloat16)
+    alpha = torch.tensor([0.6], device=dev())
+    dA8, dA16 = torch.empty(M, N, device=dev(), dtype=torch.bfloat16), torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt(G, W2t, dA8, dtype=BF16, epilogue=ops.EPI_MUL_AUX_Q8, aux=q, alpha_ptr=alpha)
+    ops.gemm_nt(G, W2t, dA16, dtype=BF16, epilogue=ops.EPI_MUL_AUX, aux=g16, alpha_ptr=alpha)
+    acc = 0.6 * (G.double() @ W2t.double().t())
+    ref8 = acc * dec
+    torch.testing.assert_close(dA8.double(), ref8, rtol=2 ** -8, atol=1e-6)              # one bf16 rounding of the exact product with the decoded multiplier
+    ref = acc * gp64
+    e8, e16 = float((dA8.double() - ref).norm() / ref.norm()), float((dA16.double() - ref).norm() / ref.norm())
+    assert e8 <= 4e-3 and e16 <= 4e-3 and e8 <= 1.6 * e16 + 5e-4, (e8, e16)            # as accurate as the two-byte path (CPU study: 2.0e-3 - 2.6e-3 against 1.6e-3 - 2.0e-3)
+    # determinism
+    q2 = torch.empty_like(q)
+    ops.gemm_nt(A, W, q2, dtype=BF16, epilogue=ops.EPI_BIAS_GELU_GRAD_Q8, bias=bias, C2=u8)
+    assert torch.equal(q, q2)
+
+
+def test_gelu_grad_one_byte_code_is_refused_where_it_does_not_exist():
+    from uvc_amd import _lib as L
+    from uvc_amd import ops
+    A = rnd(4096, 384, seed=96).to(torch.bfloat16)
+    W = rnd(1536, 384, seed=97, scale=0.05).to(torch.bfloat16)
+    q = torch.empty(4096, 1536, device=dev(), dtype=torch.uint8)
+    u = torch.empty(4096, 1536, device=dev(), dtype=torch.bfloat16)
+    assert not ops.gemm_nt_q8_supported(4096, 1536, 384, BF16) and not ops.gemm_nt_q8_supported(2048, 768, 192, BF16) and not ops.gemm_nt_q8_supported(8192, 768, 192, F32)
+    with pytest.raises(L.UvcHipError, match="one-byte"):
+        ops.gemm_nt(A, W, q, dtype=BF16, epilogue=ops.EPI_BIAS_GELU_GRAD_Q8, bias=torch.zeros(1536, device=dev()), C2=u)
+    A2 = rnd(8192, 192, seed=98).to(torch.bfloat16)
+    W2 = rnd(768, 192, seed=99, scale=0.05).to(torch.bfloat16)
+    with pytest.raises(L.UvcHipError, match="one-byte"):       # the generic kernel has no such epilogue
+        ops.gemm_nt(A2, W2, torch.empty(8192, 768, device=dev(), dtype=torch.bfloat16), dtype=BF16, epilogue=ops.EPI_MUL_AUX_Q8,
+                    aux=torch.zeros(8192, 768, device=dev(), dtype=torch.uint8), force_generic=True)

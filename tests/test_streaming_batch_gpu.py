@@ -52,13 +52,14 @@ def _oracle_step():
     return S, out
 
 
-def _hip_step(precision, force_generic=0, fuse_next_ln=True):
+def _hip_step(precision, force_generic=0, fuse_next_ln=True, gelu_grad_bf16=0):
     r = _recipe()
     gold = load_golden("tiny8_pruned")
     run = Stage1Run(r, precision=precision)
     for m in (run.model, run.teacher):
         m.force_generic = force_generic
         m.fuse_next_ln = fuse_next_ln
+        m.gelu_grad_bf16 = gelu_grad_bf16
     x_all, y_all = SC.make_inputs(r)
     md, e1, e2 = split_draws(r, gold, 0, run.cfg.depth)
     run.inject_draws(md, e1, e2)
@@ -147,6 +148,29 @@ def test_tiny_step_streaming_and_generic_kernels_agree_per_tensor(oracle):
     for (a1, a3), (b1, b3) in zip(_masks(run_s), _masks(run_g)):
         assert torch.equal(a1, b1) and torch.equal(a3, b3)
     print("streaming vs generic, per-tensor gradient difference: max %.5f (%s)" % (max(diff.values()), max(diff, key=diff.get)))
+
+
+def test_one_byte_gelu_grad_is_as_close_to_the_oracle_as_bf16_gelu_grad(oracle):
+    """r6 (uvc_vit_io.gelu_grad_bf16): the step with GELU'(a) of fc1 stored as ONE byte per activation (the default at this shape: M = 6304 >= 4096) against
+    the same step with the two-byte tensor of rounds 1-5.  Same forward bit for bit (the code is a backward-only operand); both inside the SAME per-tensor
+    bound against the oracle's float32 autograd, the one-byte step's worst tensor no worse than 1.15 x the two-byte step's; per tensor the two differ by
+    what the two codes' independent errors add up to over the 12 blocks the gradient crosses (measured max 1.05 %, in block 0; bound 1.5 %) -- well inside the
+    distance either has to the oracle; masks identical."""
+    S, o = oracle
+    run_q, out_q, g_q = _hip_step("bf16")
+    run_b, out_b, g_b = _hip_step("bf16", gelu_grad_bf16=1)
+    assert float(out_q["loss"]) == float(out_b["loss"]) and torch.equal(out_q["outputs"][0], out_b["outputs"][0])
+    w_q = _check_against_oracle(run_q, out_q, g_q, S, o, tol_grad=TOL_GRAD_BF16, tol_out=2e-2, tol_state=2e-2, what="one-byte GELU'")
+    w_b = _check_against_oracle(run_b, out_b, g_b, S, o, tol_grad=TOL_GRAD_BF16, tol_out=2e-2, tol_state=2e-2, what="bf16 GELU'")
+    diff = {n: _rel(g_q[n], g_b[n]) for n in g_q if g_q[n] is not None}
+    assert max(diff.values()) > 0.0, "the two runs are identical: the one-byte path did not run"
+    bad = {k: round(v, 5) for k, v in diff.items() if v > (1.5e-2 if k != "block_skip_gating" else 6e-2)}
+    assert not bad, ("one-byte vs bf16 GELU'", bad)
+    assert max(w_q.values()) <= 1.15 * max(w_b.values()) + 1e-3 and float(np.median(list(w_q.values()))) <= 1.1 * float(np.median(list(w_b.values()))) + 5e-4
+    for (a1, a3), (b1, b3) in zip(_masks(run_q), _masks(run_b)):
+        assert torch.equal(a1, b1) and torch.equal(a3, b3)
+    print("per-tensor gradient error vs oracle: one-byte GELU' max %.4f median %.4f | bf16 GELU' max %.4f median %.4f | one-byte vs bf16 max %.4f (%s)" %
+          (max(w_q.values()), float(np.median(list(w_q.values()))), max(w_b.values()), float(np.median(list(w_b.values()))), max(diff.values()), max(diff, key=diff.get)))
 
 
 def test_tiny_step_register_staged_streaming_kernels_match_the_rings(oracle):

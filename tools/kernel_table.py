@@ -109,8 +109,16 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
         add("proj+resid", "k_gemm_wsn16_dma<3, 6, false" if tiny else "k_gemm", (T if fuse_ln else 1 + T) * Lf, u + 2 * ru, 2.0 * M * D * D,
             lambda: ops.gemm_nt(xb, Wp, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID, bias=bD, R=xr), wfrac=ru / (u + 2 * ru))
     aa, uu = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
-    add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
-        lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu))
+    # r6: where the one-byte GELU' code exists (DeiT-Tiny's width; the engine's condition, vit_engine.hip gp_q8) fc1 writes GELU(a) in bf16 and GELU'(a) as bytes:
+    # h2 in (1 u) + 4 u + 2 u out; the dgrad of fc2 reads the bytes
+    q8 = ops.gemm_nt_q8_supported(M, F, D, dt) and os.environ.get("UVC_GELU_GRAD_BF16", "0") in ("", "0")
+    aq = torch.empty(M, F, device=dev, dtype=torch.uint8)
+    if q8:
+        add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 9", Lf, 7 * u, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(xb, W1, aq, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD_Q8, bias=bF, C2=uu), wfrac=6 / 7)
+    else:
+        add("fc1+gelu,gelu'", "k_gemm_ws<unsigned short, unsigned short, 7" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(xb, W1, aa, dtype=dt, epilogue=ops.EPI_BIAS_GELU_GRAD, bias=bF, C2=uu))
     if fuse_ln:
         add("fc2+resid+gate+norm1", "k_gemm_row384_lnbwd<true, 1>" if row384 else "k_gemm_wsn16_dma<4", Lf, 5 * u + 3 * ru, 2.0 * M * D * F,
             lambda: ops.gemm_nt(hF, W2, o32, dtype=dt, epilogue=ops.EPI_BIAS_RESID_GATE, bias=bD, R=xr, R2=gr_, gate=gate,
@@ -133,8 +141,13 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
             lambda: ops.mlp_fused_fwd(xr, gam, bet, W1, bF, W2, bD, o32, next_gamma=gam, next_beta=bet, next_h=y), wfrac=(ru + u) / (u + 2 * ru))
     # ---- backward, main stream
     dA = torch.empty(M, F, device=dev, dtype=bf)
-    add("dfc2 x gelu'", "k_gemm_ws<unsigned short, unsigned short, 8" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
-        lambda: ops.gemm_nt(g16, W1, dA, dtype=dt, epilogue=ops.EPI_MUL_AUX, aux=hF, alpha_ptr=gate))
+    if q8:
+        aq.random_(0, 256)
+        add("dfc2 x gelu'", "k_gemm_ws<unsigned short, unsigned short, 10", Lf, 7 * u, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(g16, W1, dA, dtype=dt, epilogue=ops.EPI_MUL_AUX_Q8, aux=aq, alpha_ptr=gate), wfrac=4 / 7)
+    else:
+        add("dfc2 x gelu'", "k_gemm_ws<unsigned short, unsigned short, 8" if tiny else "k_gemm", Lf, 9 * u, 2.0 * M * D * F,
+            lambda: ops.gemm_nt(g16, W1, dA, dtype=dt, epilogue=ops.EPI_MUL_AUX, aux=hF, alpha_ptr=gate))
     dx16, add16 = torch.empty(M, D, device=dev, dtype=bf), g16.clone()
     part = torch.empty(max(ops.layernorm_bwd_blocks(M), 272) * (2 * D + 2), device=dev)
     dg, db, dots = torch.empty(D, device=dev), torch.empty(D, device=dev), torch.empty(2, device=dev)

@@ -25,18 +25,18 @@ NAMES = {
     "qkv+attn_fwd (teacher)": ["k_qkv_attn_fwd<6, false", "k_qkv_attn_fwd<12, false"],
     "proj+resid": ["k_gemm_wsn16_dma<3, 6, false"],
     "proj+resid+norm2": ["k_gemm_wsn16_dma<3, 6, true"],
-    "fc1+gelu,gelu'": ["k_gemm_ws<unsigned short, unsigned short, 7"],
+    "fc1+gelu,gelu'": ["k_gemm_ws<unsigned short, unsigned short, 7", "k_gemm_ws<unsigned short, unsigned short, 9"],      # (9: GELU' as one byte, r6)
     "fc2+resid+gate+norm1": ["k_gemm_wsn16_dma<4"],
     "teacher mlp_fused+norm1": ["k_mlp_fused"],
-    "dfc2 x gelu'": ["k_gemm_ws<unsigned short, unsigned short, 8"],
+    "dfc2 x gelu'": ["k_gemm_ws<unsigned short, unsigned short, 8", "k_gemm_ws<unsigned short, unsigned short, 10"],
     "dfc1+ln2_bwd": ["k_gemm_wsn_lnbwd_dma<24"],
     "dqkv+ln1_bwd": ["k_gemm_wsn_lnbwd_dma<18"],
     "dproj": ["k_gemm_ws<unsigned short, unsigned short, 0"],
     "attn_bwd": ["k_attn_bwd_one", "k_attn_bwd_dq", "k_attn_bwd_dkv"],
     "dW2 (+reduce)": ["k_gemm_tn_dma<192, 256"],
     "dW1 (+reduce)": ["k_gemm_tn_dma<256, 192"],
-    "dWproj (+reduce)": ["k_gemm_tn<unsigned short"],
-    "dWqkv (+reduce)": ["k_gemm_tn_dma<192, 192"],
+    "dWproj (+reduce)": ["k_gemm_tn<unsigned short", "k_gemm_tn_dma<96, 192"],
+    "dWqkv (+reduce)": ["k_gemm_tn_dma<192, 192", "k_gemm_tn8p<6, 3"],
     "clip+adamw": ["k_adamw"],
 }
 

@@ -135,6 +135,8 @@ class uvc_performer_args(C.Structure):
 
 UVC_F32, UVC_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_BIAS_GELU_OUT, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX = range(9)
+EPI_BIAS_GELU_GRAD_Q8, EPI_MUL_AUX_Q8 = 9, 10      # GELU'(a) as one byte per activation (include/uvc_kernels.h)
+Q8_LO, Q8_STEP = -0.13, 1.26 / 255.0               # UVC_Q8_LO, UVC_Q8_STEP
 
 _lib = None
 VP = C.c_void_p
@@ -151,6 +153,7 @@ _SIGNATURES = {
     # include/uvc_kernels.h
     "uvc_gemm_nt": [C.POINTER(uvc_gemm_nt_args), VP],
     "uvc_gemm_nt_ln_supported": [I32, I32, I32, I32, I32],
+    "uvc_gemm_nt_q8_supported": [I32, I32, I32, I32],
     "uvc_gemm_tn": [C.POINTER(uvc_gemm_tn_args), VP],
     "uvc_gemm_tn_workspace_bytes": [I32, I32, I32, C.POINTER(I64), C.POINTER(I32)],
     "uvc_attention_fwd": [C.POINTER(uvc_attn_args), VP],

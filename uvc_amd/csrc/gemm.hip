@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64 * WS_NW, (KT > 6 && WS_NW > 6) ? 1 : (NJ == 4 ||
 #pragma unroll
   for (int e = 0; e < VN; ++e) bias_v[e] = 0.f;
   if (active && (EPI == UVC_EPI_BIAS || EPI == UVC_EPI_BIAS_GELU || EPI == UVC_EPI_BIAS_GELU_OUT || EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE ||
-                 EPI == UVC_EPI_BIAS_GELU_GRAD)) {
+                 EPI == UVC_EPI_BIAS_GELU_GRAD || EPI == UVC_EPI_BIAS_GELU_GRAD_Q8)) {
 #pragma unroll
     for (int e = 0; e < VN; ++e) bias_v[e] = g.bias[n + e];
   }
@@ -491,6 +491,10 @@ __global__ __launch_bounds__(64 * WS_NW, (KT > 6 && WS_NW > 6) ? 1 : (NJ == 4 ||
       if (EPI == UVC_EPI_BIAS_RESID || EPI == UVC_EPI_BIAS_RESID_GATE) E.r[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const TC*>(g.R) + mo * g.ldr + n);
       if (EPI == UVC_EPI_BIAS_RESID_GATE) E.r2[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const TC*>(g.R2) + mo * g.ldr + n);
       if (EPI == UVC_EPI_DGELU || EPI == UVC_EPI_MUL_AUX) E.ax[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.aux) + mo * g.ldaux + n);
+      if (EPI == UVC_EPI_MUL_AUX_Q8) {          // 8 one-byte codes of GELU'(a) (include/uvc_kernels.h)
+        const u32x2 q = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(g.aux) + mo * g.ldaux + n);
+        E.ax[it][0] = q[0]; E.ax[it][1] = q[1];
+      }
     }
   };
   auto subtile = [&](int buf_, int m0_, int sub_, const Epi& E) {
@@ -509,6 +513,9 @@ __global__ __launch_bounds__(64 * WS_NW, (KT > 6 && WS_NW > 6) ? 1 : (NJ == 4 ||
       }
     }
     __builtin_amdgcn_wave_barrier();
+    unsigned qc[IT][2];                                     // UVC_EPI_BIAS_GELU_GRAD_Q8: the lane's 8 one-byte codes of each of its rows
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { qc[it][0] = 0u; qc[it][1] = 0u; }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int r = it * RPI + lane / LPR;
@@ -545,15 +552,32 @@ __global__ __launch_bounds__(64 * WS_NW, (KT > 6 && WS_NW > 6) ? 1 : (NJ == 4 ||
             v[2 * e + 1] *= __uint_as_float(E.ax[it][e] & 0xffff0000u);
           }
         }
+        if constexpr (EPI == UVC_EPI_MUL_AUX_Q8) {
+          static_assert(VN == 8, "q8 epilogue: bf16 C");
+#pragma unroll
+          for (int e = 0; e < 8; ++e)            // (byte -> float is one v_cvt_f32_ubyteN)
+            v[e] *= __builtin_fmaf((float)((E.ax[it][e >> 2] >> (8 * (e & 3))) & 0xffu), UVC_Q8_STEP, UVC_Q8_LO);
+        }
         if (EPI == UVC_EPI_BIAS_GELU_OUT) {
 #pragma unroll
           for (int e = 0; e < VN; ++e) v[e] = Gelu<T>::f(v[e]);
         }
         float u[VN];
-        if (EPI == UVC_EPI_BIAS_GELU_GRAD) {
+        if (EPI == UVC_EPI_BIAS_GELU_GRAD || EPI == UVC_EPI_BIAS_GELU_GRAD_Q8) {
 #pragma unroll
           for (int e = 0; e < VN; ++e) { float fo, go; Gelu<T>::fg(v[e], fo, go); u[e] = fo; v[e] = go; }
         }
+        if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD_Q8) {
+          // GELU'(a) as one byte per activation (include/uvc_kernels.h): 8 codes = 8 bytes per lane, 64-byte row pieces per wave; GELU(a) as before.  Both stream
+          // past the caches (read again in the backward / by fc2)
+          static_assert(VN == 8, "q8 epilogue: bf16 C2");
+          unsigned qw[2] = {0u, 0u};
+#pragma unroll
+          for (int e = 0; e < 8; ++e)       // v_cvt_pk_u8_f32: round to nearest, saturate to [0, 255], pack into byte e & 3 -- two VALU instructions per code
+            qw[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[e], 1.0f / UVC_Q8_STEP, -UVC_Q8_LO / UVC_Q8_STEP), e & 3, qw[e >> 2]);
+          qc[it][0] = qw[0]; qc[it][1] = qw[1];            // stored behind the loop: 16 bytes per lane (below)
+          OutVec<TC>::st_nt(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
+        } else {
         // GELU'(a) and GELU(a) of the training forward are STREAMING outputs (310 MB per block, read again in the backward / by fc2 after the caches have
         // turned over): non-temporal stores.  Alone 90.2 -> 83.1 us; in the step 11.19 -> 10.96 ms (GELU' only: 79.8 us alone, 11.09 in the step) -- the rest of
         // the step keeps the Infinity Cache (profiles/r5zz_ab_nt_stores.txt).  K = 192 only: at K = 384 (DeiT-Small, T2T-ViT-14) the same stores are within
@@ -572,6 +596,23 @@ __global__ __launch_bounds__(64 * WS_NW, (KT > 6 && WS_NW > 6) ? 1 : (NJ == 4 ||
           else
           OutVec<TC>::st(reinterpret_cast<TC*>(g.C2) + mo * g.ldc + n, u);
         }
+        }
+      }
+    }
+    if constexpr (EPI == UVC_EPI_BIAS_GELU_GRAD_Q8) {
+      // The codes leave as 16 bytes per lane, ONE store instruction per 16-row sub-tile instead of two of 8 bytes: fc1's epilogue is bound by its store
+      // instructions as much as by its bytes (8-byte stores of the codes: the step 10.93 -> 10.90 ms where the tensor not written at all gives 10.70,
+      // profiles/r6d, r6b).  Lanes l, l ^ 1 hold neighbouring 8-column groups of the SAME two rows (it = 0, 1): the even lane takes both groups of row 0,
+      // the odd lane both groups of row 1 (one DPP quad permute per dword).
+      static_assert(IT == 2 && LPR == 8 && RPI == 8, "q8 epilogue: four waves x 64 columns");
+      const bool odd = lane & 1;
+      const unsigned s0 = odd ? qc[0][0] : qc[1][0], s1 = odd ? qc[0][1] : qc[1][1];      // what the partner stores: my codes of ITS row
+      const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]: lane ^ 1
+      const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
+      const int m = m0_ + sub_ * 16 + (odd ? RPI : 0) + lane / LPR;
+      if (m < g.M) {
+        const u32x4 o = odd ? u32x4{r0, r1, qc[1][0], qc[1][1]} : u32x4{qc[0][0], qc[0][1], r0, r1};
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(g.C) + (size_t)m * g.ldc + (n & ~15)));
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -616,6 +657,13 @@ static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
   if (nslots < 8) nslots = 8;
   if (nslots > ((ntiles + 7) & ~7)) nslots = (ntiles + 7) & ~7;
   const int grid = nslots * ngroups;
+  if (epi == UVC_EPI_BIAS_GELU_GRAD_Q8) {                  // (bf16 operands and outputs, K = 192, four waves x 64 columns: uvc_gemm_nt checked)
+    if constexpr (sizeof(TA) == 2 && sizeof(TC) == 2 && KT == 6 && WS_NW == 4) {
+      k_gemm_ws<TA, TC, UVC_EPI_BIAS_GELU_GRAD_Q8, KT, WS_NW><<<grid, 64 * WS_NW, 0, st>>>(a, ngroups, nslots);
+      UVC_CHECK_LAUNCH();
+      return UVC_OK;
+    } else return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: UVC_EPI_BIAS_GELU_GRAD_Q8 outside uvc_gemm_nt_q8_supported");
+  }
 #define WS_CASE(E) case E: k_gemm_ws<TA, TC, E, KT, WS_NW><<<grid, 64 * WS_NW, 0, st>>>(a, ngroups, nslots); break;
   switch (epi) {
     WS_CASE(UVC_EPI_NONE) WS_CASE(UVC_EPI_BIAS) WS_CASE(UVC_EPI_BIAS_GELU) WS_CASE(UVC_EPI_BIAS_RESID)
@@ -669,7 +717,7 @@ static int launch_ws_narrow(const NtArgs& a, int epi, hipStream_t st) {      // 
   const int grid = nslots * ngroups;
 #define WS_CASE(E) case E: k_gemm_ws<TA, TC, E, KT, 8, 2><<<grid, 512, 0, st>>>(a, ngroups, nslots); break;
   switch (epi) {
-    WS_CASE(UVC_EPI_DGELU) WS_CASE(UVC_EPI_MUL_AUX)
+    WS_CASE(UVC_EPI_DGELU) WS_CASE(UVC_EPI_MUL_AUX) WS_CASE(UVC_EPI_MUL_AUX_Q8)
     default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue");
   }
 #undef WS_CASE
@@ -681,8 +729,9 @@ static int launch_ws(const NtArgs& a, int epi, hipStream_t st) {
   // dL/d(fc1 out) = (g W2) * gelu'(a): measured 95 -> 83 us (stored gelu') and 118 -> 105 us (recomputed) with 32 columns per wave;
   // the forward's GELU epilogues are VALU-bound either way and stay on the 64-column tiling
   if constexpr (sizeof(TC) == 2 && sizeof(TA) == 2) {
-    if (a.N % 256 == 0 && a.K == 192 && (epi == UVC_EPI_DGELU || epi == UVC_EPI_MUL_AUX)) return launch_ws_narrow<TA, TC, 6>(a, epi, st);
+    if (a.N % 256 == 0 && a.K == 192 && (epi == UVC_EPI_DGELU || epi == UVC_EPI_MUL_AUX || epi == UVC_EPI_MUL_AUX_Q8)) return launch_ws_narrow<TA, TC, 6>(a, epi, st);
   }
+  if (epi == UVC_EPI_MUL_AUX_Q8) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: UVC_EPI_MUL_AUX_Q8 outside uvc_gemm_nt_q8_supported");
   // 4 waves (256 columns) per workgroup when N divides: more waves per CU to overlap the GELU epilogues
   if (a.N % 256 == 0) return a.K == 192 ? launch_ws_epi<TA, TC, 6, 4>(a, epi, st) : launch_ws_epi<TA, TC, 4, 4>(a, epi, st);
   return a.K == 192 ? launch_ws_epi<TA, TC, 6, 3>(a, epi, st) : launch_ws_epi<TA, TC, 4, 3>(a, epi, st);
@@ -1029,6 +1078,10 @@ extern "C" int uvc_gemm_nt_ln_supported(int32_t M, int32_t N, int32_t K, int32_t
   return ((K == 768 || K == 512 || K == 256) && (epilogue == UVC_EPI_BIAS_RESID || epilogue == UVC_EPI_BIAS_RESID_GATE)) || (K == 192 && epilogue == UVC_EPI_BIAS_RESID);
 }
 
+extern "C" int uvc_gemm_nt_q8_supported(int32_t M, int32_t hidden, int32_t embed_dim, int32_t dtype) {
+  return dtype == UVC_BF16 && embed_dim == 192 && hidden > 0 && hidden % 256 == 0 && M >= 4096;
+}
+
 extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
   if (!p || !p->A || !p->B || !p->C) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: null pointer");
   if (p->M <= 0 || p->N <= 0 || p->K <= 0) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: empty problem");
@@ -1044,7 +1097,13 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
     return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: R / R2 have C's element type (r_is_f32 must equal c_is_f32)");
   if (e == UVC_EPI_BIAS_RESID_GATE && (!p->R2 || !p->gate)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: gate epilogue needs R2 and gate");
   if ((e == UVC_EPI_BIAS_GELU || e == UVC_EPI_BIAS_GELU_GRAD) && !p->C2) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: GELU epilogue needs C2");
-  if ((e == UVC_EPI_DGELU || e == UVC_EPI_MUL_AUX) && !p->aux) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dGELU epilogue needs aux");
+  if ((e == UVC_EPI_DGELU || e == UVC_EPI_MUL_AUX || e == UVC_EPI_MUL_AUX_Q8) && !p->aux) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: dGELU epilogue needs aux");
+  const bool q8 = e == UVC_EPI_BIAS_GELU_GRAD_Q8 || e == UVC_EPI_MUL_AUX_Q8;
+  if (e == UVC_EPI_BIAS_GELU_GRAD_Q8 && (!p->bias || !p->C2)) return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: UVC_EPI_BIAS_GELU_GRAD_Q8 needs bias and C2");
+  // the one-byte GELU' code exists in the streaming kernel of DeiT-Tiny's width only (uvc_gemm_nt_q8_supported): N here is the hidden width, K the embed_dim
+  if (q8 && (p->force_generic == 1 || p->a_is_f32 || p->c_is_f32 || p->ln_out || !uvc_gemm_nt_q8_supported(p->M, p->N, p->K, p->dtype) ||
+             (p->ldaux ? p->ldaux : p->ldc) % 8 || p->ldc % 8 || p->ldb != p->K))
+    return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: the one-byte GELU' epilogues need bf16 A / C, K = 192, N % 256 == 0, M >= 4096 (uvc_gemm_nt_q8_supported)");
   NtArgs a;
   a.A = p->A; a.B = p->B; a.C = p->C; a.C2 = p->C2; a.bias = p->bias; a.R = p->R; a.R2 = p->R2; a.aux = p->aux;
   a.dptr = p->gate; a.M = p->M; a.N = p->N; a.K = p->K; a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
@@ -1082,6 +1141,7 @@ extern "C" int uvc_gemm_nt(const uvc_gemm_nt_args* p, void* stream) {
       return p->c_is_f32 ? launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, false, 7, false>(a, st) : launch_wsn16_dma<UVC_EPI_BIAS_RESID, 6, false, 7, true>(a, st);
   }
   const bool ws = !generic && ws_ok(a, p->c_is_f32 ? 4 : 8);
+  if (q8 && !ws) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: the one-byte GELU' epilogues exist in the K = 192 streaming kernel only");
   if (!generic && ws384_ok(a, e, p->c_is_f32 ? 4 : 8, p->a_is_f32 != 0)) {
     if (!p->c_is_f32 && a.N % 128 == 0 && a.N >= 512 && p->force_generic != 5) return launch_ws384<bf16_t, 8>(a, e, st);    // (force_generic == 5: six waves, A/B)
     return p->c_is_f32 ? launch_ws384<float>(a, e, st) : launch_ws384<bf16_t>(a, e, st);

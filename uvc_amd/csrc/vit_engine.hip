@@ -306,6 +306,13 @@ int attn_tok(const Ctx& c, const BlockBufs& b, bool bwd, int layer = -1) {
   a.B = c.d.B; a.N = c.d.N; a.H = c.d.H; a.head_dim = 64; a.ntok = c.d.ntok; a.dtype = c.d.dtype; a.scale = 0.125f;
   return bwd ? uvc_attention_tok_bwd(&a, c.st) : uvc_attention_tok_fwd(&a, c.st);
 }
+// GELU'(a) of this MLP call as one byte per activation (uvc_vit_io.gelu_grad_bf16 = 0; UVC_EPI_BIAS_GELU_GRAD_Q8 / UVC_EPI_MUL_AUX_Q8)?  The same answer in the
+// forward and in the backward: it depends on the call's shape and the io switches only.
+bool gp_q8(const Ctx& c, int rows, int Fe) {
+  if (c.io->gelu_grad_bf16 || c.io->force_generic == 1) return false;
+  if (c.io->fused_train_mlp && uvc_mlp_fused_supported(c.d.D, Fe, c.d.dtype)) return false;      // (that kernel writes bf16 GELU')
+  return uvc_gemm_nt_q8_supported(rows, Fe, c.d.D, c.d.dtype) != 0;
+}
 // token rows of a [B, N, D] tensor (element size esz) -> compact [B, ntok, D], or back
 int gather_tok(const Ctx& c, const void* full, void* compact, size_t esz) {
   return uvc_copy_row_groups(full, compact, c.d.B, (int64_t)c.d.ntok * c.d.D * esz, (int64_t)c.d.N * c.d.D * esz, (int64_t)c.d.ntok * c.d.D * esz, c.st);
@@ -573,7 +580,7 @@ extern "C" int uvc_vit_forward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, voi
     if (!ln2_in_proj) TRY(ln_fwd(c, x1, q[6], q[7], h2, mean2, rstd2, rows, 1, d.D));
     if (io->training)
       // `ga` receives GELU'(pre-activation): that is all the backward needs of it (one multiply in the dgrad epilogue)
-      TRY(nt(c, h2, 0, w1, ga, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_GRAD, b1, nullptr, nullptr, nullptr, nullptr, gu));
+      TRY(nt(c, h2, 0, w1, ga, 0, rows, Fe, d.D, gp_q8(c, rows, Fe) ? UVC_EPI_BIAS_GELU_GRAD_Q8 : UVC_EPI_BIAS_GELU_GRAD, b1, nullptr, nullptr, nullptr, nullptr, gu));
     else   // inference (teacher / eval): the pre-activation is not needed, write GELU(a) only
       TRY(nt(c, h2, 0, w1, gu, 0, rows, Fe, d.D, UVC_EPI_BIAS_GELU_OUT, b1));
     NextLn nl;
@@ -683,14 +690,15 @@ extern "C" int uvc_vit_backward(const uvc_vit_cfg* cfg, const uvc_vit_io* io, vo
     const bool fuse2 = !mc && !tail && lnb_fused_ok(c, d.F);
     c.tn_inline = c.side && l == last_l && !mc;
     if (!mc) {
-      TRY(nt(c, gA, gf, sh(c, so.blk_wt[l][3]), dA, 0, rows, d.F, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, fa, nullptr, nullptr, g1));
+      TRY(nt(c, gA, gf, sh(c, so.blk_wt[l][3]), dA, 0, rows, d.F, d.D, gp_q8(c, rows, d.F) ? UVC_EPI_MUL_AUX_Q8 : UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, fa, nullptr,
+             nullptr, g1));
       TRY(tn(c, gA, gf, fu, G + q[10], G + q[11], rows, d.D, d.F, g1));
       if (!fuse2) TRY(nt(c, dA, 0, sh(c, so.blk_wt[l][2]), dH, 0, rows, d.D, d.F, UVC_EPI_NONE));
       TRY(tn(c, dA, 0, fh2, G + q[8], G + q[9], rows, d.F, d.D));
     } else {
       const int Fe = mc->width;
       if (io->accumulate != 0.f) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_vit_backward: gradient accumulation with MLP compaction");
-      TRY(nt(c, gA, gf, mc->w2t, dA, 0, rows, Fe, d.D, UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, fa, nullptr, nullptr, g1));
+      TRY(nt(c, gA, gf, mc->w2t, dA, 0, rows, Fe, d.D, gp_q8(c, rows, Fe) ? UVC_EPI_MUL_AUX_Q8 : UVC_EPI_MUL_AUX, nullptr, nullptr, nullptr, fa, nullptr, nullptr, g1));
       TRY(tn(c, gA, gf, fu, mc->dw2, G + q[11], rows, d.D, Fe, g1, 0, 0, true));     // db2 goes straight to its place
       TRY(nt(c, dA, 0, mc->w1t, dH, 0, rows, d.D, Fe, UVC_EPI_NONE));
       TRY(tn(c, dA, 0, fh2, mc->dw1, mc->db1, rows, Fe, d.D, nullptr, 0, 0, true));

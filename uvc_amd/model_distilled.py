@@ -56,7 +56,7 @@ class uvc_vit_io(C.Structure):
                 ("accumulate", C.c_float), ("stage_begin", C.c_int32), ("stage_end", C.c_int32), ("side_stream", C.c_void_p),
                 ("mlp_compact", C.c_void_p), ("head_keep", C.c_void_p), ("full_tail", C.c_int32), ("fused_train_mlp", C.c_int32), ("patches_in", C.c_void_p),
                 ("fuse_next_ln", C.c_int32), ("force_generic", C.c_int32), ("head_keep_bwd", C.c_int32), ("shared_bwd_streams", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("gelu_grad_bf16", C.c_int32)]
 
 
 class uvc_mlp_compact(C.Structure):
@@ -68,6 +68,7 @@ class uvc_mlp_compact(C.Structure):
 # computes that block's tail on the token rows only (uvc_vit_io.full_tail = 0; identical outputs and gradients).  UVC_FULL_TAIL=1, or
 # model.full_tail = True, runs every row as the reference does (A/B measurements, tests).
 _FULL_TAIL_DEFAULT = os.environ.get("UVC_FULL_TAIL", "0") not in ("", "0")
+_GELU_GRAD_BF16_DEFAULT = os.environ.get("UVC_GELU_GRAD_BF16", "0") not in ("", "0")   # A/B: GELU'(a) of fc1 in bf16 instead of the one-byte code
 _FUSE_NEXT_LN_DEFAULT = os.environ.get("UVC_FUSE_NEXT_LN", "1") not in ("", "0")       # norm1 of block l+1 written by the kernel that produces its input rows
 # bf16 mode: the residual stream (the rows every block reads and writes) is bf16 like every other activation; UVC_RESID_F32=1 or
 # DistilledVisionTransformer(..., resid_f32=True) keeps the float32 rows of rounds 1-2 (A/B runs).  uvc_vit_cfg.resid_f32.
@@ -568,6 +569,7 @@ class DistilledVisionTransformer(nn.Module):
         io.fused_train_mlp = int(getattr(self, "fused_train_mlp", _FUSED_TRAIN_MLP_DEFAULT))
         io.fuse_next_ln = int(getattr(self, "fuse_next_ln", _FUSE_NEXT_LN_DEFAULT))
         io.force_generic = int(getattr(self, "force_generic", 0))      # tests / A-B runs (uvc_vit_io.force_generic)
+        io.gelu_grad_bf16 = int(getattr(self, "gelu_grad_bf16", _GELU_GRAD_BF16_DEFAULT))      # 1: bf16 GELU'(a) everywhere (uvc_vit_io.gelu_grad_bf16)
         return io
 
     def _ws_view(self, B, training, which):

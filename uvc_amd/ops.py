@@ -9,8 +9,8 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_GRAD, EPI_BIAS_GELU_OUT, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU, EPI_MUL_AUX, EPI_NONE,
-                   UVC_BF16, UVC_F32)
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_GRAD, EPI_BIAS_GELU_GRAD_Q8, EPI_BIAS_GELU_OUT, EPI_BIAS_RESID, EPI_BIAS_RESID_GATE, EPI_DGELU,
+                   EPI_MUL_AUX, EPI_MUL_AUX_Q8, EPI_NONE, Q8_LO, Q8_STEP, UVC_BF16, UVC_F32)
 
 __all__ = ["EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RESID", "EPI_BIAS_RESID_GATE", "EPI_DGELU", "UVC_F32",
            "UVC_BF16"]
@@ -192,6 +192,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, rows, D,
         if t is not None and t.dtype != dx.dtype:
             raise L.UvcHipError("layernorm_bwd: add1/add2 must have dx's element type")
     L.check(L.lib().uvc_layernorm_bwd(C.byref(a), L.cur_stream()), "uvc_layernorm_bwd")
+
+
+def gemm_nt_q8_supported(M, hidden, embed_dim, dtype) -> bool:
+    """Where the one-byte GELU'(a) epilogues exist (EPI_BIAS_GELU_GRAD_Q8 / EPI_MUL_AUX_Q8)."""
+    return bool(L.lib().uvc_gemm_nt_q8_supported(M, hidden, embed_dim, dtype))
 
 
 def gemm_lnbwd_supported(M, D, K, dtype) -> bool:

@@ -178,10 +178,10 @@ def build(B, D=192, H=3, L=12, N=197, with_teacher=True, tail=True, F=None, resi
     # ---- backward, weight-gradient stream (each entry = the split-M GEMM + its fixed-order reduction)
     ws = torch.empty(max(ops.gemm_tn_workspace_bytes(M, F, D), ops.gemm_tn_workspace_bytes(M, D, F), ops.gemm_tn_workspace_bytes(M, 3 * D, D), ops.gemm_tn_workspace_bytes(M, D, D)) // 4, device=dev)
     C1, C2, C3, C4 = torch.empty(D, F, device=dev), torch.empty(F, D, device=dev), torch.empty(D, D, device=dev), torch.empty(3 * D, D, device=dev)
-    add("dW2 (+reduce)", "k_gemm_tn_dma<192, 256", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(g16, hF, C1, ws, dtype=dt))
-    add("dW1 (+reduce)", "k_gemm_tn_dma<256, 192", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(hF, xb, C2, ws, dtype=dt))
-    add("dWproj (+reduce)", "k_gemm_tn<unsigned short", Lf, 2 * u, 2.0 * M * D * D, lambda: ops.gemm_tn(g16, xb, C3, ws, dtype=dt))
-    add("dWqkv (+reduce)", "k_gemm_tn_dma<192, 192", L, 4 * u, 2.0 * M * D * 3 * D, lambda: ops.gemm_tn(q3, xb, C4, ws, dtype=dt))
+    add("dW2 (+reduce)", "k_gemm_tn8p<6, 4" if tiny else "k_gemm_tn", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(g16, hF, C1, ws, dtype=dt))
+    add("dW1 (+reduce)", "k_gemm_tn8p<8, 3" if tiny else "k_gemm_tn", Lf, 5 * u, 2.0 * M * D * F, lambda: ops.gemm_tn(hF, xb, C2, ws, dtype=dt))
+    add("dWproj (+reduce)", "k_gemm_tn_dma<96, 192" if tiny else "k_gemm_tn", Lf, 2 * u, 2.0 * M * D * D, lambda: ops.gemm_tn(g16, xb, C3, ws, dtype=dt))
+    add("dWqkv (+reduce)", "k_gemm_tn8p<6, 3" if tiny else "k_gemm_tn", L, 4 * u, 2.0 * M * D * 3 * D, lambda: ops.gemm_tn(q3, xb, C4, ws, dtype=dt))
     # ---- optimiser
     n = 5717440 if tiny else L * (4 * D * D + 2 * D * F)
     p, gr, m, v = (rn(n) for _ in range(4))

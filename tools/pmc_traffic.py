@@ -33,8 +33,8 @@ NAMES = {
     "dqkv+ln1_bwd": ["k_gemm_wsn_lnbwd_dma<18"],
     "dproj": ["k_gemm_ws<unsigned short, unsigned short, 0"],
     "attn_bwd": ["k_attn_bwd_one", "k_attn_bwd_dq", "k_attn_bwd_dkv"],
-    "dW2 (+reduce)": ["k_gemm_tn_dma<192, 256"],
-    "dW1 (+reduce)": ["k_gemm_tn_dma<256, 192"],
+    "dW2 (+reduce)": ["k_gemm_tn_dma<192, 256", "k_gemm_tn8p<6, 4"],      # (r6: the two-group schedule)
+    "dW1 (+reduce)": ["k_gemm_tn_dma<256, 192", "k_gemm_tn8p<8, 3"],
     "dWproj (+reduce)": ["k_gemm_tn<unsigned short", "k_gemm_tn_dma<96, 192"],
     "dWqkv (+reduce)": ["k_gemm_tn_dma<192, 192", "k_gemm_tn8p<6, 3"],
     "clip+adamw": ["k_adamw"],

@@ -3103,6 +3103,11 @@ __device__ __forceinline__ bf16x8 tr_frag_asm(const char* tile, int ld, int c0, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// Timing probes (tools/tn_probes.sh builds copies of the library with -DUVC_TN_PROBE=n; 0 in the product): 1 = the operand ring only (no fragment reads, no MFMAs),
+// 2 = the compute only (no DMA requests: the stages' LDS images hold whatever they hold), 3 = no partial-tile store.  Wrong results on purpose.
+#ifndef UVC_TN_PROBE
+#define UVC_TN_PROBE 0
+#endif
 template <int B1, int B2, int W1, int W2>
 __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
   typedef bf16_t T;
@@ -3159,6 +3164,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
     }
   }
   auto issue_one = [&](int t, int q) {                   // DMA instruction q of stage t (full stages only: every row is inside the split)
+    if (UVC_TN_PROBE == 2) return;
     const int m0 = mbeg + t * TD_BM;
     char* img = smem_td + (t % TD_NST) * IMG;
     const char* src = (isA[q] ? A : B) + goff[q] + (int64_t)m0 * gstr[q];
@@ -3183,6 +3189,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
   // tn >= 0: the DMA instructions of stage tn go BETWEEN the MFMA rows (their issue cost hides under the matrix pipe; issued as a burst
   // behind the barrier they cost every wave of the lock-stepped workgroup 100-200 cycles each with nothing else to issue)
   auto compute = [&](const char* sA, int tn) {
+    if (UVC_TN_PROBE == 1) {                                 // the ring alone: the next stage's requests, nothing else
+      if (tn >= 0) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) issue_one(tn, q);
+      }
+      return;
+    }
     const char* sB = sA + TD_BM * LD1;
     typename MM::Frag fa[TI], fb[TJ];
 #pragma unroll
@@ -3231,6 +3244,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_dma(TnArgs g) {
     for (int i = 0; i < TI; ++i) g.bpart[(size_t)bz * g.N1 + n10 + w1 * (B1 / W1) + i * 16 + (lane & 15)] = cs[i][0];
   }
   float* P = g.part + (size_t)bz * g.N1 * g.N2;
+  if (UVC_TN_PROBE == 3 && g.M > 0) return;
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int n1 = n10 + w1 * (B1 / W1) + i * 16 + (lane & 15);
@@ -3582,12 +3596,18 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
         UVC_MAX_LDS(sh_, k_gemm_tn_dma<B1_, B2_, W1_, W2_>); \
         k_gemm_tn_dma<B1_, B2_, W1_, W2_><<<grid, 512, sh_, st>>>(a); }
       if (p->a_is_f32) { TN_BIG(float) }           // float32 A (converted on load): register-staged kernel
+      // (r6: these two stood BEHIND the unconditional cfg == 1 / cfg == 2 cases until now, i.e. variant 1 never reached them and the r4 / r6c "equal" were
+      //  the ring kernel measured against itself)
+      // r6: the two-group schedule for the 192 x 256 / 256 x 192 tiles too.  tools/tn_probes.sh on 126 workgroups (profiles/r6h_tn_probes.txt): the ring kernel's
+      // operand ring ALONE 32 us, its compute ALONE (no requests) 60 us of the 68 -- [24 transposing reads | wait | 32 MFMAs] in lock step add up to ~1 900 clocks per
+      // 32-row stage where either half needs ~800; k_gemm_tn8p requests a phase's fragments inside the MFMA block of the phase before: dW2 79.4 -> 64.6 us, dW1
+      // 77.4 -> 60.9 (bit-identical partial tiles).  variant 2: the ring kernel.
+      else if (p->variant != 2 && cfg == 1) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<6, 4>); k_gemm_tn8p<6, 4><<<grid, 512, T8_LDS, st>>>(a); }
+      else if (p->variant != 2 && cfg == 2) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<8, 3>); k_gemm_tn8p<8, 3><<<grid, 512, T8_LDS, st>>>(a); }
       else if (cfg == 1) TN_DMA_ONE(192, 256, 2, 4)
       else if (cfg == 2) TN_DMA_ONE(256, 192, 4, 2)
       else if (cfg == 4) TN_DMA_ONE(96, 192, 2, 4)
       else if (cfg == 5) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<8, 4>); k_gemm_tn8p<8, 4><<<grid, 512, T8_LDS, st>>>(a); }
-      else if (p->variant == 1 && cfg == 1) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<6, 4>); k_gemm_tn8p<6, 4><<<grid, 512, T8_LDS, st>>>(a); }
-      else if (p->variant == 1 && cfg == 2) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<8, 3>); k_gemm_tn8p<8, 3><<<grid, 512, T8_LDS, st>>>(a); }
       // 192 x 192 tiles (dW_qkv of DeiT-Tiny / Small, every block weight of T2T-ViT-14): the two-group schedule by default -- 45.9 -> 40.9 us at
       // 100 864 x 576 x 192, 67.6 -> 55.6 at 50 432 x 1152 x 384, 44 -> 37 on T2T's three shapes; bit-identical partial tiles (variant 2: the ring kernel).
       // The 192 x 256 / 256 x 192 tiles measured equal on both kernels and stay on the ring kernel (variant 1 moves them).

@@ -604,15 +604,25 @@ __global__ __launch_bounds__(64 * WS_NW, (KT > 6 && WS_NW > 6) ? 1 : (NJ == 4 ||
       // instructions as much as by its bytes (8-byte stores of the codes: the step 10.93 -> 10.90 ms where the tensor not written at all gives 10.70,
       // profiles/r6d, r6b).  Lanes l, l ^ 1 hold neighbouring 8-column groups of the SAME two rows (it = 0, 1): the even lane takes both groups of row 0,
       // the odd lane both groups of row 1 (one DPP quad permute per dword).
-      static_assert(IT == 2 && LPR == 8 && RPI == 8, "q8 epilogue: four waves x 64 columns");
       const bool odd = lane & 1;
-      const unsigned s0 = odd ? qc[0][0] : qc[1][0], s1 = odd ? qc[0][1] : qc[1][1];      // what the partner stores: my codes of ITS row
-      const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]: lane ^ 1
-      const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
-      const int m = m0_ + sub_ * 16 + (odd ? RPI : 0) + lane / LPR;
-      if (m < g.M) {
-        const u32x4 o = odd ? u32x4{r0, r1, qc[1][0], qc[1][1]} : u32x4{qc[0][0], qc[0][1], r0, r1};
-        __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(g.C) + (size_t)m * g.ldc + (n & ~15)));
+      if constexpr (IT == 2) {
+        static_assert(LPR == 8 && RPI == 8, "q8 epilogue: four waves x 64 columns");
+        const unsigned s0 = odd ? qc[0][0] : qc[1][0], s1 = odd ? qc[0][1] : qc[1][1];      // what the partner stores: my codes of ITS row
+        const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]: lane ^ 1
+        const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
+        const int m = m0_ + sub_ * 16 + (odd ? RPI : 0) + lane / LPR;
+        if (m < g.M) {
+          const u32x4 o = odd ? u32x4{r0, r1, qc[1][0], qc[1][1]} : u32x4{qc[0][0], qc[0][1], r0, r1};
+          __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(g.C) + (size_t)m * g.ldc + (n & ~15)));
+        }
+      } else {
+        // eight waves x 32 columns: one row per lane and sub-tile; the even lane of a pair stores both 8-column groups of the row
+        static_assert(IT == 1 && LPR == 4, "q8 epilogue: eight waves x 32 columns");
+        const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)qc[0][0], 0xB1, 0xF, 0xF, true);
+        const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)qc[0][1], 0xB1, 0xF, 0xF, true);
+        const int m = m0_ + sub_ * 16 + lane / LPR;
+        if (m < g.M && !odd)
+          __builtin_nontemporal_store(u32x4{qc[0][0], qc[0][1], r0, r1}, reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(g.C) + (size_t)m * g.ldc + n));
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -717,7 +727,7 @@ static int launch_ws_narrow(const NtArgs& a, int epi, hipStream_t st) {      // 
   const int grid = nslots * ngroups;
 #define WS_CASE(E) case E: k_gemm_ws<TA, TC, E, KT, 8, 2><<<grid, 512, 0, st>>>(a, ngroups, nslots); break;
   switch (epi) {
-    WS_CASE(UVC_EPI_DGELU) WS_CASE(UVC_EPI_MUL_AUX) WS_CASE(UVC_EPI_MUL_AUX_Q8)
+    WS_CASE(UVC_EPI_DGELU) WS_CASE(UVC_EPI_MUL_AUX) WS_CASE(UVC_EPI_MUL_AUX_Q8) WS_CASE(UVC_EPI_BIAS_GELU_GRAD_Q8)
     default: return uvc_set_error_msg(UVC_ERR_ARG, "uvc_gemm_nt: epilogue");
   }
 #undef WS_CASE
@@ -730,6 +740,9 @@ static int launch_ws(const NtArgs& a, int epi, hipStream_t st) {
   // the forward's GELU epilogues are VALU-bound either way and stay on the 64-column tiling
   if constexpr (sizeof(TC) == 2 && sizeof(TA) == 2) {
     if (a.N % 256 == 0 && a.K == 192 && (epi == UVC_EPI_DGELU || epi == UVC_EPI_MUL_AUX || epi == UVC_EPI_MUL_AUX_Q8)) return launch_ws_narrow<TA, TC, 6>(a, epi, st);
+#ifdef UVC_FC1_NARROW        // A/B build: fc1 + GELU, GELU' (one-byte code) on eight waves x 32 columns (109 us against 84, the step 11.07 against 10.64 ms: not kept, profiles/r6j_ab_fc1_narrow_not_kept.txt)
+    if (a.N % 256 == 0 && a.K == 192 && epi == UVC_EPI_BIAS_GELU_GRAD_Q8) return launch_ws_narrow<TA, TC, 6>(a, epi, st);
+#endif
   }
   if (epi == UVC_EPI_MUL_AUX_Q8) return uvc_set_error_msg(UVC_ERR_UNSUPPORTED, "uvc_gemm_nt: UVC_EPI_MUL_AUX_Q8 outside uvc_gemm_nt_q8_supported");
   // 4 waves (256 columns) per workgroup when N divides: more waves per CU to overlap the GELU epilogues
@@ -3527,7 +3540,11 @@ static int tn_splits(int M, int N1, int N2, int cfg) {
     // The wider models keep the whole chip: DeiT-Small 15.6 -> 16.7 ms and DeiT-Base 23.4 -> 24.5 at 128 (192: +- 0 / -0.7 %), T2T-ViT-14 +0.7 %.
     // Measured again once the side stream had become the backward's critical path (one event per block, vit_engine.hip): 128 / 160 / 192 / 256 workgroups
     // 11.14 / 11.18 / 11.23 / 11.44 ms (profiles/r5z_ab_wgrad_targets.txt).
-    target = tiles <= 4 ? 128 : 256;
+    // (r6, with the two-group schedule for these tiles: 96 / 128 / 192 / 256 workgroups measured again, profiles/r6i_ab_wgrad_targets.txt)
+#ifndef UVC_TN_TARGET_FEW
+#define UVC_TN_TARGET_FEW 128
+#endif
+    target = tiles <= 4 ? UVC_TN_TARGET_FEW : 256;
   }
   int splits = cfg == 0 ? ceil_div(target, tiles) : target / tiles;       // big tiles: one workgroup per CU (LDS), so at most 256 of them -- one more is a second round
   const int max_splits = ceil_div(M, TN_BM);

@@ -449,6 +449,10 @@ def main():
                 "step_tflops_per_gpu": round(imgs / world * gf / 1e3, 2) if gf else None,
                 "step_frac_of_bf16_mfma_peak": round(imgs / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None,
                 "residual_stream": "float32" if (args.precision != "bf16" or os.environ.get("UVC_RESID_F32", "0") not in ("", "0")) else "bf16",
+                # what fc1 leaves for the backward (r6): GELU(a) in bf16 (an MFMA operand of fc2 and dW2) and GELU'(a) as one byte per activation where the streaming
+                # kernel of DeiT-Tiny's width runs (uvc_vit_io.gelu_grad_bf16 = 0; include/uvc_kernels.h: uniform code over [-0.13, 1.13], |error| <= 2.47e-3)
+                "hidden_tensors": ("GELU(a) bf16 + GELU'(a) one byte (uniform code, |err| <= 2.47e-3)" if (args.precision == "bf16" and tiny and args.batch * 197 >= 4096
+                                    and os.environ.get("UVC_GELU_GRAD_BF16", "0") in ("", "0")) else "GELU(a), GELU'(a) in the compute dtype"),
                 "final_loss": round(loss, 4)}
         if args.stage == 1:
             line["cur_resource"] = round(float(out["cur"]), 4)

@@ -11,14 +11,17 @@ from uvc_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 D, F, N = 192, 768, 197
+VARIANTS = (0, 1, 2)
+if len(sys.argv) > 2 and sys.argv[2] == "base":       # DeiT-Base widths: 256 x 256 tiles (variant 0) against 128 x 256 (variant 3)
+    D, F, N, VARIANTS = 768, 3072, 198, (0, 3)
 M = B * N
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(1)
 rn = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
 gD, hF, xD, q3 = rn(M, D), rn(M, F), rn(M, D), rn(M, 3 * D)
 ws = torch.empty(max(ops.gemm_tn_workspace_bytes(M, F, D), ops.gemm_tn_workspace_bytes(M, D, F), ops.gemm_tn_workspace_bytes(M, 3 * D, D)) // 4, device=dev)
-shapes = {"dW2 [192 x 768]": (gD, hF, torch.empty(D, F, device=dev)), "dW1 [768 x 192]": (hF, xD, torch.empty(F, D, device=dev)),
-          "dWqkv [576 x 192]": (q3, xD, torch.empty(3 * D, D, device=dev)), "dWproj [192 x 192]": (gD, xD, torch.empty(D, D, device=dev))}
+shapes = {f"dW2 [{D} x {F}]": (gD, hF, torch.empty(D, F, device=dev)), f"dW1 [{F} x {D}]": (hF, xD, torch.empty(F, D, device=dev)),
+          f"dWqkv [{3 * D} x {D}]": (q3, xD, torch.empty(3 * D, D, device=dev)), f"dWproj [{D} x {D}]": (gD, xD, torch.empty(D, D, device=dev))}
 
 
 def t(fn, iters=30):
@@ -33,10 +36,10 @@ def t(fn, iters=30):
 
 
 ref = {}
-print(f"# DeiT-Tiny batch {B}: M = {M}; us per launch (GEMM + reduce), back to back on one stream")
+print(f"# D = {D}, batch {B}: M = {M}; us per launch (GEMM + reduce), back to back on one stream")
 for name, (A, Bm, C) in shapes.items():
     row = []
-    for v in (0, 1, 2):
+    for v in VARIANTS:
         us = t(lambda: ops.gemm_tn(A, Bm, C, ws, dtype=ops.UVC_BF16, variant=v))
         torch.cuda.synchronize()
         if v == 0:

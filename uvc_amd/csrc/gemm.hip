@@ -3527,7 +3527,7 @@ static int tn_config(int N1, int N2) {
   if (N1 == 192 && N2 == 192) return 4;       // dW_proj of DeiT-Tiny: two 96x192 tiles x 128 splits (the generic kernel ran it at 1.75 TB/s)
   return 0;
 }
-static void tn_tile(int cfg, int& b1, int& b2) { b1 = (cfg == 2 || cfg == 5) ? 256 : cfg == 4 ? 96 : 192; b2 = (cfg == 1 || cfg == 5) ? 256 : 192; }
+static void tn_tile(int cfg, int& b1, int& b2) { b1 = (cfg == 2 || cfg == 5) ? 256 : cfg == 4 ? 96 : cfg == 6 ? 128 : 192; b2 = (cfg == 1 || cfg == 5 || cfg == 6) ? 256 : 192; }
 static int tn_splits(int M, int N1, int N2, int cfg) {
   int tiles, target;
   if (cfg == 0) { tiles = ceil_div(N1, TN_B1) * ceil_div(N2, TN_B2); target = 768; }
@@ -3581,6 +3581,9 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   // the 256 x 256 kernel addresses its operands with 32-bit buffer offsets: beyond 2 GB the problem goes to the generic kernel (64-bit
   // addresses; the workspace is sized for either, see uvc_gemm_tn_workspace_bytes) -- checked on the configuration that will RUN
   if (cfg == 5 && (size_t)(p->M + 256) * (p->lda > p->ldb ? p->lda : p->ldb) * 2 >= (1ull << 31)) cfg = 0;
+  // variant 3 (A/B, r6): 128 x 256 tiles for the shapes that take 256 x 256 -- twice the tiles, half the splits: half the float32 partial bytes (DeiT-Base dW1: 66 -> 28 MB
+  // written and read back per launch) for 25 % fewer MFMAs per fragment read
+  if (cfg == 5 && p->variant == 3) cfg = 6;
   splits = tn_splits(p->M, p->N1, p->N2, cfg);
   TnArgs a;
   a.A = p->A; a.B = p->B; a.part = (float*)p->workspace; a.M = p->M; a.N1 = p->N1; a.N2 = p->N2; a.lda = p->lda; a.ldb = p->ldb;
@@ -3625,6 +3628,7 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
       else if (cfg == 2) TN_DMA_ONE(256, 192, 4, 2)
       else if (cfg == 4) TN_DMA_ONE(96, 192, 2, 4)
       else if (cfg == 5) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<8, 4>); k_gemm_tn8p<8, 4><<<grid, 512, T8_LDS, st>>>(a); }
+      else if (cfg == 6) { UVC_MAX_LDS(T8_LDS, k_gemm_tn8p<4, 4>); k_gemm_tn8p<4, 4><<<grid, 512, T8_LDS, st>>>(a); }
       // 192 x 192 tiles (dW_qkv of DeiT-Tiny / Small, every block weight of T2T-ViT-14): the two-group schedule by default -- 45.9 -> 40.9 us at
       // 100 864 x 576 x 192, 67.6 -> 55.6 at 50 432 x 1152 x 384, 44 -> 37 on T2T's three shapes; bit-identical partial tiles (variant 2: the ring kernel).
       // The 192 x 256 / 256 x 192 tiles measured equal on both kernels and stay on the ring kernel (variant 1 moves them).

@@ -94,7 +94,7 @@ typedef struct uvc_gemm_tn_args {
   int32_t dtype, a_is_f32;
   int32_t variant;     /* tuning / A-B: 0 (and 1) = kernel picked by shape -- since r6 the two-group schedule (k_gemm_tn8p) for every 192- / 256-wide tile but
                           the 96 x 192 one; 2 = the LDS-DMA ring kernel (k_gemm_tn_dma) for the 192 x 192, 192 x 256 and 256 x 192 tiles.  All of them write
-                          the same bits */
+                          the same bits.  3 = 128 x 256 tiles where the shape takes 256 x 256 (half the splits: another summation order) */
 } uvc_gemm_tn_args;
 int uvc_gemm_tn(const uvc_gemm_tn_args* args, void* stream);
 int uvc_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2, int64_t* bytes, int32_t* splits);

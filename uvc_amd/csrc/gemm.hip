@@ -3582,7 +3582,8 @@ extern "C" int uvc_gemm_tn(const uvc_gemm_tn_args* p, void* stream) {
   // addresses; the workspace is sized for either, see uvc_gemm_tn_workspace_bytes) -- checked on the configuration that will RUN
   if (cfg == 5 && (size_t)(p->M + 256) * (p->lda > p->ldb ? p->lda : p->ldb) * 2 >= (1ull << 31)) cfg = 0;
   // variant 3 (A/B, r6): 128 x 256 tiles for the shapes that take 256 x 256 -- twice the tiles, half the splits: half the float32 partial bytes (DeiT-Base dW1: 66 -> 28 MB
-  // written and read back per launch) for 25 % fewer MFMAs per fragment read
+  // written and read back per launch) for 25 % fewer MFMAs per fragment read.  Measured (profiles/r6n_tn_variants_base.txt, GEMM + reduce, M = 25 344): dW2 141.9 -> 168.1 us,
+  // dW1 131.3 -> 154.2, dWqkv 98.4 -> 110.8, dWproj 49.4 -> 44.6: not the default
   if (cfg == 5 && p->variant == 3) cfg = 6;
   splits = tn_splits(p->M, p->N1, p->N2, cfg);
   TnArgs a;

@@ -663,7 +663,12 @@ template <typename TA, typename TC, int KT, int WS_NW>
 static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
   const int ngroups = ceil_div(a.N, 64 * WS_NW);
   const int ntiles = ceil_div(a.M, WS_BM);
-  int nslots = (512 / ngroups) & ~7;                       // ~2 workgroups per CU in total, slots a multiple of the 8 XCDs (r5: these main-stream kernels on 224 / 192 CUs: +1 % step time, profiles/r5u)
+  // (r6: more, shorter workgroups -- 4 / 8 per CU in total, so that the dispatcher hands tiles to whichever CU is free beside the weight-gradient stream -- measured:
+  //  profiles/r6o_ab_ws_slots.txt; -DUVC_WS_WG_TOTAL=1024 / 2048 builds)
+#ifndef UVC_WS_WG_TOTAL
+#define UVC_WS_WG_TOTAL 512
+#endif
+  int nslots = (UVC_WS_WG_TOTAL / ngroups) & ~7;           // ~2 workgroups per CU in total, slots a multiple of the 8 XCDs (r5: these main-stream kernels on 224 / 192 CUs: +1 % step time, profiles/r5u)
   if (nslots < 8) nslots = 8;
   if (nslots > ((ntiles + 7) & ~7)) nslots = (ntiles + 7) & ~7;
   const int grid = nslots * ngroups;
@@ -721,7 +726,7 @@ template <typename TA, typename TC, int KT>
 static int launch_ws_narrow(const NtArgs& a, int epi, hipStream_t st) {      // 8 waves x 32 columns
   const int ngroups = ceil_div(a.N, 256);
   const int ntiles = ceil_div(a.M, WS_BM);
-  int nslots = (512 / ngroups) & ~7;
+  int nslots = (UVC_WS_WG_TOTAL / ngroups) & ~7;
   if (nslots < 8) nslots = 8;
   if (nslots > ((ntiles + 7) & ~7)) nslots = (ntiles + 7) & ~7;
   const int grid = nslots * ngroups;

@@ -664,7 +664,7 @@ static int launch_ws_epi(const NtArgs& a, int epi, hipStream_t st) {
   const int ngroups = ceil_div(a.N, 64 * WS_NW);
   const int ntiles = ceil_div(a.M, WS_BM);
   // (r6: more, shorter workgroups -- 4 / 8 per CU in total, so that the dispatcher hands tiles to whichever CU is free beside the weight-gradient stream -- measured:
-  //  profiles/r6o_ab_ws_slots.txt; -DUVC_WS_WG_TOTAL=1024 / 2048 builds)
+  //  1024 / 2048 in total: +0.10 / +0.15 ms in the step, profiles/r6o_ab_ws_slots_not_kept.txt; -DUVC_WS_WG_TOTAL builds)
 #ifndef UVC_WS_WG_TOTAL
 #define UVC_WS_WG_TOTAL 512
 #endif

@@ -10,22 +10,21 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wno-unused-value -Wno-unused-result -I$R/include -I$R/uvc_amd/csrc"
 S='c.io->training'; D='c.d.D'; F='c.d.F'
 declare -A V
-V[s_qkv]="-DPROBE_NT=($S&&N==3*$D&&K==$D&&(epi==UVC_EPI_BIAS||epi==UVC_EPI_NONE)&&a_f32==0&&M==c.d.M)"
-V[t_qkv]="-DPROBE_NT=(!$S&&N==3*$D&&K==$D)"
-V[s_attn_fwd]="-DPROBE_ATTN=($S&&!bwd)"
-V[t_attn_fwd]="-DPROBE_ATTN=(!$S&&!bwd)"
+# (r6: the qkv Linear + attention forward of every block but the last are ONE kernel since r5, k_qkv_attn_fwd)
+V[s_qkvattn]="-DPROBE_QA=(io->training)"
+V[t_qkvattn]="-DPROBE_QA=(!io->training)"
 V[s_proj]="-DPROBE_NT=($S&&N==$D&&K==$D&&epi==UVC_EPI_BIAS_RESID)"
 V[t_proj]="-DPROBE_NT=(!$S&&N==$D&&K==$D&&epi==UVC_EPI_BIAS_RESID)"
-V[s_fc1]="-DPROBE_NT=(epi==UVC_EPI_BIAS_GELU_GRAD)"
+V[s_fc1]="-DPROBE_NT=(epi==UVC_EPI_BIAS_GELU_GRAD||epi==UVC_EPI_BIAS_GELU_GRAD_Q8)"
 V[s_fc2]="-DPROBE_NT=($S&&K==$F&&N==$D&&(epi==UVC_EPI_BIAS_RESID||epi==UVC_EPI_BIAS_RESID_GATE))"
 V[t_mlp]="-DPROBE_MLP=(!io->training)"
-V[dfc2]="-DPROBE_NT=(epi==UVC_EPI_MUL_AUX)"
+V[dfc2]="-DPROBE_NT=(epi==UVC_EPI_MUL_AUX||epi==UVC_EPI_MUL_AUX_Q8)"
 V[dfc1_ln]="-DPROBE_LNB=(K==$F)"
 V[dproj]="-DPROBE_NT=($S&&epi==UVC_EPI_NONE&&N==$D&&K==$D&&M==c.d.M)"
 V[attn_bwd]="-DPROBE_ATTN=(bwd)"
 V[dqkv_ln]="-DPROBE_LNB=(K==3*$D)"
 V[wgrads]="-DPROBE_TN=1"
-ORDER="s_qkv s_attn_fwd s_proj s_fc1 s_fc2 t_qkv t_attn_fwd t_proj t_mlp dfc2 dfc1_ln dproj attn_bwd dqkv_ln wgrads"
+ORDER="s_qkvattn s_proj s_fc1 s_fc2 t_qkvattn t_proj t_mlp dfc2 dfc1_ln dproj attn_bwd dqkv_ln wgrads"
 if [ "${1:-}" = build ]; then
   python -m uvc_amd.build > /dev/null || exit 1
   mkdir -p /tmp/perturb "$R/tools/perturb"
@@ -37,12 +36,14 @@ def ins(after, text):
     global s
     assert s.count(after) == 1, after
     s = s.replace(after, after + text)
-s = s.replace('#include "common.h"', '#include "%s/uvc_amd/csrc/common.h"\n#ifndef PROBE_NT\n#define PROBE_NT 0\n#endif\n#ifndef PROBE_TN\n#define PROBE_TN 0\n#endif\n#ifndef PROBE_ATTN\n#define PROBE_ATTN 0\n#endif\n#ifndef PROBE_LNB\n#define PROBE_LNB 0\n#endif\n#ifndef PROBE_MLP\n#define PROBE_MLP 0\n#endif' % R)
+s = s.replace('#include "common.h"', '#include "%s/uvc_amd/csrc/common.h"\n#ifndef PROBE_NT\n#define PROBE_NT 0\n#endif\n#ifndef PROBE_TN\n#define PROBE_TN 0\n#endif\n#ifndef PROBE_ATTN\n#define PROBE_ATTN 0\n#endif\n#ifndef PROBE_LNB\n#define PROBE_LNB 0\n#endif\n#ifndef PROBE_MLP\n#define PROBE_MLP 0\n#endif\n#ifndef PROBE_QA\n#define PROBE_QA 0\n#endif' % R)
 s = s.replace('#include "../../include/', '#include "%s/include/' % R)
 ins('       const float* alpha_ptr = nullptr, int lda = 0, int ldc = 0, const NextLn* ln = nullptr) {\n', '  if (PROBE_NT) return UVC_OK;\n')
-ins('       int lda = 0, int ldb = 0, int buf = BUF_OTHER, bool scratch = false) {\n', '  if (PROBE_TN) return UVC_OK;\n')
+ins('       int lda = 0, int ldb = 0, bool scratch = false) {\n', '  if (PROBE_TN) return UVC_OK;\n')
 ins('                 const void* add1, const float* a1, const void* add2, const float* a2, float* dots) {\n', '  if (PROBE_LNB) return UVC_OK;\n')
 ins('int attn(const Ctx& c, const BlockBufs& b, bool bwd, int layer = -1) {\n', '  if (PROBE_ATTN) return UVC_OK;\n')
+assert s.count('      TRY(uvc_qkv_attention_fwd(&qa, c.st));') == 1
+s = s.replace('      TRY(uvc_qkv_attention_fwd(&qa, c.st));', '      if (!(PROBE_QA)) TRY(uvc_qkv_attention_fwd(&qa, c.st));')
 assert s.count('      TRY(uvc_mlp_fused_fwd(&m, c.st));') == 1
 s = s.replace('      TRY(uvc_mlp_fused_fwd(&m, c.st));', '      if (!(PROBE_MLP)) TRY(uvc_mlp_fused_fwd(&m, c.st));')
 open(sys.argv[2], 'w').write(s)
